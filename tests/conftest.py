@@ -1,0 +1,43 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+GOLDEN = os.path.join(REPO, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+
+
+def pytest_collection_modifyitems(config, items):
+    """GPU tests are skipped (not failed) when no device is visible."""
+    import torch
+    if torch.cuda.is_available():
+        return
+    skip = pytest.mark.skip(reason="no GPU in this container")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
+@pytest.fixture(scope="session")
+def golden():
+    def _load(name):
+        return dict(np.load(os.path.join(GOLDEN, name + ".npz")))
+    return _load
+
+
+def rel_err(a, ref):
+    """max |a-ref| / max |ref|  -- the tolerance metric used throughout
+    (element-wise relative error is ill-conditioned for near-zero correlation
+    outputs; SURVEY.md section 7 'hard parts' #1)."""
+    a = np.asarray(a, dtype=np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
+    denom = np.abs(ref).max()
+    return float(np.abs(a - ref).max() / (denom if denom > 0 else 1.0))

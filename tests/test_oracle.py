@@ -1,0 +1,178 @@
+"""Oracle pinning (CPU): the restatements under oracle/ against the golden
+vectors captured from the reference's own Python (tools/gen_golden.py)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err
+import oracle
+from cerberusnet_amd.synth import hash_uniform, W32_PYRAMID_1024x512
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d"])
+def test_c_oracle_matches_reference_correlationtorch(golden, tag):
+    g = golden("corr_" + tag)
+    d = int(g["d"])
+    out = oracle.corr_forward_ref(g["x1"], g["x2"], d, 1, d, 1, 1)
+    assert out.shape == g["out"].shape
+    assert rel_err(out, g["out64"]) < 1e-6
+    g1, g2 = oracle.corr_backward_ref(g["x1"], g["x2"], g["gout"], d, 1, d, 1, 1)
+    assert rel_err(g1, g["g1_64"]) < 1e-6
+    assert rel_err(g2, g["g2_64"]) < 1e-6
+    # and the reference's own fp32 result sits within fp32 rounding of both
+    assert rel_err(g["out"], g["out64"]) < 1e-6
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d"])
+def test_c_oracle_fp64_is_tight(golden, tag):
+    g = golden("corr_" + tag)
+    d = int(g["d"])
+    x1, x2, go = (g[k].astype(np.float64) for k in ("x1", "x2", "gout"))
+    out = oracle.corr_forward_ref(x1, x2, d, 1, d, 1, 1)
+    g1, g2 = oracle.corr_backward_ref(x1, x2, go, d, 1, d, 1, 1)
+    assert rel_err(out, g["out64"]) < 1e-14
+    assert rel_err(g1, g["g1_64"]) < 1e-14
+    assert rel_err(g2, g["g2_64"]) < 1e-14
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d"])
+def test_torch_restatement_matches_reference(golden, tag):
+    g = golden("corr_" + tag)
+    d = int(g["d"])
+    x1 = torch.from_numpy(g["x1"]).requires_grad_(True)
+    x2 = torch.from_numpy(g["x2"]).requires_grad_(True)
+    out = oracle.correlation_torch_ref(x1, x2, d)
+    # same op sequence on the same torch build -> bit-identical
+    assert np.array_equal(out.detach().numpy(), g["out"])
+    g1, g2 = torch.autograd.grad(out, (x1, x2), torch.from_numpy(g["gout"]))
+    assert rel_err(g1.numpy(), g["g1"]) < 1e-6
+    assert rel_err(g2.numpy(), g["g2"]) < 1e-6
+
+
+def test_fullsize_checksums_config1_and_pyramid(golden):
+    """Config-1 tensor and the four config-3 level shapes, inputs regenerated
+    from the portable hash generator, outputs vs the reference's checksums."""
+    g = golden("fullsize")
+    shapes = {"cfg1": (1, 64, 64, 128)}
+    for lvl, (C, H, W) in enumerate(W32_PYRAMID_1024x512):
+        shapes["L%d" % lvl] = (1, C, H, W)
+    for name, shp in shapes.items():
+        assert tuple(g[name + "_shape"]) == shp
+        B, C, H, W = shp
+        x1 = hash_uniform(shp, 0)
+        x2 = hash_uniform(shp, 1)
+        go = hash_uniform((B, 81, H, W), 2)
+        out = oracle.corr_forward_ref(x1, x2, 4, 1, 4, 1, 1)
+        g1, g2 = oracle.corr_backward_ref(x1, x2, go, 4, 1, 4, 1, 1)
+        for key, arr in (("out", out), ("g1", g1), ("g2", g2)):
+            amax = float(g["%s_%s_absmax" % (name, key)])
+            idx = g["%s_%s_idx" % (name, key)]
+            val = g["%s_%s_val" % (name, key)]
+            got = arr.reshape(-1)[idx]
+            assert np.abs(got - val).max() <= 2e-6 * amax, (name, key)
+            a64 = arr.astype(np.float64)
+            assert abs(a64.sum() - g["%s_%s_sum" % (name, key)]) <= \
+                1e-6 * amax * np.sqrt(a64.size) + 1e-9
+            assert abs((a64 * a64).sum() - g["%s_%s_sumsq" % (name, key)]) <= \
+                1e-5 * g["%s_%s_sumsq" % (name, key)]
+
+
+# ------------------------------------------------------------------ general
+# parameters: no executable reference -> self-consistency only (UNPINNED)
+@pytest.mark.parametrize("pad,k,d,s1,s2", [
+    (4, 1, 4, 1, 1), (3, 3, 4, 1, 2), (5, 3, 4, 1, 1), (2, 1, 4, 1, 1),
+    (4, 1, 10, 1, 1), (6, 1, 6, 1, 3), (3, 3, 20, 1, 2)])
+def test_backward_is_gradient_of_forward_fp64(pad, k, d, s1, s2):
+    rng = np.random.default_rng(7)
+    need = 2 * ((k - 1) // 2 + d) - 2 * pad
+    B, C, H, W = 1, 3, max(9, need + 5), max(8, need + 6)
+    try:
+        oC, oH, oW = oracle.corr_out_shape(B, C, H, W, pad, k, d, s1, s2)
+    except RuntimeError:
+        pytest.skip("empty output for this geometry")
+    x1 = rng.standard_normal((B, C, H, W))
+    x2 = rng.standard_normal((B, C, H, W))
+    go = rng.standard_normal((B, oC, oH, oW))
+    g1, g2 = oracle.corr_backward_ref(x1, x2, go, pad, k, d, s1, s2)
+    # the op is bilinear in (x1, x2): directional derivatives are exact
+    for which, grad in ((0, g1), (1, g2)):
+        direction = rng.standard_normal((B, C, H, W))
+        if which == 0:
+            delta = oracle.corr_forward_ref(direction, x2, pad, k, d, s1, s2)
+        else:
+            delta = oracle.corr_forward_ref(x1, direction, pad, k, d, s1, s2)
+        lhs = float((delta * go).sum())
+        rhs = float((grad * direction).sum())
+        assert abs(lhs - rhs) <= 1e-10 * max(1.0, abs(lhs)), (which, lhs, rhs)
+
+
+def test_forward_stride1_2_shape_and_values():
+    """stride1 > 1 is forward-only (Q4): output is the s1=1 output subsampled."""
+    rng = np.random.default_rng(3)
+    x1 = rng.standard_normal((1, 4, 10, 12)).astype(np.float32)
+    x2 = rng.standard_normal((1, 4, 10, 12)).astype(np.float32)
+    full = oracle.corr_forward_ref(x1, x2, 4, 1, 4, 1, 1)
+    sub = oracle.corr_forward_ref(x1, x2, 4, 1, 4, 2, 1)
+    assert sub.shape == (1, 81, 5, 6)
+    assert np.array_equal(sub, full[:, :, ::2, ::2])
+    with pytest.raises(RuntimeError):
+        oracle.corr_backward_ref(x1, x2, sub, 4, 1, 4, 2, 1)
+
+
+def test_out_shape_rules():
+    # correlation_cuda.cpp:6-14
+    assert oracle.corr_out_shape(1, 8, 16, 32, 4, 1, 4, 1, 1) == (81, 16, 32)
+    assert oracle.corr_out_shape(1, 8, 16, 32, 4, 1, 10, 1, 1) == (441, 4, 20)
+    assert oracle.corr_out_shape(1, 8, 64, 64, 3, 3, 20, 1, 2) == (441, 28, 28)
+    assert oracle.corr_out_shape(2, 8, 17, 33, 4, 1, 4, 2, 2) == (25, 9, 17)
+
+
+# ------------------------------------------------------------------ flow_warp
+@pytest.mark.parametrize("tag", ["a", "b"])
+@pytest.mark.parametrize("pad", ["border", "zeros"])
+def test_warp_oracles_match_reference(golden, tag, pad):
+    g = golden("warp_" + tag)
+    img, flo, go = (torch.from_numpy(g[k]) for k in ("image", "flow", "gout"))
+    out, gi, gf = oracle.flow_warp_grads_ref(img, flo, go, pad)
+    assert np.array_equal(out.numpy(), g["out_" + pad])
+    assert rel_err(gi.numpy(), g["gimage_" + pad]) < 1e-6
+    assert rel_err(gf.numpy(), g["gflow_" + pad]) < 1e-6
+    near = oracle.flow_warp_ref(img, flo, pad, "nearest")
+    assert np.array_equal(near.numpy(), g["nearest_" + pad])
+    # independent numpy restatement of ATen's algorithm
+    out_np = oracle.flow_warp_numpy(g["image"], g["flow"], pad)
+    assert rel_err(out_np, g["out_" + pad]) < 2e-6
+    near_np = oracle.flow_warp_numpy(g["image"], g["flow"], pad, "nearest")
+    assert rel_err(near_np, g["nearest_" + pad]) < 1e-7
+    gi_np, gf_np = oracle.flow_warp_numpy_grads(g["image"], g["flow"],
+                                                g["gout"], pad)
+    assert rel_err(gi_np, g["gimage_" + pad]) < 2e-6
+    assert rel_err(gf_np, g["gflow_" + pad]) < 2e-5
+
+
+def test_warp_q2_zero_flow_is_not_identity(golden):
+    g = golden("warp_q2")
+    out = oracle.flow_warp_ref(torch.from_numpy(g["image"]),
+                               torch.zeros(1, 2, 4, 6))
+    assert np.array_equal(out.numpy(), g["out"])
+    assert abs(float(g["out"][0, 0, 0, 1]) - 0.7) < 1e-5  # not 1.0
+    out_np = oracle.flow_warp_numpy(g["image"], np.zeros((1, 2, 4, 6), np.float32))
+    assert rel_err(out_np, g["out"]) < 1e-6
+
+
+def test_warp_numpy_fp64_agrees_with_torch_fp64():
+    rng = np.random.default_rng(11)
+    img = rng.standard_normal((2, 4, 9, 13))
+    flo = rng.uniform(-6, 6, (2, 2, 9, 13))
+    go = rng.standard_normal((2, 4, 9, 13))
+    for pad in ("border", "zeros"):
+        out, gi, gf = oracle.flow_warp_grads_ref(
+            torch.from_numpy(img), torch.from_numpy(flo), torch.from_numpy(go), pad)
+        assert rel_err(oracle.flow_warp_numpy(img, flo, pad), out.numpy()) < 1e-13
+        gi_np, gf_np = oracle.flow_warp_numpy_grads(img, flo, go, pad)
+        assert rel_err(gi_np, gi.numpy()) < 1e-13
+        assert rel_err(gf_np, gf.numpy()) < 1e-12
+    refl = oracle.flow_warp_ref(torch.from_numpy(img), torch.from_numpy(flo),
+                                "reflection")
+    assert rel_err(oracle.flow_warp_numpy(img, flo, "reflection"),
+                   refl.numpy()) < 1e-13
