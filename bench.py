@@ -1,0 +1,309 @@
+#!/usr/bin/env python3
+"""Headline benchmark: image-pairs/s of the correlation + flow-warp hot path,
+forward + backward, on the HRNetV2-W32 feature pyramid of a 1024x512 frame pair.
+
+    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torchrun)
+
+One "step" = the hot path of one training iteration over a batch of `--pairs`
+image pairs (default 4 per GPU, BASELINE config 4's per-GPU batch; the tensors
+are BASELINE config 3's: W32 pyramid, 1024x512, d=4, fp32): for both flow
+directions and all four pyramid levels, in the order PWCNetHead issues them
+(reference pwcnet_sfd.py:171-197, cerberus.py:131,135):
+
+    forward : [flow_warp(f2, flow)] -> correlation(f1, warped)          (L0 has no warp)
+    backward: correlation_backward -> [flow_warp_backward]
+
+Inputs are synthetic (portable hash generator), resident in HBM before the
+timed region.  The timed region replays the whole step from a hipGraph
+(captured through torch.cuda.CUDAGraph; --no-graph launches eagerly).
+
+The JSON line also carries
+  roofline     : achieved algorithmic GB/s of the dominant kernel, measured
+                 live with HIP events on the launch stream, vs the 8 TB/s HBM peak
+  cpu_baseline : the reference's pure-PyTorch CPU correlation (oracle port of
+                 CorrelationTorch, correlation.py:4-21) fwd+bwd on the same
+                 pyramid, timed on this box's host cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+METRIC = "image-pairs/sec fwd+bwd @1024×512 d=4; correlation HBM GB/s vs roofline"
+CORR_P = (4, 1, 4, 1, 1, 1)  # pad, k, d, s1, s2, corr_type_multiply (pwcnet_sfd.py:131-133)
+
+
+def corr_bytes(C, B, H, W, e=4):
+    """ALGORITHMIC bytes: fwd (2C+81)BHWe, bwd (4C+81)BHWe."""
+    return (2 * C + 81) * B * H * W * e, (4 * C + 81) * B * H * W * e
+
+
+def warp_bytes(C, B, H, W, e=4):
+    return (2 * C + 2) * B * H * W * e, (3 * C + 4) * B * H * W * e
+
+
+class Workload:
+    """Device-resident tensors of one step + the op sequence."""
+
+    def __init__(self, pairs, width, height, device):
+        from cerberusnet_amd.synth import hash_uniform, pyramid_shapes
+        import cerberusnet_amd  # noqa: F401  registers torch.ops.cerberus.*
+        self.levels = pyramid_shapes(width, height, 32)
+        self.pairs = pairs
+        self.dirs = []
+        for direction in range(2):
+            lv = []
+            for l, (C, H, W) in enumerate(self.levels):
+                seed = 16 * direction + 4 * l
+                t = lambda shape, s, lo=-1.0, hi=1.0: torch.from_numpy(
+                    hash_uniform(shape, seed + s, lo, hi)).to(device)
+                lv.append(dict(
+                    f1=t((pairs, C, H, W), 0), f2=t((pairs, C, H, W), 1),
+                    gout=t((pairs, 81, H, W), 2),
+                    flow=t((pairs, 2, H, W), 3, -6.0, 6.0) if l > 0 else None))
+            self.dirs.append(lv)
+
+    def kernels(self):
+        """(label, algorithmic bytes) of every launch in one step."""
+        out = []
+        for l, (C, H, W) in enumerate(self.levels):
+            cf, cb = corr_bytes(C, self.pairs, H, W)
+            out += [("corr_fwd_L%d" % l, cf), ("corr_bwd_L%d" % l, cb)]
+            if l > 0:
+                wf, wb = warp_bytes(C, self.pairs, H, W)
+                out += [("warp_fwd_L%d" % l, wf), ("warp_bwd_L%d" % l, wb)]
+        return out
+
+    def step(self, probe=None):
+        """Run one step. `probe(label)` returns a context manager used by the
+        per-kernel timing pass; None on the timed path."""
+        ops = torch.ops.cerberus
+        keep = []
+        for lv in self.dirs:
+            # forward, coarse to fine
+            for l, t in enumerate(lv):
+                if l > 0:
+                    with probe("warp_fwd_L%d" % l) if probe else _null:
+                        t["warped"] = ops.flow_warp(t["f2"], t["flow"], 1, 0)
+                else:
+                    t["warped"] = t["f2"]
+                with probe("corr_fwd_L%d" % l) if probe else _null:
+                    t["out"] = ops.correlation(t["f1"], t["warped"], *CORR_P)
+            # backward, fine to coarse
+            for l in reversed(range(len(lv))):
+                t = lv[l]
+                with probe("corr_bwd_L%d" % l) if probe else _null:
+                    g1, g2 = ops.correlation_backward(t["f1"], t["warped"], t["gout"], *CORR_P)
+                keep.append(g1)
+                if l > 0:
+                    with probe("warp_bwd_L%d" % l) if probe else _null:
+                        gi, gf = ops.flow_warp_backward(t["f2"], t["flow"], g2, 1, 0, True, True)
+                    keep += [gi, gf]
+                else:
+                    keep.append(g2)
+        return keep
+
+
+class _Null:
+    def __enter__(self): return self
+    def __exit__(self, *a): return False
+
+
+_null = _Null()
+
+
+class EventProbe:
+    """HIP-event brackets on the launch stream (torch's current stream IS the
+    stream every cerberus op launches on, ops.py:_stream_ptr)."""
+
+    def __init__(self):
+        self.records = {}
+
+    def __call__(self, label):
+        probe = self
+
+        class _Ctx:
+            def __enter__(self_inner):
+                self_inner.a = torch.cuda.Event(enable_timing=True)
+                self_inner.b = torch.cuda.Event(enable_timing=True)
+                self_inner.a.record()
+                return self_inner
+
+            def __exit__(self_inner, *exc):
+                self_inner.b.record()
+                probe.records.setdefault(label, []).append((self_inner.a, self_inner.b))
+                return False
+        return _Ctx()
+
+    def summary(self):
+        torch.cuda.synchronize()
+        return {k: float(np.mean([a.elapsed_time(b) for a, b in v])) * 1e-3
+                for k, v in self.records.items()}  # seconds per launch
+
+
+def cpu_baseline(levels, budget_s=12.0):
+    """Reference CPU path: CorrelationTorch semantics (oracle port) forward +
+    autograd backward on the B=1 pyramid, both directions = one image pair."""
+    from oracle import correlation_torch_ref
+    from cerberusnet_amd.synth import hash_uniform
+    threads = torch.get_num_threads()
+    data = []
+    for l, (C, H, W) in enumerate(levels):
+        data.append((torch.from_numpy(hash_uniform((1, C, H, W), 4 * l)).requires_grad_(True),
+                     torch.from_numpy(hash_uniform((1, C, H, W), 4 * l + 1)).requires_grad_(True),
+                     torch.from_numpy(hash_uniform((1, 81, H, W), 4 * l + 2))))
+
+    def one_pair():
+        for _ in range(2):
+            for x1, x2, go in data:
+                out = correlation_torch_ref(x1, x2, 4)
+                torch.autograd.grad(out, (x1, x2), go)
+
+    one_pair()  # warm-up
+    n, t0 = 0, time.perf_counter()
+    while True:
+        one_pair()
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt > budget_s or n >= 50:
+            break
+    return {"value": round(n / dt, 4), "unit": "image-pairs/s", "cores": threads,
+            "kind": "port",
+            "sample": "%d image pairs (B=1, 4 levels x 2 directions, correlation fwd+bwd only, "
+                      "torch CPU, %d threads of %d host cores) in %.1f s"
+                      % (n, threads, os.cpu_count(), dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--pairs", type=int, default=4, help="image pairs per GPU per step")
+    ap.add_argument("--width", type=int, default=1024)
+    ap.add_argument("--height", type=int, default=512)
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--probe-steps", type=int, default=20)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("--gpus %d needs torchrun (one process per GPU)" % args.gpus)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU path exists for the product)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=device)  # RCCL
+
+    wl = Workload(args.pairs, args.width, args.height, device)
+
+    # ---- warm-up (eager), then capture the step into a hipGraph ----
+    for _ in range(max(1, args.warmup if args.no_graph else 3)):
+        wl.step()
+    torch.cuda.synchronize()
+    graph = None
+    if not args.no_graph:
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            wl.step()
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            held = wl.step()  # noqa: F841  keep outputs alive for the graph's pool
+        for _ in range(args.warmup):
+            graph.replay()
+    run = graph.replay if graph is not None else wl.step
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    result = None
+    if rank == 0:
+        pairs_total = args.pairs * world * args.steps
+        kern = dict(wl.kernels())
+        step_bytes = 2 * sum(kern.values())                       # two directions
+        corr_step_bytes = 2 * sum(v for k, v in kern.items() if k.startswith("corr"))
+        result = {
+            "metric": METRIC, "value": round(pairs_total / elapsed, 2), "unit": "image-pairs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 5), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {
+                "workload": "BASELINE config 3 tensors (HRNetV2-W32 pyramid of 1024x512, corr "
+                            "d=4 + flow-warp, fp32), %d image pairs per GPU per step (config 4's "
+                            "per-GPU batch), both flow directions, fwd+bwd" % args.pairs,
+                "pairs_per_gpu": args.pairs, "levels_CHW": [list(s) for s in wl.levels],
+                "launch": "hipGraph replay" if graph is not None else "eager",
+                "sharding": "image pairs sharded over ranks, no data-path collective",
+                "algorithmic_bytes_per_step": step_bytes,
+                "step_algorithmic_GBps_per_gpu": round(step_bytes * args.steps / elapsed / 1e9, 1),
+                "corr_only_frac_of_hbm_peak_whole_step": round(
+                    corr_step_bytes * args.steps / elapsed / 1e9 / HBM_PEAK_GBPS, 4),
+            },
+        }
+
+    # ---- per-kernel pass: HIP events around every launch (rank 0 only) ----
+    if rank == 0:
+        probe = EventProbe()
+        for _ in range(max(1, args.probe_steps)):
+            wl.step(probe)
+        per = probe.summary()
+        kern = dict(wl.kernels())
+        dominant = max(per, key=lambda k: per[k])
+        ach = kern[dominant] / per[dominant] / 1e9
+        result["roofline"] = {
+            "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": None, "kernel": dominant,
+            "avg_us": round(per[dominant] * 1e6, 2), "algorithmic_bytes": kern[dominant],
+            "per_kernel": {k: {"us": round(per[k] * 1e6, 2),
+                               "GBps": round(kern[k] / per[k] / 1e9, 1)} for k in sorted(per)},
+        }
+        try:
+            from cerberusnet_amd import _lib
+            result["roofline"]["variants"] = [_lib.last_kernel(0), _lib.last_kernel(1)]
+        except Exception:  # diagnostics only
+            pass
+        if not args.no_cpu_baseline and world == 1:
+            result["cpu_baseline"] = cpu_baseline(wl.levels)
+        elif not args.no_cpu_baseline:
+            result["cpu_baseline"] = None
+        print(json.dumps(result), flush=True)
+
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,166 @@
+// api.hip -- the extern "C" surface declared in include/cerberus_hip.h.
+// Argument validation + dispatch only; kernels live in corr_d4.hip,
+// corr_generic.hip and warp.hip.
+#include <atomic>
+#include <cstring>
+
+#include "common.h"
+
+namespace cerb {
+namespace {
+std::atomic<int> g_force_generic{0};
+thread_local const char *t_last_kernel[2] = {"none", "none"};
+
+bool dtype_ok(int dtype) { return dtype >= CERB_F32 && dtype <= CERB_F64; }
+}  // namespace
+
+int option_force_generic() { return g_force_generic.load(std::memory_order_relaxed); }
+void note_kernel(int which, const char *name) { t_last_kernel[which & 1] = name; }
+}  // namespace cerb
+
+using namespace cerb;
+
+extern "C" {
+
+int cerberus_abi_version(void) { return CERBERUS_HIP_ABI_VERSION; }
+
+const char *cerberus_error_string(int code) {
+    switch (code) {
+        case CERB_OK: return "success";
+        case CERB_EINVAL: return "invalid argument (null pointer, non-positive size or empty output)";
+        case CERB_EDTYPE: return "unknown dtype";
+        case CERB_ESTRIDE1: return "correlation backward requires stride1 == 1";
+        case CERB_EMODE: return "unknown padding or interpolation mode";
+        case CERB_EUNSUPPORTED: return "valid request that is not implemented";
+        case CERB_ETOOLARGE: return "dimension exceeds launch/index limits";
+        default: break;
+    }
+    if (code > 0) return hipGetErrorString(static_cast<hipError_t>(code));
+    return "unknown cerberus_hip error";
+}
+
+int cerberus_correlation_out_shape(int H, int W, int pad_size, int kernel_size,
+                                   int max_displacement, int stride1, int stride2,
+                                   int *out_channels, int *out_height, int *out_width) {
+    if (!out_channels || !out_height || !out_width) return CERB_EINVAL;
+    CorrGeom g;
+    const int rc = corr_geom_init(g, 1, 1, H, W, pad_size, kernel_size, max_displacement, stride1,
+                                  stride2);
+    if (rc) return rc;
+    *out_channels = g.oC; *out_height = g.oH; *out_width = g.oW;
+    return CERB_OK;
+}
+
+int cerberus_correlation_forward_ex(const void *input1, const void *input2, void *output, int B,
+                                    int C, int H, int W, int pad_size, int kernel_size,
+                                    int max_displacement, int stride1, int stride2,
+                                    float negative_slope, int64_t out_batch_stride, int dtype,
+                                    void *stream) {
+    if (!dtype_ok(dtype)) return CERB_EDTYPE;
+    CorrGeom g;
+    int rc = corr_geom_init(g, B, C, H, W, pad_size, kernel_size, max_displacement, stride1,
+                            stride2);
+    if (rc) return rc;
+    if (B == 0) return CERB_OK;
+    if (!input1 || !input2 || !output) return CERB_EINVAL;
+    if (B > 65535) return CERB_ETOOLARGE;
+    if (out_batch_stride != 0 &&
+        out_batch_stride < static_cast<int64_t>(g.oC) * g.oH * g.oW)
+        return CERB_EINVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (!option_force_generic()) {
+        rc = corr_d4_forward(input1, input2, output, g, negative_slope, out_batch_stride, dtype, s);
+        if (rc != CERB_EUNSUPPORTED) return rc;
+    }
+    note_kernel(0, "corr_fwd_generic");
+    return corr_generic_forward(input1, input2, output, g, negative_slope, out_batch_stride, dtype,
+                                s);
+}
+
+int cerberus_correlation_forward(const void *input1, const void *input2, void *output, int B,
+                                 int C, int H, int W, int pad_size, int kernel_size,
+                                 int max_displacement, int stride1, int stride2,
+                                 int corr_type_multiply, int dtype, void *stream) {
+    (void)corr_type_multiply;  // accepted and ignored, exactly like the reference
+    return cerberus_correlation_forward_ex(input1, input2, output, B, C, H, W, pad_size,
+                                           kernel_size, max_displacement, stride1, stride2, 1.0f,
+                                           0, dtype, stream);
+}
+
+int cerberus_correlation_backward(const void *input1, const void *input2, const void *grad_output,
+                                  void *grad_input1, void *grad_input2, int B, int C, int H,
+                                  int W, int pad_size, int kernel_size, int max_displacement,
+                                  int stride1, int stride2, int corr_type_multiply, int dtype,
+                                  void *stream) {
+    (void)corr_type_multiply;
+    if (!dtype_ok(dtype)) return CERB_EDTYPE;
+    CorrGeom g;
+    int rc = corr_geom_init(g, B, C, H, W, pad_size, kernel_size, max_displacement, stride1,
+                            stride2);
+    if (rc) return rc;
+    if (stride1 != 1) return CERB_ESTRIDE1;
+    if (B == 0) return CERB_OK;
+    if (!input1 || !input2 || !grad_output || !grad_input1 || !grad_input2) return CERB_EINVAL;
+    if (B > 65535) return CERB_ETOOLARGE;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (!option_force_generic()) {
+        rc = corr_d4_backward(input1, input2, grad_output, grad_input1, grad_input2, g, dtype, s);
+        if (rc != CERB_EUNSUPPORTED) return rc;
+    }
+    note_kernel(1, "corr_bwd_generic");
+    return corr_generic_backward(input1, input2, grad_output, grad_input1, grad_input2, g, dtype,
+                                 s);
+}
+
+static int warp_args_ok(int B, int C, int H, int W, int pad_mode, int interp_mode, int dtype) {
+    if (!dtype_ok(dtype)) return CERB_EDTYPE;
+    if (B < 0 || C <= 0 || H <= 0 || W <= 0) return CERB_EINVAL;
+    if (B > 65535) return CERB_ETOOLARGE;
+    if (pad_mode < CERB_PAD_ZEROS || pad_mode > CERB_PAD_REFLECTION) return CERB_EMODE;
+    if (interp_mode < CERB_INTERP_BILINEAR || interp_mode > CERB_INTERP_NEAREST) return CERB_EMODE;
+    return CERB_OK;
+}
+
+int cerberus_flow_warp_forward(const void *image, const void *flow, void *out, int B, int C, int H,
+                               int W, int pad_mode, int interp_mode, int dtype, void *stream) {
+    const int rc = warp_args_ok(B, C, H, W, pad_mode, interp_mode, dtype);
+    if (rc) return rc;
+    if (B == 0) return CERB_OK;
+    if (!image || !flow || !out) return CERB_EINVAL;
+    return warp_forward(image, flow, out, B, C, H, W, pad_mode, interp_mode, dtype,
+                        static_cast<hipStream_t>(stream));
+}
+
+int cerberus_flow_warp_backward(const void *image, const void *flow, const void *grad_out,
+                                void *grad_image, void *grad_flow, int B, int C, int H, int W,
+                                int pad_mode, int interp_mode, int dtype, void *stream) {
+    const int rc = warp_args_ok(B, C, H, W, pad_mode, interp_mode, dtype);
+    if (rc) return rc;
+    if (B == 0) return CERB_OK;
+    if (!image || !flow || !grad_out) return CERB_EINVAL;
+    if (!grad_image && !grad_flow) return CERB_OK;
+    return warp_backward(image, flow, grad_out, grad_image, grad_flow, B, C, H, W, pad_mode,
+                         interp_mode, dtype, static_cast<hipStream_t>(stream));
+}
+
+int cerberus_set_option(const char *key, int value) {
+    if (!key) return CERB_EINVAL;
+    if (!std::strcmp(key, "corr_force_generic")) {
+        g_force_generic.store(value, std::memory_order_relaxed);
+        return CERB_OK;
+    }
+    return CERB_EINVAL;
+}
+
+int cerberus_get_option(const char *key, int *value) {
+    if (!key || !value) return CERB_EINVAL;
+    if (!std::strcmp(key, "corr_force_generic")) {
+        *value = g_force_generic.load(std::memory_order_relaxed);
+        return CERB_OK;
+    }
+    return CERB_EINVAL;
+}
+
+const char *cerberus_last_kernel(int which) { return t_last_kernel[which & 1]; }
+
+}  // extern "C"

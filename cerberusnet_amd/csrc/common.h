@@ -1,0 +1,95 @@
+// common.h -- shared device/host helpers for libcerberus_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <hip/hip_bfloat16.h>
+#include <stdint.h>
+
+#include "../../include/cerberus_hip.h"
+
+namespace cerb {
+
+// ---- storage type -> arithmetic type ---------------------------------------
+// fp16/bf16 are storage formats only: every product is formed and accumulated
+// in fp32 (the reference accumulates fp16 in fp16; we do better).
+template <typename T> struct Acc { using type = float; };
+template <> struct Acc<double> { using type = double; };
+
+template <typename T> __device__ __forceinline__ typename Acc<T>::type ld(const T *p) {
+    return static_cast<typename Acc<T>::type>(*p);
+}
+template <> __device__ __forceinline__ float ld<__half>(const __half *p) { return __half2float(*p); }
+template <> __device__ __forceinline__ float ld<hip_bfloat16>(const hip_bfloat16 *p) {
+    return static_cast<float>(*p);
+}
+template <typename T, typename A> __device__ __forceinline__ void st(T *p, A v) { *p = static_cast<T>(v); }
+template <> __device__ __forceinline__ void st<__half, float>(__half *p, float v) { *p = __float2half(v); }
+template <> __device__ __forceinline__ void st<hip_bfloat16, float>(hip_bfloat16 *p, float v) {
+    *p = hip_bfloat16(v);
+}
+
+// ---- correlation geometry (correlation_cuda.cpp:6-14) -----------------------
+struct CorrGeom {
+    int B, C, H, W;
+    int pad, ksize, maxd, s1, s2;
+    int krad, drad, dsize;
+    int oC, oH, oW;
+};
+
+static inline int ceil_div_float(int a, int b) {
+    // the reference rounds through float: ceil((float)a / (float)b)
+    float q = static_cast<float>(a) / static_cast<float>(b);
+    int r = static_cast<int>(q);
+    return (static_cast<float>(r) < q) ? r + 1 : r;
+}
+
+static inline int corr_geom_init(CorrGeom &g, int B, int C, int H, int W, int pad, int ksize,
+                                 int maxd, int s1, int s2) {
+    if (B < 0 || C <= 0 || H <= 0 || W <= 0 || pad < 0 || ksize <= 0 || maxd < 0 || s1 <= 0 ||
+        s2 <= 0)
+        return CERB_EINVAL;
+    g.B = B; g.C = C; g.H = H; g.W = W;
+    g.pad = pad; g.ksize = ksize; g.maxd = maxd; g.s1 = s1; g.s2 = s2;
+    g.krad = (ksize - 1) / 2;
+    const int border = g.krad + maxd;
+    g.drad = maxd / s2;
+    g.dsize = 2 * g.drad + 1;
+    g.oC = g.dsize * g.dsize;
+    g.oH = ceil_div_float(H + 2 * pad - 2 * border, s1);
+    g.oW = ceil_div_float(W + 2 * pad - 2 * border, s1);
+    if (g.oH <= 0 || g.oW <= 0) return CERB_EINVAL;
+    return CERB_OK;
+}
+
+// process-wide knobs (api.hip)
+int option_force_generic();
+int option_get(const char *key, int *value);
+void note_kernel(int which, const char *name);
+
+// ---- launchers implemented in the kernel translation units ------------------
+// all return hipError_t (as int) of the launch, or a negative CERB_E* code.
+int corr_generic_forward(const void *in1, const void *in2, void *out, const CorrGeom &g,
+                         float slope, int64_t out_bstride, int dtype, hipStream_t s);
+int corr_generic_backward(const void *in1, const void *in2, const void *gout, void *gin1,
+                          void *gin2, const CorrGeom &g, int dtype, hipStream_t s);
+
+// fast path: pad == d == 4, k == 1, s1 == s2 == 1, fp32 (corr_d4.hip).
+// Returns CERB_EUNSUPPORTED when the shape/dtype is not covered -> caller falls
+// back to the generic kernels (still HIP; there is no CPU path anywhere).
+int corr_d4_forward(const void *in1, const void *in2, void *out, const CorrGeom &g, float slope,
+                    int64_t out_bstride, int dtype, hipStream_t s);
+int corr_d4_backward(const void *in1, const void *in2, const void *gout, void *gin1, void *gin2,
+                     const CorrGeom &g, int dtype, hipStream_t s);
+
+int warp_forward(const void *image, const void *flow, void *out, int B, int C, int H, int W,
+                 int pad_mode, int interp, int dtype, hipStream_t s);
+int warp_backward(const void *image, const void *flow, const void *gout, void *gimage,
+                  void *gflow, int B, int C, int H, int W, int pad_mode, int interp, int dtype,
+                  hipStream_t s);
+
+static inline int launch_status() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? CERB_OK : static_cast<int>(e);
+}
+
+}  // namespace cerb

@@ -1,0 +1,308 @@
+"""torch.ops.cerberus.* -- the reference's operator names and schemas, bound to
+the HIP kernels through the C ABI (include/cerberus_hip.h).
+
+Reference registration being replaced
+(/root/reference/nnet_training/correlation_package/correlation_cuda.cpp:45-48):
+
+    TORCH_LIBRARY(cerberus, m) {
+        m.def("correlation", correlation_forward_cuda);            // :3-26
+        m.def("correlation_backward", correlation_backward_cuda);  // :28-43
+    }
+
+Same names, same argument order (the ONNX symbolic in utilities/onnx_export.py:18-23
+depends on it), same ownership (the op allocates and returns its outputs), same
+threading contract (enqueue on the current stream, never synchronise).  Extra
+ops ``cerberus::flow_warp`` / ``flow_warp_backward`` / ``correlation_leaky``
+carry the fused warp (UnFlowLoss.py:83-94) and the fused LeakyReLU epilogue
+(pwcnet_sfd.py:181-182).
+
+CPU tensors are rejected with RuntimeError: the product has no CPU path.
+PyTorch is plumbing here (device memory, streams, autograd graph) -- the
+arithmetic is all in libcerberus_hip.so.
+"""
+import ctypes
+from typing import List
+
+import torch
+from torch.library import Library
+
+from . import _lib
+
+_DTYPES = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2, torch.float64: 3}
+PAD_MODES = {"zeros": 0, "border": 1, "reflection": 2}
+INTERP_MODES = {"bilinear": 0, "nearest": 1}
+
+_CORR_ARGS = ("int pad_size, int kernel_size, int max_displacement, "
+              "int stride1, int stride2, int corr_type_multiply")
+
+_def = Library("cerberus", "DEF")
+_def.define("correlation(Tensor input1, Tensor input2, %s) -> Tensor" % _CORR_ARGS)
+_def.define("correlation_backward(Tensor input1, Tensor input2, Tensor gradOutput, %s) "
+            "-> Tensor[]" % _CORR_ARGS)
+_def.define("correlation_leaky(Tensor input1, Tensor input2, %s, float negative_slope) "
+            "-> Tensor" % _CORR_ARGS)
+_def.define("flow_warp(Tensor image, Tensor flow, int pad_mode, int interp_mode) -> Tensor")
+_def.define("flow_warp_backward(Tensor image, Tensor flow, Tensor grad_out, int pad_mode, "
+            "int interp_mode, bool need_image, bool need_flow) -> Tensor[]")
+
+
+def _stream_ptr(t: torch.Tensor):
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _dtype_code(t: torch.Tensor, what: str) -> int:
+    try:
+        return _DTYPES[t.dtype]
+    except KeyError:
+        raise RuntimeError("%s: unsupported dtype %s (float32/float16/bfloat16/float64)"
+                           % (what, t.dtype)) from None
+
+
+def _check_pair(a: torch.Tensor, b: torch.Tensor, what: str):
+    if a.dim() != 4 or b.dim() != 4:
+        raise RuntimeError("%s: expected 4-D NCHW tensors, got %s and %s"
+                           % (what, tuple(a.shape), tuple(b.shape)))
+    if a.shape != b.shape:
+        raise RuntimeError("%s: input shapes differ: %s vs %s"
+                           % (what, tuple(a.shape), tuple(b.shape)))
+    if a.dtype != b.dtype:
+        raise RuntimeError("%s: input dtypes differ: %s vs %s" % (what, a.dtype, b.dtype))
+    if a.device != b.device:
+        raise RuntimeError("%s: inputs on different devices: %s vs %s"
+                           % (what, a.device, b.device))
+
+
+def _corr_out_shape(H, W, pad, k, d, s1, s2):
+    lib = _lib.get()
+    oc, oh, ow = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    _lib.check(lib.cerberus_correlation_out_shape(H, W, pad, k, d, s1, s2, ctypes.byref(oc),
+                                                  ctypes.byref(oh), ctypes.byref(ow)),
+               "cerberus::correlation (output shape)")
+    return oc.value, oh.value, ow.value
+
+
+def _meta_out_shape(H, W, pad, k, d, s1, s2):
+    # shape maths of correlation_cuda.cpp:6-14 without touching the library
+    import math
+    kr = (k - 1) // 2
+    border = kr + d
+    oc = ((d // s2) * 2 + 1) ** 2
+    oh = math.ceil((H + 2 * pad - 2 * border) / s1)
+    ow = math.ceil((W + 2 * pad - 2 * border) / s1)
+    return oc, oh, ow
+
+
+# ----------------------------------------------------------------------------
+# correlation forward
+# ----------------------------------------------------------------------------
+def _correlation_impl(input1, input2, pad, k, d, s1, s2, mult, slope, what):
+    _check_pair(input1, input2, what)
+    code = _dtype_code(input1, what)
+    x1 = input1.contiguous()   # the reference honours strides via accessors (.cu:271-272)
+    x2 = input2.contiguous()
+    B, C, H, W = x1.shape
+    oc, oh, ow = _corr_out_shape(H, W, pad, k, d, s1, s2)
+    out = torch.empty((B, oc, oh, ow), dtype=x1.dtype, device=x1.device)
+    if out.numel() == 0:
+        return out
+    with torch.cuda.device(x1.device):
+        rc = _lib.get().cerberus_correlation_forward_ex(
+            x1.data_ptr(), x2.data_ptr(), out.data_ptr(), B, C, H, W, pad, k, d, s1, s2,
+            ctypes.c_float(slope), 0, code, _stream_ptr(x1))
+    _lib.check(rc, what)
+    return out
+
+
+def _correlation_cuda(input1, input2, pad_size, kernel_size, max_displacement, stride1,
+                      stride2, corr_type_multiply):
+    return _correlation_impl(input1, input2, pad_size, kernel_size, max_displacement, stride1,
+                             stride2, corr_type_multiply, 1.0, "cerberus::correlation")
+
+
+def _correlation_leaky_cuda(input1, input2, pad_size, kernel_size, max_displacement, stride1,
+                            stride2, corr_type_multiply, negative_slope):
+    return _correlation_impl(input1, input2, pad_size, kernel_size, max_displacement, stride1,
+                             stride2, corr_type_multiply, float(negative_slope),
+                             "cerberus::correlation_leaky")
+
+
+def _correlation_meta(input1, input2, pad_size, kernel_size, max_displacement, stride1,
+                      stride2, corr_type_multiply, *_):
+    B, _, H, W = input1.shape
+    oc, oh, ow = _meta_out_shape(H, W, pad_size, kernel_size, max_displacement, stride1, stride2)
+    return input1.new_empty((B, oc, oh, ow))
+
+
+# ----------------------------------------------------------------------------
+# correlation backward
+# ----------------------------------------------------------------------------
+def _correlation_backward_cuda(input1, input2, gradOutput, pad_size, kernel_size,
+                               max_displacement, stride1, stride2,
+                               corr_type_multiply) -> List[torch.Tensor]:
+    what = "cerberus::correlation_backward"
+    _check_pair(input1, input2, what)
+    code = _dtype_code(input1, what)
+    if stride1 != 1:
+        raise RuntimeError(what + ": stride1 must be 1 (the reference kernel writes out of "
+                           "bounds for stride1 > 1, correlation_cuda_kernel.cu:106-107,169)")
+    x1 = input1.contiguous()
+    x2 = input2.contiguous()
+    B, C, H, W = x1.shape
+    oc, oh, ow = _corr_out_shape(H, W, pad_size, kernel_size, max_displacement, stride1, stride2)
+    if tuple(gradOutput.shape) != (B, oc, oh, ow):
+        raise RuntimeError("%s: gradOutput shape %s, expected %s"
+                           % (what, tuple(gradOutput.shape), (B, oc, oh, ow)))
+    go = gradOutput.to(dtype=x1.dtype).contiguous()
+    g1 = torch.empty_like(x1)
+    g2 = torch.empty_like(x2)
+    if x1.numel() == 0:
+        return [g1, g2]
+    with torch.cuda.device(x1.device):
+        rc = _lib.get().cerberus_correlation_backward(
+            x1.data_ptr(), x2.data_ptr(), go.data_ptr(), g1.data_ptr(), g2.data_ptr(), B, C, H,
+            W, pad_size, kernel_size, max_displacement, stride1, stride2, corr_type_multiply,
+            code, _stream_ptr(x1))
+    _lib.check(rc, what)
+    return [g1, g2]
+
+
+def _correlation_backward_meta(input1, input2, gradOutput, *_):
+    return [torch.empty_like(input1), torch.empty_like(input2)]
+
+
+# ----------------------------------------------------------------------------
+# flow warp
+# ----------------------------------------------------------------------------
+def _warp_check(image, flow, what):
+    if image.dim() != 4 or flow.dim() != 4:
+        raise RuntimeError("%s: expected image (B,C,H,W) and flow (B,2,H,W)" % what)
+    B, _, H, W = image.shape
+    if tuple(flow.shape) != (B, 2, H, W):
+        raise RuntimeError("%s: flow shape %s, expected %s"
+                           % (what, tuple(flow.shape), (B, 2, H, W)))
+    if image.device != flow.device:
+        raise RuntimeError("%s: image and flow on different devices" % what)
+
+
+def _flow_warp_cuda(image, flow, pad_mode, interp_mode):
+    what = "cerberus::flow_warp"
+    _warp_check(image, flow, what)
+    code = _dtype_code(image, what)
+    img = image.contiguous()
+    flo = flow.to(dtype=img.dtype).contiguous()
+    out = torch.empty_like(img)
+    if out.numel() == 0:
+        return out
+    B, C, H, W = img.shape
+    with torch.cuda.device(img.device):
+        rc = _lib.get().cerberus_flow_warp_forward(img.data_ptr(), flo.data_ptr(),
+                                                   out.data_ptr(), B, C, H, W, pad_mode,
+                                                   interp_mode, code, _stream_ptr(img))
+    _lib.check(rc, what)
+    return out
+
+
+def _flow_warp_backward_cuda(image, flow, grad_out, pad_mode, interp_mode, need_image,
+                             need_flow) -> List[torch.Tensor]:
+    what = "cerberus::flow_warp_backward"
+    _warp_check(image, flow, what)
+    code = _dtype_code(image, what)
+    img = image.contiguous()
+    flo = flow.to(dtype=img.dtype).contiguous()
+    go = grad_out.to(dtype=img.dtype).contiguous()
+    if go.shape != img.shape:
+        raise RuntimeError("%s: grad_out shape %s, expected %s"
+                           % (what, tuple(go.shape), tuple(img.shape)))
+    gi = torch.empty_like(img) if need_image else img.new_empty(0)
+    gf = torch.empty_like(flo) if need_flow else flo.new_empty(0)
+    if img.numel() == 0 or not (need_image or need_flow):
+        return [gi, gf]
+    B, C, H, W = img.shape
+    with torch.cuda.device(img.device):
+        rc = _lib.get().cerberus_flow_warp_backward(
+            img.data_ptr(), flo.data_ptr(), go.data_ptr(),
+            gi.data_ptr() if need_image else None, gf.data_ptr() if need_flow else None,
+            B, C, H, W, pad_mode, interp_mode, code, _stream_ptr(img))
+    _lib.check(rc, what)
+    return [gi, gf]
+
+
+def _no_cpu(name):
+    def _raise(*_a, **_k):
+        raise RuntimeError("cerberus::%s has no CPU implementation: this build is the "
+                           "MI355X HIP path only (move the tensors to the GPU)" % name)
+    return _raise
+
+
+_def.impl("correlation", _correlation_cuda, "CUDA")
+_def.impl("correlation", _correlation_meta, "Meta")
+_def.impl("correlation", _no_cpu("correlation"), "CPU")
+_def.impl("correlation_leaky", _correlation_leaky_cuda, "CUDA")
+_def.impl("correlation_leaky", _correlation_meta, "Meta")
+_def.impl("correlation_leaky", _no_cpu("correlation_leaky"), "CPU")
+_def.impl("correlation_backward", _correlation_backward_cuda, "CUDA")
+_def.impl("correlation_backward", _correlation_backward_meta, "Meta")
+_def.impl("correlation_backward", _no_cpu("correlation_backward"), "CPU")
+_def.impl("flow_warp", _flow_warp_cuda, "CUDA")
+_def.impl("flow_warp", lambda image, flow, p, m: torch.empty_like(image), "Meta")
+_def.impl("flow_warp", _no_cpu("flow_warp"), "CPU")
+_def.impl("flow_warp_backward", _flow_warp_backward_cuda, "CUDA")
+_def.impl("flow_warp_backward",
+          lambda image, flow, go, p, m, ni, nf: [torch.empty_like(image), torch.empty_like(flow)],
+          "Meta")
+_def.impl("flow_warp_backward", _no_cpu("flow_warp_backward"), "CPU")
+
+
+# ----------------------------------------------------------------------------
+# autograd formulas for the raw ops.  The reference registers none (its raw op
+# is only differentiable through CorrelationFunction); having them makes the
+# eval-mode path of Correlation.forward (correlation.py:78-80) differentiable
+# too and costs nothing.
+# ----------------------------------------------------------------------------
+def _corr_setup(ctx, inputs, output):
+    input1, input2, *params = inputs
+    ctx.save_for_backward(input1, input2)
+    ctx.params = tuple(params[:6])
+
+
+def _corr_backward(ctx, grad):
+    input1, input2 = ctx.saved_tensors
+    g1, g2 = torch.ops.cerberus.correlation_backward(input1, input2, grad, *ctx.params)
+    return (g1, g2) + (None,) * 6
+
+
+def _corr_leaky_setup(ctx, inputs, output):
+    input1, input2, *params = inputs
+    ctx.save_for_backward(input1, input2, output)
+    ctx.params = tuple(params[:6])
+    ctx.slope = params[6]
+
+
+def _corr_leaky_backward(ctx, grad):
+    input1, input2, output = ctx.saved_tensors
+    # d leaky(v)/dv from the sign of the output (slope > 0 keeps the sign)
+    grad = torch.where(output > 0, grad, grad * ctx.slope)
+    g1, g2 = torch.ops.cerberus.correlation_backward(input1, input2, grad, *ctx.params)
+    return (g1, g2) + (None,) * 7
+
+
+def _warp_setup(ctx, inputs, output):
+    image, flow, pad_mode, interp_mode = inputs
+    ctx.save_for_backward(image, flow)
+    ctx.modes = (pad_mode, interp_mode)
+
+
+def _warp_backward(ctx, grad):
+    image, flow = ctx.saved_tensors
+    need_image, need_flow = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+    gi, gf = torch.ops.cerberus.flow_warp_backward(image, flow, grad, ctx.modes[0],
+                                                   ctx.modes[1], need_image, need_flow)
+    return (gi if need_image else None, gf.to(flow.dtype) if need_flow else None, None, None)
+
+
+torch.library.register_autograd("cerberus::correlation", _corr_backward,
+                                setup_context=_corr_setup)
+torch.library.register_autograd("cerberus::correlation_leaky", _corr_leaky_backward,
+                                setup_context=_corr_leaky_setup)
+torch.library.register_autograd("cerberus::flow_warp", _warp_backward,
+                                setup_context=_warp_setup)

@@ -1,0 +1,143 @@
+/*
+ * cerberus_hip.h -- C ABI of libcerberus_hip.so, the MI355X (gfx950) drop-in for
+ * CerberusNet's cost-volume correlation + flow-warp hot path.
+ *
+ * Plain pointers and sizes only: no torch types, no C++ in the signatures.  All
+ * tensors are dense, contiguous NCHW device buffers owned by the caller
+ * (outputs included: the caller allocates, the library fully overwrites them).
+ * Every entry point enqueues asynchronously on `stream` (a hipStream_t passed
+ * as void*, NULL = default stream), never synchronises, allocates nothing,
+ * keeps no global mutable state (re-entrant: autograd may call backward from
+ * its own engine thread) and is therefore safe to capture into a hipGraph.
+ *
+ * Return value: 0 on success; a negative CERB_E* code for rejected arguments;
+ * a positive value is the hipError_t reported by the launch.
+ * cerberus_error_string() turns either into text.
+ *
+ * Reference interfaces these replace (paths under /root/reference/):
+ *   nnet_training/correlation_package/correlation_cuda.cpp:3-26   correlation_forward_cuda
+ *   nnet_training/correlation_package/correlation_cuda.cpp:28-43  correlation_backward_cuda
+ *   nnet_training/correlation_package/correlation_cuda_kernel.cuh:5-14 (kernel launchers)
+ *   nnet_training/loss_functions/UnFlowLoss.py:83-94              flow_warp (-> ATen grid_sampler_2d fwd/bwd)
+ * The Python binding that registers torch.ops.cerberus.{correlation,
+ * correlation_backward} on top of this ABI is cerberusnet_amd/ops.py; the
+ * reference-side stub a maintainer would add is shown in INTEGRATION.md.
+ */
+#ifndef CERBERUS_HIP_H
+#define CERBERUS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CERBERUS_HIP_ABI_VERSION 1
+
+/* element types (AT_DISPATCH_FLOATING_TYPES_AND_HALF in the reference,
+ * correlation_cuda_kernel.cu:269,303; bf16 is an extension) */
+enum cerb_dtype {
+    CERB_F32  = 0,
+    CERB_F16  = 1,  /* fp16 storage, fp32 accumulation (reference accumulates in fp16: Q6) */
+    CERB_BF16 = 2,  /* bf16 storage, fp32 accumulation (not in the reference)             */
+    CERB_F64  = 3
+};
+
+/* grid_sample modes used by flow_warp(image, flow12, pad='border', mode='bilinear') */
+enum cerb_pad_mode    { CERB_PAD_ZEROS = 0, CERB_PAD_BORDER = 1, CERB_PAD_REFLECTION = 2 };
+enum cerb_interp_mode { CERB_INTERP_BILINEAR = 0, CERB_INTERP_NEAREST = 1 };
+
+/* argument-rejection codes (negative) */
+#define CERB_OK            0
+#define CERB_EINVAL       -1  /* null pointer, non-positive size, empty output          */
+#define CERB_EDTYPE       -2  /* unknown dtype                                          */
+#define CERB_ESTRIDE1     -3  /* correlation backward with stride1 != 1 (reference is   */
+                              /* memory-unsafe there, correlation_cuda_kernel.cu:106)   */
+#define CERB_EMODE        -4  /* unknown padding / interpolation mode                   */
+#define CERB_EUNSUPPORTED -5  /* valid but not implemented (reflection-pad backward)    */
+#define CERB_ETOOLARGE    -6  /* a dimension exceeds 32-bit launch / index limits       */
+
+int cerberus_abi_version(void);
+
+/* Human-readable text for a return code of any function below. */
+const char *cerberus_error_string(int code);
+
+/* Output geometry, exactly correlation_cuda.cpp:6-14:
+ *   oC = ((d/s2)*2+1)^2, oH = ceil((H+2p-2(kr+d))/s1), oW likewise, kr=(k-1)/2. */
+int cerberus_correlation_out_shape(int H, int W, int pad_size, int kernel_size,
+                                   int max_displacement, int stride1,
+                                   int stride2, int *out_channels,
+                                   int *out_height, int *out_width);
+
+/* correlation forward.  Replaces correlation_forward_cuda
+ * (correlation_cuda.cpp:3-26 -> correlation_cuda_kernel.cu:244-324).
+ *   input1,input2 : (B,C,H,W)      output : (B,oC,oH,oW), fully overwritten
+ *   out[n][(tj+dr)*D+(ti+dr)][y][x] = 1/(k*k*C) * sum_{j,i in kernel} sum_c
+ *        pad(in1)[n][c][y*s1+d+j][x*s1+d+i] * pad(in2)[n][c][y*s1+d+tj*s2+j][x*s1+d+ti*s2+i]
+ * corr_type_multiply is accepted and ignored, as in the reference. */
+int cerberus_correlation_forward(const void *input1, const void *input2,
+                                 void *output, int B, int C, int H, int W,
+                                 int pad_size, int kernel_size,
+                                 int max_displacement, int stride1, int stride2,
+                                 int corr_type_multiply, int dtype,
+                                 void *stream);
+
+/* Same, with the consumer's epilogue fused (the caller
+ * pwcnet_sfd.py:181-187 applies leaky_relu(0.1) in place and concatenates):
+ *   out = v > 0 ? v : v * negative_slope   (negative_slope = 1.0f -> identity)
+ *   written at output + n*out_batch_stride elements (out_batch_stride = 0 means
+ *   dense oC*oH*oW), so the 81 channels can land inside a wider concat buffer. */
+int cerberus_correlation_forward_ex(const void *input1, const void *input2,
+                                    void *output, int B, int C, int H, int W,
+                                    int pad_size, int kernel_size,
+                                    int max_displacement, int stride1,
+                                    int stride2, float negative_slope,
+                                    int64_t out_batch_stride, int dtype,
+                                    void *stream);
+
+/* correlation backward.  Replaces correlation_backward_cuda
+ * (correlation_cuda.cpp:28-43 -> correlation_cuda_kernel.cu:326-429).
+ *   grad_output : (B,oC,oH,oW)   grad_input1, grad_input2 : (B,C,H,W), fully
+ *   overwritten (zeros where the reference's kernels early-return).
+ *   Requires stride1 == 1 (CERB_ESTRIDE1 otherwise). */
+int cerberus_correlation_backward(const void *input1, const void *input2,
+                                  const void *grad_output, void *grad_input1,
+                                  void *grad_input2, int B, int C, int H, int W,
+                                  int pad_size, int kernel_size,
+                                  int max_displacement, int stride1,
+                                  int stride2, int corr_type_multiply,
+                                  int dtype, void *stream);
+
+/* flow_warp forward.  Replaces the body of flow_warp (UnFlowLoss.py:83-94):
+ * mesh_grid + flow -> norm_grid by (W-1),(H-1) -> grid_sample(align_corners=False),
+ * fused: no grid tensor is materialised.
+ *   image : (B,C,H,W)  flow : (B,2,H,W) (ch0 = x, ch1 = y, pixels)  out : (B,C,H,W) */
+int cerberus_flow_warp_forward(const void *image, const void *flow, void *out,
+                               int B, int C, int H, int W, int pad_mode,
+                               int interp_mode, int dtype, void *stream);
+
+/* flow_warp backward (autograd of the above w.r.t. image and flow).
+ *   grad_image : (B,C,H,W) -- zero-filled by this call, then accumulated with
+ *                float atomics (summation order is not deterministic, as ATen's)
+ *   grad_flow  : (B,2,H,W) -- fully overwritten, deterministic
+ * Either grad pointer may be NULL to skip that gradient. */
+int cerberus_flow_warp_backward(const void *image, const void *flow,
+                                const void *grad_out, void *grad_image,
+                                void *grad_flow, int B, int C, int H, int W,
+                                int pad_mode, int interp_mode, int dtype,
+                                void *stream);
+
+/* Diagnostics / tuning knobs (process-wide, read at launch time, default 0):
+ *   "corr_force_generic" : 1 = always use the generic kernels (testing)
+ * Returns CERB_EINVAL for an unknown key. */
+int cerberus_set_option(const char *key, int value);
+int cerberus_get_option(const char *key, int *value);
+
+/* Name of the kernel variant the most recent correlation forward / backward on
+ * this thread dispatched to (for tests and the bench's roofline report). */
+const char *cerberus_last_kernel(int which /*0 = forward, 1 = backward*/);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CERBERUS_HIP_H */

@@ -1,0 +1,283 @@
+"""GPU parity tests for the correlation HIP path (through torch.ops -> C ABI).
+
+Tolerance: fp32 outputs must agree with the oracle to <= 1e-5 relative, measured
+as max|a-ref| / max|ref| (BASELINE.json north_star; element-wise relative error
+is ill-conditioned for near-zero correlation values)."""
+import numpy as np
+import pytest
+import torch
+
+import cerberusnet_amd as ca
+from cerberusnet_amd import _lib
+from cerberusnet_amd.synth import hash_uniform, W32_PYRAMID_1024x512
+from conftest import rel_err
+import oracle
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+DEV = "cuda:0"
+
+
+def dev(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    return t if dtype is None else t.to(dtype)
+
+
+def run_fwd(x1, x2, p):
+    return torch.ops.cerberus.correlation(dev(x1), dev(x2), *p, 1).cpu().numpy()
+
+
+def run_bwd(x1, x2, go, p):
+    g1, g2 = torch.ops.cerberus.correlation_backward(dev(x1), dev(x2), dev(go), *p, 1)
+    return g1.cpu().numpy(), g2.cpu().numpy()
+
+
+@pytest.fixture(params=[0, 1], ids=["tuned", "generic"])
+def force_generic(request):
+    _lib.set_option("corr_force_generic", request.param)
+    yield request.param
+    _lib.set_option("corr_force_generic", 0)
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d"])
+def test_golden_vectors(golden, tag, force_generic):
+    g = golden("corr_" + tag)
+    d = int(g["d"])
+    p = (d, 1, d, 1, 1)
+    assert rel_err(run_fwd(g["x1"], g["x2"], p), g["out64"]) < TOL
+    g1, g2 = run_bwd(g["x1"], g["x2"], g["gout"], p)
+    assert rel_err(g1, g["g1_64"]) < TOL
+    assert rel_err(g2, g["g2_64"]) < TOL
+
+
+# ragged / edge shapes at the configuration every model uses (pad=d=4,k=1,s=1)
+D4_SHAPES = [(1, 1, 1, 1), (1, 3, 5, 7), (2, 7, 9, 33), (1, 32, 16, 24), (3, 16, 13, 64),
+             (1, 64, 20, 36), (2, 33, 8, 130), (1, 5, 70, 9), (1, 256, 16, 32),
+             (2, 128, 32, 64), (1, 48, 30, 62), (1, 32, 17, 258)]
+
+
+@pytest.mark.parametrize("shape", D4_SHAPES)
+def test_d4_against_c_oracle(shape, force_generic):
+    B, C, H, W = shape
+    x1 = hash_uniform(shape, 100 + C)
+    x2 = hash_uniform(shape, 200 + H)
+    go = hash_uniform((B, 81, H, W), 300 + W)
+    p = (4, 1, 4, 1, 1)
+    assert rel_err(run_fwd(x1, x2, p), oracle.corr_forward_ref(x1, x2, *p)) < TOL
+    r1, r2 = oracle.corr_backward_ref(x1, x2, go, *p)
+    g1, g2 = run_bwd(x1, x2, go, p)
+    assert rel_err(g1, r1) < TOL
+    assert rel_err(g2, r2) < TOL
+
+
+GENERAL = [(4, 1, 4, 1, 1), (3, 3, 4, 1, 2), (5, 3, 4, 1, 1), (2, 1, 4, 1, 1), (4, 1, 10, 1, 1),
+           (6, 1, 6, 1, 3), (3, 3, 20, 1, 2), (0, 1, 0, 1, 1), (2, 1, 2, 1, 1), (1, 1, 1, 1, 1),
+           (4, 3, 3, 1, 1)]
+
+
+@pytest.mark.parametrize("p", GENERAL)
+def test_general_parameters_against_c_oracle(p):
+    pad, k, d, s1, s2 = p
+    need = 2 * ((k - 1) // 2 + d) - 2 * pad
+    B, C, H, W = 2, 6, max(9, need + 6), max(11, need + 9)
+    x1 = hash_uniform((B, C, H, W), 1)
+    x2 = hash_uniform((B, C, H, W), 2)
+    ref = oracle.corr_forward_ref(x1, x2, *p)
+    assert rel_err(run_fwd(x1, x2, p), ref) < TOL
+    go = hash_uniform(ref.shape, 3)
+    r1, r2 = oracle.corr_backward_ref(x1, x2, go, *p)
+    g1, g2 = run_bwd(x1, x2, go, p)
+    assert rel_err(g1, r1) < TOL
+    assert rel_err(g2, r2) < TOL
+
+
+def test_forward_stride1_gt_1_and_backward_rejects_it():
+    x1 = hash_uniform((1, 4, 10, 12), 5)
+    x2 = hash_uniform((1, 4, 10, 12), 6)
+    for p in [(4, 1, 4, 2, 1), (4, 1, 4, 3, 2), (3, 3, 4, 2, 2)]:
+        ref = oracle.corr_forward_ref(x1, x2, *p)
+        out = run_fwd(x1, x2, p)
+        assert out.shape == ref.shape and rel_err(out, ref) < TOL
+    with pytest.raises(RuntimeError, match="stride1"):
+        torch.ops.cerberus.correlation_backward(dev(x1), dev(x2), dev(np.zeros((1, 81, 5, 6),
+                                                np.float32)), 4, 1, 4, 2, 1, 1)
+
+
+@pytest.mark.parametrize("lvl", [0, 1, 2, 3])
+def test_fullsize_levels_against_reference_checksums(golden, lvl, force_generic):
+    """BASELINE config-3 level shapes (B=1), inputs from the portable generator,
+    compared with the checksums/samples the REFERENCE produced in-container."""
+    g = golden("fullsize")
+    C, H, W = W32_PYRAMID_1024x512[lvl]
+    shp = (1, C, H, W)
+    x1, x2, go = hash_uniform(shp, 0), hash_uniform(shp, 1), hash_uniform((1, 81, H, W), 2)
+    p = (4, 1, 4, 1, 1)
+    out = run_fwd(x1, x2, p)
+    g1, g2 = run_bwd(x1, x2, go, p)
+    name = "L%d" % lvl
+    for key, arr in (("out", out), ("g1", g1), ("g2", g2)):
+        amax = float(g["%s_%s_absmax" % (name, key)])
+        got = arr.reshape(-1)[g["%s_%s_idx" % (name, key)]]
+        assert np.abs(got - g["%s_%s_val" % (name, key)]).max() <= TOL * amax
+        a64 = arr.astype(np.float64)
+        assert abs(a64.sum() - g["%s_%s_sum" % (name, key)]) <= 1e-6 * amax * np.sqrt(a64.size)
+        assert abs((a64 * a64).sum() - g["%s_%s_sumsq" % (name, key)]) <= \
+            1e-5 * g["%s_%s_sumsq" % (name, key)]
+
+
+def test_config1_forward_against_reference_checksums(golden):
+    g = golden("fullsize")
+    shp = (1, 64, 64, 128)
+    out = run_fwd(hash_uniform(shp, 0), hash_uniform(shp, 1), (4, 1, 4, 1, 1))
+    amax = float(g["cfg1_out_absmax"])
+    assert np.abs(out.reshape(-1)[g["cfg1_out_idx"]] - g["cfg1_out_val"]).max() <= TOL * amax
+
+
+@pytest.mark.parametrize("lvl", [0, 1, 2, 3])
+def test_fullsize_batch4_properties(lvl):
+    """B=4 (config 4 per-GPU batch): size-independent properties.
+    (1) batch items are independent: item n of the B=4 call is bit-identical to
+        the B=1 call on item n; (2) bilinearity: corr(a*x1, x2) == a*corr(x1, x2)
+        exactly for a power of two; (3) adjoint identity ties backward to forward:
+        <corr(x1,x2), gO> == <x1, g1> == <x2, g2>."""
+    C, H, W = W32_PYRAMID_1024x512[lvl]
+    B = 4
+    x1 = dev(hash_uniform((B, C, H, W), 7))
+    x2 = dev(hash_uniform((B, C, H, W), 8))
+    go = dev(hash_uniform((B, 81, H, W), 9))
+    p = (4, 1, 4, 1, 1, 1)
+    out = torch.ops.cerberus.correlation(x1, x2, *p)
+    g1, g2 = torch.ops.cerberus.correlation_backward(x1, x2, go, *p)
+    for n in (0, 3):
+        assert torch.equal(torch.ops.cerberus.correlation(x1[n:n + 1], x2[n:n + 1], *p)[0], out[n])
+        h1, h2 = torch.ops.cerberus.correlation_backward(x1[n:n + 1], x2[n:n + 1],
+                                                         go[n:n + 1], *p)
+        assert torch.equal(h1[0], g1[n]) and torch.equal(h2[0], g2[n])
+    assert torch.equal(torch.ops.cerberus.correlation(x1 * 4.0, x2, *p), out * 4.0)
+    lhs = (out.double() * go.double()).sum().item()
+    assert abs(lhs - (x1.double() * g1.double()).sum().item()) <= 1e-6 * abs(lhs) + 1e-6
+    assert abs(lhs - (x2.double() * g2.double()).sum().item()) <= 1e-6 * abs(lhs) + 1e-6
+    # swapping the roles of the two maps mirrors the displacement axis
+    swapped = torch.ops.cerberus.correlation(x2, x1, *p)
+    chk = out[:, 40]  # zero displacement channel is symmetric
+    assert torch.allclose(swapped[:, 40], chk, rtol=0, atol=1e-6)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-12), (torch.float16, 2e-3),
+                                       (torch.bfloat16, 1.6e-2)])
+def test_other_dtypes(dtype, tol, force_generic):
+    """fp64 bit-for-bit class accuracy; fp16/bf16 are storage formats with fp32
+    accumulation (Q6): compare with the fp64 oracle run on the rounded inputs;
+    the tolerance is the output rounding of the storage type."""
+    shp = (2, 24, 10, 20)
+    x1 = torch.from_numpy(hash_uniform(shp, 1)).to(dtype)
+    x2 = torch.from_numpy(hash_uniform(shp, 2)).to(dtype)
+    go = torch.from_numpy(hash_uniform((2, 81, 10, 20), 3)).to(dtype)
+    p = (4, 1, 4, 1, 1)
+    ref = oracle.corr_forward_ref(x1.double().numpy(), x2.double().numpy(), *p)
+    r1, r2 = oracle.corr_backward_ref(x1.double().numpy(), x2.double().numpy(),
+                                      go.double().numpy(), *p)
+    out = torch.ops.cerberus.correlation(x1.to(DEV), x2.to(DEV), *p, 1)
+    assert out.dtype == dtype
+    g1, g2 = torch.ops.cerberus.correlation_backward(x1.to(DEV), x2.to(DEV), go.to(DEV), *p, 1)
+    assert rel_err(out.double().cpu().numpy(), ref) < tol
+    assert rel_err(g1.double().cpu().numpy(), r1) < tol
+    assert rel_err(g2.double().cpu().numpy(), r2) < tol
+
+
+def test_module_train_and_eval_paths_and_inplace_leaky():
+    """Correlation nn.Module: training -> CorrelationFunction (autograd), eval ->
+    raw op (correlation.py:72-80); the caller's in-place leaky_relu on the output
+    (pwcnet_sfd.py:182) must stay legal; gradients equal torch autograd through
+    the reference-semantics CorrelationTorch."""
+    shp = (2, 16, 12, 20)
+    a = dev(hash_uniform(shp, 11)).requires_grad_(True)
+    b = dev(hash_uniform(shp, 12)).requires_grad_(True)
+    corr = ca.Correlation(pad_size=4, kernel_size=1, max_displacement=4, stride1=1, stride2=1,
+                          corr_multiply=1).to(DEV)
+    corr.train()
+    out = corr(a, b)
+    torch.nn.functional.leaky_relu(out, 0.1, inplace=True)
+    out.square().sum().backward()
+    a2 = a.detach().clone().requires_grad_(True)
+    b2 = b.detach().clone().requires_grad_(True)
+    ref = torch.nn.functional.leaky_relu(ca.CorrelationTorch(4)(a2, b2), 0.1)
+    ref.square().sum().backward()
+    assert rel_err(out.detach().cpu().numpy(), ref.detach().cpu().numpy()) < TOL
+    assert rel_err(a.grad.cpu().numpy(), a2.grad.cpu().numpy()) < TOL
+    assert rel_err(b.grad.cpu().numpy(), b2.grad.cpu().numpy()) < TOL
+    corr.eval()
+    with torch.no_grad():
+        ev = corr(a, b)
+    assert rel_err(ev.cpu().numpy(), ca.CorrelationTorch(4)(a2, b2).detach().cpu().numpy()) < TOL
+
+
+def test_fused_leaky_epilogue_matches_two_step():
+    shp = (2, 16, 12, 20)
+    a = dev(hash_uniform(shp, 13)).requires_grad_(True)
+    b = dev(hash_uniform(shp, 14)).requires_grad_(True)
+    p = (4, 1, 4, 1, 1, 1)
+    fused = torch.ops.cerberus.correlation_leaky(a, b, *p, 0.1)
+    two = torch.nn.functional.leaky_relu(torch.ops.cerberus.correlation(a, b, *p), 0.1)
+    assert torch.equal(fused, two)
+    w = dev(hash_uniform(fused.shape, 15))
+    ga, gb = torch.autograd.grad((fused * w).sum(), (a, b))
+    ha, hb = torch.autograd.grad((two * w).sum(), (a, b))
+    assert torch.equal(ga, ha) and torch.equal(gb, hb)
+
+
+def test_non_contiguous_and_empty_inputs():
+    base1 = dev(hash_uniform((2, 8, 10, 24), 21))
+    base2 = dev(hash_uniform((2, 8, 10, 24), 22))
+    v1, v2 = base1[:, :, :, ::2], base2.transpose(2, 3)[:, :, :12, :].transpose(2, 3)
+    assert not v1.is_contiguous()
+    p = (4, 1, 4, 1, 1, 1)
+    out = torch.ops.cerberus.correlation(v1, v2[:, :, :, :12], *p)
+    ref = oracle.corr_forward_ref(v1.cpu().numpy(), v2[:, :, :, :12].cpu().numpy(), 4, 1, 4, 1, 1)
+    assert rel_err(out.cpu().numpy(), ref) < TOL
+    e = torch.empty(0, 8, 10, 12, device=DEV)
+    assert torch.ops.cerberus.correlation(e, e, *p).shape == (0, 81, 10, 12)
+    g1, g2 = torch.ops.cerberus.correlation_backward(e, e, torch.empty(0, 81, 10, 12, device=DEV), *p)
+    assert g1.shape == e.shape and g2.shape == e.shape
+
+
+def test_error_behaviour():
+    a = dev(hash_uniform((1, 4, 8, 8), 1))
+    p = (4, 1, 4, 1, 1, 1)
+    with pytest.raises(RuntimeError, match="shapes differ"):
+        torch.ops.cerberus.correlation(a, a[:, :, :, :4], *p)
+    with pytest.raises(RuntimeError, match="dtypes differ"):
+        torch.ops.cerberus.correlation(a, a.half(), *p)
+    with pytest.raises(RuntimeError, match="gradOutput shape"):
+        torch.ops.cerberus.correlation_backward(a, a, a, *p)
+    with pytest.raises(RuntimeError):  # empty output geometry
+        torch.ops.cerberus.correlation(a, a, 0, 1, 10, 1, 1, 1)
+
+
+def test_current_stream_is_honoured_and_graph_capturable():
+    a = dev(hash_uniform((1, 32, 16, 24), 31))
+    b = dev(hash_uniform((1, 32, 16, 24), 32))
+    p = (4, 1, 4, 1, 1, 1)
+    want = torch.ops.cerberus.correlation(a, b, *p)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        got = torch.ops.cerberus.correlation(a, b, *p)
+    side.synchronize()
+    assert torch.equal(got, want)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        cap = torch.ops.cerberus.correlation(a, b, *p)
+        cg1, cg2 = torch.ops.cerberus.correlation_backward(a, b, cap, *p)
+    cap.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(cap, want)
+    e1, e2 = torch.ops.cerberus.correlation_backward(a, b, want, *p)
+    assert torch.equal(cg1, e1) and torch.equal(cg2, e2)
+
+
+def test_native_library_is_loaded():
+    import os
+    maps = open("/proc/%d/maps" % os.getpid()).read()
+    assert "libcerberus_hip.so" in maps

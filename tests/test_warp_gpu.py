@@ -1,0 +1,125 @@
+"""GPU parity tests for the fused flow_warp HIP kernels (through the C ABI)."""
+import numpy as np
+import pytest
+import torch
+
+import cerberusnet_amd as ca
+from cerberusnet_amd.synth import hash_uniform, W32_PYRAMID_1024x512
+from conftest import rel_err
+import oracle
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+DEV = "cuda:0"
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def hip_warp_with_grads(img, flo, go, pad):
+    i = dev(img).requires_grad_(True)
+    f = dev(flo).requires_grad_(True)
+    out = ca.flow_warp(i, f, pad=pad)
+    gi, gf = torch.autograd.grad(out, (i, f), dev(go))
+    return out.detach().cpu().numpy(), gi.cpu().numpy(), gf.cpu().numpy()
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+@pytest.mark.parametrize("pad", ["border", "zeros"])
+def test_golden_vectors(golden, tag, pad):
+    g = golden("warp_" + tag)
+    out, gi, gf = hip_warp_with_grads(g["image"], g["flow"], g["gout"], pad)
+    assert rel_err(out, g["out_" + pad]) < TOL
+    assert rel_err(gi, g["gimage_" + pad]) < TOL
+    assert rel_err(gf, g["gflow_" + pad]) < TOL
+    near = ca.flow_warp(dev(g["image"]), dev(g["flow"]), pad=pad, mode="nearest")
+    assert np.array_equal(near.cpu().numpy(), g["nearest_" + pad])
+
+
+def test_q2_zero_flow_is_not_identity(golden):
+    g = golden("warp_q2")
+    out = ca.flow_warp(dev(g["image"]), torch.zeros(1, 2, 4, 6, device=DEV))
+    assert rel_err(out.cpu().numpy(), g["out"]) < 1e-6
+    assert abs(float(out[0, 0, 0, 1]) - 0.7) < 1e-5
+
+
+SHAPES = [(1, 1, 2, 2), (2, 3, 7, 9), (1, 16, 12, 20), (2, 5, 33, 65), (1, 130, 9, 17),
+          (3, 32, 64, 128)]
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+@pytest.mark.parametrize("pad", ["border", "zeros"])
+def test_against_torch_cpu_oracle(shape, pad):
+    B, C, H, W = shape
+    img = hash_uniform(shape, 1)
+    flo = hash_uniform((B, 2, H, W), 2, -6.0, 6.0)
+    go = hash_uniform(shape, 3)
+    ref, rgi, rgf = oracle.flow_warp_grads_ref(torch.from_numpy(img), torch.from_numpy(flo),
+                                               torch.from_numpy(go), pad)
+    out, gi, gf = hip_warp_with_grads(img, flo, go, pad)
+    assert rel_err(out, ref.numpy()) < TOL
+    assert rel_err(gi, rgi.numpy()) < TOL
+    assert rel_err(gf, rgf.numpy()) < TOL
+
+
+@pytest.mark.parametrize("lvl", [1, 2, 3])
+def test_fullsize_feature_warps(lvl):
+    """Config-3 feature-warp shapes (levels 1-3), B=1 vs the torch-CPU oracle and
+    B=4 batch-independence; flows in [-6, 6) px so borders are hit."""
+    C, H, W = W32_PYRAMID_1024x512[lvl]
+    img = hash_uniform((4, C, H, W), 4)
+    flo = hash_uniform((4, 2, H, W), 5, -6.0, 6.0)
+    go = hash_uniform((4, C, H, W), 6)
+    ref, rgi, rgf = oracle.flow_warp_grads_ref(torch.from_numpy(img[:1]),
+                                               torch.from_numpy(flo[:1]),
+                                               torch.from_numpy(go[:1]), "border")
+    out, gi, gf = hip_warp_with_grads(img, flo, go, "border")
+    assert rel_err(out[:1], ref.numpy()) < TOL
+    assert rel_err(gi[:1], rgi.numpy()) < TOL
+    assert rel_err(gf[:1], rgf.numpy()) < TOL
+    o1, _, f1 = hip_warp_with_grads(img[3:], flo[3:], go[3:], "border")
+    assert np.array_equal(o1[0], out[3]) and np.array_equal(f1[0], gf[3])
+
+
+def test_rgb_loss_warps_and_reflection_nearest_modes():
+    img = hash_uniform((2, 3, 64, 128), 7)
+    flo = hash_uniform((2, 2, 64, 128), 8, -9.0, 9.0)
+    for pad in ("border", "zeros", "reflection"):
+        for mode in ("bilinear", "nearest"):
+            ref = oracle.flow_warp_ref(torch.from_numpy(img), torch.from_numpy(flo), pad, mode)
+            out = ca.flow_warp(dev(img), dev(flo), pad=pad, mode=mode)
+            assert rel_err(out.cpu().numpy(), ref.numpy()) < TOL, (pad, mode)
+
+
+def test_fp64_and_half_dtypes():
+    img = hash_uniform((1, 8, 20, 30), 9).astype(np.float64)
+    flo = hash_uniform((1, 2, 20, 30), 10, -5.0, 5.0).astype(np.float64)
+    go = hash_uniform((1, 8, 20, 30), 11).astype(np.float64)
+    ref, rgi, rgf = oracle.flow_warp_grads_ref(torch.from_numpy(img), torch.from_numpy(flo),
+                                               torch.from_numpy(go), "border")
+    out, gi, gf = hip_warp_with_grads(img, flo, go, "border")
+    assert rel_err(out, ref.numpy()) < 1e-12
+    assert rel_err(gi, rgi.numpy()) < 1e-12
+    assert rel_err(gf, rgf.numpy()) < 1e-11
+    for dt, tol in ((torch.float16, 2e-3), (torch.bfloat16, 1.6e-2)):
+        i16 = torch.from_numpy(img).to(dt)
+        f16 = torch.from_numpy(flo).to(dt)
+        r = oracle.flow_warp_ref(i16.double(), f16.double(), "border")
+        o = ca.flow_warp(i16.to(DEV), f16.to(DEV))
+        assert o.dtype == dt
+        assert rel_err(o.double().cpu().numpy(), r.numpy()) < tol
+        ii = i16.to(DEV).requires_grad_(True)
+        ff = f16.to(DEV).requires_grad_(True)
+        ca.flow_warp(ii, ff).float().sum().backward()
+        assert ii.grad is not None and ff.grad is not None and ii.grad.dtype == dt
+
+
+def test_errors():
+    img = dev(hash_uniform((1, 3, 8, 8), 1))
+    with pytest.raises(RuntimeError, match="flow shape"):
+        ca.flow_warp(img, torch.zeros(1, 2, 8, 9, device=DEV))
+    with pytest.raises(ValueError):
+        ca.flow_warp(img, torch.zeros(1, 2, 8, 8, device=DEV), pad="wrap")
+    with pytest.raises(ValueError):
+        ca.flow_warp(img, torch.zeros(1, 2, 8, 8, device=DEV), mode="bicubic")
