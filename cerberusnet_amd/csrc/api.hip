@@ -8,13 +8,26 @@
 
 namespace cerb {
 namespace {
-std::atomic<int> g_force_generic{0};
+struct Option { const char *key; std::atomic<int> value; };
+Option g_options[] = {{"corr_force_generic", {0}},   // 1: always use the generic kernels
+                      {"corr_fwd_variant", {0}},     // 0: auto, 1..6: force a tuned forward variant
+                      {"corr_bwd_cslice", {0}}};     // 0: auto, else channels per backward workgroup
 thread_local const char *t_last_kernel[2] = {"none", "none"};
+
+Option *find_option(const char *key) {
+    for (auto &o : g_options)
+        if (!std::strcmp(o.key, key)) return &o;
+    return nullptr;
+}
 
 bool dtype_ok(int dtype) { return dtype >= CERB_F32 && dtype <= CERB_F64; }
 }  // namespace
 
-int option_force_generic() { return g_force_generic.load(std::memory_order_relaxed); }
+int option_force_generic() { return g_options[0].value.load(std::memory_order_relaxed); }
+int option_value(const char *key) {
+    Option *o = find_option(key);
+    return o ? o->value.load(std::memory_order_relaxed) : 0;
+}
 void note_kernel(int which, const char *name) { t_last_kernel[which & 1] = name; }
 }  // namespace cerb
 
@@ -145,20 +158,18 @@ int cerberus_flow_warp_backward(const void *image, const void *flow, const void 
 
 int cerberus_set_option(const char *key, int value) {
     if (!key) return CERB_EINVAL;
-    if (!std::strcmp(key, "corr_force_generic")) {
-        g_force_generic.store(value, std::memory_order_relaxed);
-        return CERB_OK;
-    }
-    return CERB_EINVAL;
+    Option *o = find_option(key);
+    if (!o) return CERB_EINVAL;
+    o->value.store(value, std::memory_order_relaxed);
+    return CERB_OK;
 }
 
 int cerberus_get_option(const char *key, int *value) {
     if (!key || !value) return CERB_EINVAL;
-    if (!std::strcmp(key, "corr_force_generic")) {
-        *value = g_force_generic.load(std::memory_order_relaxed);
-        return CERB_OK;
-    }
-    return CERB_EINVAL;
+    Option *o = find_option(key);
+    if (!o) return CERB_EINVAL;
+    *value = o->value.load(std::memory_order_relaxed);
+    return CERB_OK;
 }
 
 const char *cerberus_last_kernel(int which) { return t_last_kernel[which & 1]; }

@@ -63,7 +63,7 @@ static inline int corr_geom_init(CorrGeom &g, int B, int C, int H, int W, int pa
 
 // process-wide knobs (api.hip)
 int option_force_generic();
-int option_get(const char *key, int *value);
+int option_value(const char *key);
 void note_kernel(int which, const char *name);
 
 // ---- launchers implemented in the kernel translation units ------------------

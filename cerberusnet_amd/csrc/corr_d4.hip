@@ -1,8 +1,560 @@
-// corr_d4.hip -- tuned correlation kernels (placeholder until the first tuned version lands)
+// corr_d4.hip -- tuned CDNA4 (gfx950) kernels for the one correlation
+// configuration every CerberusNet model uses: pad = max_displacement = 4,
+// kernel 1, stride1 = stride2 = 1 (pwcnet_sfd.py:131-133), fp32.
+//
+//   out[n][(dy+4)*9+(dx+4)][y][x] = 1/C * sum_c x1[n][c][y][x] * x2[n][c][y+dy][x+dx]
+//   gI1[n][c][y][x] = 1/C * sum_d gO[n][d][y][x]       * x2[n][c][y+dy][x+dx]
+//   gI2[n][c][y][x] = 1/C * sum_d gO[n][d][y-dy][x-dx] * x1[n][c][y-dy][x-dx]
+//
+// What the reference does (correlation_cuda_kernel.cu) and what replaces it:
+//   * NHWC zero-padded copies of both inputs in forward AND again in backward
+//     (.cu:13-27, 266-293, 345-376)          -> none: NCHW is read directly,
+//     W-contiguous 16-byte loads, the halo is predicated to zero.
+//   * one 32-thread block per output pixel, 81 barrier-separated serial
+//     lane-0 reductions (.cu:55-93)          -> a workgroup owns a spatial
+//     tile; the (tile + 2d)^2 window of x2 is staged in LDS once per channel
+//     chunk (double buffered, next chunk prefetched into registers while the
+//     current one is consumed); each lane owns a 4-pixel strip and slides a
+//     12-float x2 row segment across the 9 horizontal displacements in
+//     registers (36 FMAs per 4 LDS reads); the 9 vertical displacements are
+//     the 9 wavefronts of the workgroup.
+//   * channel reduction by shared memory + one lane (.cu:78-83) -> channels
+//     are split over S lane groups of a wavefront where the map is small and
+//     reduced with wave64 shuffles (ds_bpermute), no LDS round trip.
+//   * backward: 2*B sequential launches of H*W*C one-warp blocks with
+//     H*W-strided gradOutput reads (.cu:386-426) -> one launch; a lane keeps
+//     all 81 gradOutput values of its 2 pixels in registers (the flipped /
+//     shifted gather for gI2 is done once per tile) and streams channels
+//     through the LDS window: 162 FMAs per 45 ds_read_b64, no atomics, no
+//     cross-lane reduction; channels are additionally split over workgroups.
+//
+// No MFMA: this is a gather-reduce (a banded product wastes >7x the flops as a
+// dense GEMM and fp32 MFMA runs at the vector rate anyway).
 #include "common.h"
+
 namespace cerb {
-int corr_d4_forward(const void *, const void *, void *, const CorrGeom &, float, int64_t, int,
-                    hipStream_t) { return CERB_EUNSUPPORTED; }
-int corr_d4_backward(const void *, const void *, const void *, void *, void *, const CorrGeom &,
-                     int, hipStream_t) { return CERB_EUNSUPPORTED; }
+namespace {
+
+constexpr int kD = 4;            // max displacement
+constexpr int kND = 2 * kD + 1;  // 9 displacements per axis
+constexpr int kP = 4;            // pixels per lane in forward (one float4)
+
+__host__ __device__ constexpr int pad_to_residue(int x, int res) {
+    return x + ((res - x % 64) + 64) % 64;
+}
+
+// ============================================================================
+// forward
+// ============================================================================
+// S    channel groups per wavefront (lanes cg*NS .. cg*NS+NS-1 own channels
+//      [cg*C/S, (cg+1)*C/S)), reduced with shuffles at the end
+// TSX  4-pixel strips per tile row        RB  row blocks per lane
+// CC   channels per group per LDS chunk   ROT strip rotation per row (bank fix)
+// RS/RS1 row strides (floats) of the x2 / x1 LDS tiles, PRES plane-stride
+// residue mod 64 -- chosen with tools/lds_conflicts.py so that every
+// ds_read_b128 of the main loop is conflict free.
+template <int S_, int TSX_, int RB_, int CC_, int ROT_, int RS_, int RS1_, int PRES_, int WPS_ = 3>
+struct FwdCfg {
+    static constexpr int S = S_, TSX = TSX_, RB = RB_, CC = CC_, ROT = ROT_;
+    static constexpr int NS = 64 / S;        // strips per channel group
+    static constexpr int NR = NS / TSX;      // tile rows per row block
+    static constexpr int TH = NR * RB;       // tile height
+    static constexpr int TW = TSX * kP;      // tile width
+    static constexpr int HR = TH + 2 * kD;   // halo rows
+    static constexpr int HW4 = TSX + 2;      // halo width in float4
+    static constexpr int RS = RS_, RS1 = RS1_;
+    static constexpr int PS = pad_to_residue(HR * RS, PRES_);
+    static constexpr int PS1 = pad_to_residue(TH * RS1, PRES_);
+    static constexpr int NCH = S * CC;       // channel planes per chunk
+    static constexpr int THREADS = 64 * kND;
+    static constexpr int N2 = NCH * HR * HW4;  // float4 slots of the x2 halo chunk
+    static constexpr int N1 = NCH * TH * TSX;  // float4 slots of the x1 chunk
+    static constexpr int NSLOT = (N2 + N1 + THREADS - 1) / THREADS;
+    static constexpr int BUF = NCH * (PS + PS1);  // floats per LDS buffer
+    static constexpr size_t LDS_BYTES = 2 * sizeof(float) * BUF;
+    // waves per SIMD requested from the register allocator: two 9-wave workgroups per CU
+    // need 5 (<= 96 VGPRs); the 2-row-block variant keeps 72 accumulators and asks for 3
+    static constexpr int WPS = WPS_;
+    static_assert(NS % TSX == 0, "strips must tile rows");
+    static_assert(RS % 4 == 0 && RS1 % 4 == 0 && PS % 4 == 0 && PS1 % 4 == 0, "16B alignment");
+};
+
+__device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+__device__ __forceinline__ void st4(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
+
+template <typename K, bool VEC>
+__global__ __launch_bounds__(K::THREADS, K::WPS) void corr_fwd_d4_kernel(
+    const float *__restrict__ x1, const float *__restrict__ x2, float *__restrict__ out, int C,
+    int H, int W, int tiles_x, int tiles_y, float slope, int64_t out_bstride) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int S = K::S, TSX = K::TSX, RB = K::RB, CC = K::CC;
+
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6;  // vertical displacement index dy + 4
+    const int lane = tid & 63;
+    const int cg = lane / K::NS;
+    const int si = lane % K::NS;
+    const int r = si / TSX;
+    const int sx = (K::ROT == 0) ? si % TSX : (si % TSX + TSX - (K::ROT * r) % TSX) % TSX;
+
+    int bid = blockIdx.x;
+    const int tx = bid % tiles_x; bid /= tiles_x;
+    const int ty = bid % tiles_y;
+    const int b = bid / tiles_y;
+    const int x0 = tx * K::TW, y0 = ty * K::TH;
+
+    const int plane = H * W;
+    const int Cg = C / S;  // channels per group (launcher guarantees C % S == 0)
+    const int nchunks = (Cg + CC - 1) / CC;
+    const float *x1b = x1 + static_cast<int64_t>(b) * C * plane;
+    const float *x2b = x2 + static_cast<int64_t>(b) * C * plane;
+
+    // ---- per-slot staging descriptors (fixed for the whole kernel) ----
+    int goff[K::NSLOT];   // element offset inside the batch item for chunk 0
+    int loff[K::NSLOT];   // LDS float offset inside a buffer, <0: slot unused
+    int gx0[K::NSLOT];    // first x of the slot (scalar path bounds)
+    int chi[K::NSLOT];    // channel index inside the chunk, <0: slot lies outside the image
+#pragma unroll
+    for (int j = 0; j < K::NSLOT; ++j) {
+        int id = tid + j * K::THREADS;
+        goff[j] = 0; loff[j] = -1; gx0[j] = 0; chi[j] = -1;
+        if (id < K::N2) {
+            const int pl = id / (K::HR * K::HW4);
+            const int rem = id % (K::HR * K::HW4);
+            const int row = rem / K::HW4, c4 = rem % K::HW4;
+            const int i = pl / S, g = pl % S;
+            const int gy = y0 - kD + row, gx = x0 - kD + 4 * c4;
+            loff[j] = pl * K::PS + row * K::RS + 4 * c4;
+            gx0[j] = gx;
+            const bool in = gy >= 0 && gy < H && (VEC ? (gx >= 0 && gx < W) : (gx > -4 && gx < W));
+            if (in) { chi[j] = i; goff[j] = (g * Cg + i) * plane + gy * W + gx; }
+        } else if (id < K::N2 + K::N1) {
+            id -= K::N2;
+            const int pl = id / (K::TH * TSX);
+            const int rem = id % (K::TH * TSX);
+            const int row = rem / TSX, c4 = rem % TSX;
+            const int i = pl / S, g = pl % S;
+            const int gy = y0 + row, gx = x0 + 4 * c4;
+            loff[j] = K::NCH * K::PS + pl * K::PS1 + row * K::RS1 + 4 * c4;
+            gx0[j] = gx;
+            const bool in = gy < H && gx < W;
+            if (in) { chi[j] = i; goff[j] = (g * Cg + i) * plane + gy * W + gx; }
+        }
+    }
+    float4 stage[K::NSLOT];
+
+    auto prefetch = [&](int k) {
+#pragma unroll
+        for (int j = 0; j < K::NSLOT; ++j) {
+            const int id = tid + j * K::THREADS;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            const bool live = chi[j] >= 0 && (k * CC + chi[j] < Cg);
+            if (live) {
+                const float *src = (id < K::N2 ? x2b : x1b) + goff[j] + k * CC * plane;
+                if (VEC) {
+                    v = ld4(src);
+                } else {
+                    const int gx = gx0[j];
+                    if (gx >= 0 && gx < W) v.x = src[0];
+                    if (gx + 1 >= 0 && gx + 1 < W) v.y = src[1];
+                    if (gx + 2 >= 0 && gx + 2 < W) v.z = src[2];
+                    if (gx + 3 >= 0 && gx + 3 < W) v.w = src[3];
+                }
+            }
+            stage[j] = v;
+        }
+    };
+    auto commit = [&](float *buf) {
+#pragma unroll
+        for (int j = 0; j < K::NSLOT; ++j)
+            if (loff[j] >= 0) st4(buf + loff[j], stage[j]);
+    };
+
+    float acc[RB][kND][kP];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int d = 0; d < kND; ++d)
+#pragma unroll
+            for (int p = 0; p < kP; ++p) acc[rb][d][p] = 0.f;
+
+    prefetch(0);
+    for (int k = 0; k < nchunks; ++k) {
+        float *buf = smem + (k & 1) * K::BUF;
+        commit(buf);
+        __syncthreads();
+        if (k + 1 < nchunks) prefetch(k + 1);
+        const float *X2 = buf + cg * K::PS + (r + wave) * K::RS + 4 * sx;
+        const float *X1 = buf + K::NCH * K::PS + cg * K::PS1 + r * K::RS1 + 4 * sx;
+#pragma unroll
+        for (int i = 0; i < CC; ++i) {
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) {
+                const float4 a = ld4(X1 + i * S * K::PS1 + rb * K::NR * K::RS1);
+                const float *bp = X2 + i * S * K::PS + rb * K::NR * K::RS;
+                const float4 b0 = ld4(bp), b1 = ld4(bp + 4), b2 = ld4(bp + 8);
+                const float av[4] = {a.x, a.y, a.z, a.w};
+                const float bv[12] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w,
+                                      b2.x, b2.y, b2.z, b2.w};
+#pragma unroll
+                for (int d = 0; d < kND; ++d)
+#pragma unroll
+                    for (int p = 0; p < kP; ++p)
+                        acc[rb][d][p] = fmaf(av[p], bv[p + d], acc[rb][d][p]);
+            }
+        }
+    }
+
+    // ---- channel-group reduction with wave64 shuffles ----
+    if (S > 1) {
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+            for (int d = 0; d < kND; ++d)
+#pragma unroll
+                for (int p = 0; p < kP; ++p) {
+                    float v = acc[rb][d][p];
+#pragma unroll
+                    for (int m = K::NS; m < 64; m <<= 1) v += __shfl_xor(v, m, 64);
+                    acc[rb][d][p] = v;
+                }
+    }
+
+    // ---- epilogue: 1/C, fused LeakyReLU, coalesced stores ----
+    if (cg != 0) return;
+    const float nelems = static_cast<float>(C);
+    const int64_t obs = out_bstride ? out_bstride : static_cast<int64_t>(kND * kND) * plane;
+    float *ob = out + b * obs + static_cast<int64_t>(wave * kND) * plane;
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+        const int y = y0 + r + rb * K::NR;
+        const int x = x0 + 4 * sx;
+        if (y >= H || x >= W) continue;
+#pragma unroll
+        for (int d = 0; d < kND; ++d) {
+            float v[4];
+#pragma unroll
+            for (int p = 0; p < kP; ++p) {
+                const float q = acc[rb][d][p] / nelems;
+                v[p] = q > 0.f ? q : q * slope;
+            }
+            float *dst = ob + static_cast<int64_t>(d) * plane + y * W + x;
+            if (VEC) {
+                st4(dst, make_float4(v[0], v[1], v[2], v[3]));
+            } else {
+#pragma unroll
+                for (int p = 0; p < kP; ++p)
+                    if (x + p < W) dst[p] = v[p];
+            }
+        }
+    }
+}
+
+// ============================================================================
+// backward
+// ============================================================================
+// TSXP pixel pairs per tile row (tile width 2*TSXP); a wavefront covers
+// 64/TSXP rows, the workgroup's 4 wavefronts stack vertically.
+// RS is the halo row stride: TW+8 for TSXP=32 (each 32-lane half of a
+// ds_read_b64 is one row = 64 consecutive dwords), 96 for TSXP=16 (rows r,r+1
+// of a half must differ by 32 banks).
+template <int TSXP_, int CC_, int RS_>
+struct BwdCfg {
+    static constexpr int TSXP = TSXP_, CC = CC_, RS = RS_;
+    static constexpr int TW = 2 * TSXP;
+    static constexpr int RPW = 64 / TSXP;      // rows per wavefront
+    static constexpr int TH = 4 * RPW;         // 4 wavefronts
+    static constexpr int HR = TH + 2 * kD;
+    static constexpr int HW4 = (TW + 2 * kD) / 4;
+    static constexpr int PS = HR * RS;
+    static constexpr int THREADS = 256;
+    static constexpr int N = CC * HR * HW4;
+    static constexpr int NSLOT = (N + THREADS - 1) / THREADS;
+    static constexpr int BUF = CC * PS;
+    static constexpr size_t LDS_BYTES = 2 * sizeof(float) * BUF;
+};
+
+__device__ __forceinline__ float2 ld2(const float *p) { return *reinterpret_cast<const float2 *>(p); }
+struct __attribute__((packed, aligned(4))) float2_u { float x, y; };  // dword-aligned pair
+__device__ __forceinline__ float2 ld2u(const float *p) {
+    const float2_u t = *reinterpret_cast<const float2_u *>(p);
+    return make_float2(t.x, t.y);
+}
+
+template <typename K, bool VEC>
+__global__ __launch_bounds__(256, 2) void corr_bwd_d4_kernel(
+    const float *__restrict__ x1, const float *__restrict__ x2, const float *__restrict__ gout,
+    float *__restrict__ gin1, float *__restrict__ gin2, int C, int H, int W, int tiles_x,
+    int tiles_y, int cslice) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int CC = K::CC;
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int r = wave * K::RPW + lane / K::TSXP;
+    const int sxp = lane % K::TSXP;
+
+    int bid = blockIdx.x;
+    const int tx = bid % tiles_x; bid /= tiles_x;
+    const int ty = bid % tiles_y;
+    const int b = bid / tiles_y;
+    const int x0 = tx * K::TW, y0 = ty * K::TH;
+    const int side = blockIdx.z;                 // 0: gradInput1, 1: gradInput2
+    const int c_begin = blockIdx.y * cslice;
+    const int c_end = min(C, c_begin + cslice);
+    const int plane = H * W;
+
+    const float *src = (side == 0 ? x2 : x1) + static_cast<int64_t>(b) * C * plane;
+    float *dstb = (side == 0 ? gin1 : gin2) + static_cast<int64_t>(b) * C * plane;
+    const float *gob = gout + static_cast<int64_t>(b) * (kND * kND) * plane;
+
+    const int y = y0 + r, x = x0 + 2 * sxp;
+    const bool live = y < H && x < W;
+
+    // ---- staging descriptors ----
+    int goff[K::NSLOT], loff[K::NSLOT], gx0[K::NSLOT], chi[K::NSLOT];
+#pragma unroll
+    for (int j = 0; j < K::NSLOT; ++j) {
+        const int id = tid + j * K::THREADS;
+        goff[j] = 0; loff[j] = -1; gx0[j] = 0; chi[j] = -1;
+        if (id < K::N) {
+            const int pl = id / (K::HR * K::HW4);
+            const int rem = id % (K::HR * K::HW4);
+            const int row = rem / K::HW4, c4 = rem % K::HW4;
+            const int gy = y0 - kD + row, gx = x0 - kD + 4 * c4;
+            loff[j] = pl * K::PS + row * K::RS + 4 * c4;
+            gx0[j] = gx;
+            const bool in = gy >= 0 && gy < H && (VEC ? (gx >= 0 && gx < W) : (gx > -4 && gx < W));
+            if (in) { chi[j] = pl; goff[j] = pl * plane + gy * W + gx; }
+        }
+    }
+    float4 stage[K::NSLOT];
+    auto prefetch = [&](int c_first) {
+#pragma unroll
+        for (int j = 0; j < K::NSLOT; ++j) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (chi[j] >= 0 && c_first + chi[j] < c_end) {
+                const float *p = src + static_cast<int64_t>(c_first) * plane + goff[j];
+                if (VEC) {
+                    v = ld4(p);
+                } else {
+                    const int gx = gx0[j];
+                    if (gx >= 0 && gx < W) v.x = p[0];
+                    if (gx + 1 >= 0 && gx + 1 < W) v.y = p[1];
+                    if (gx + 2 >= 0 && gx + 2 < W) v.z = p[2];
+                    if (gx + 3 >= 0 && gx + 3 < W) v.w = p[3];
+                }
+            }
+            stage[j] = v;
+        }
+    };
+    auto commit = [&](float *buf) {
+#pragma unroll
+        for (int j = 0; j < K::NSLOT; ++j)
+            if (loff[j] >= 0) st4(buf + loff[j], stage[j]);
+    };
+
+    prefetch(c_begin);  // in flight while the gradOutput registers are gathered
+
+    // ---- the 81 gradOutput values of this lane's two pixels ----
+    // side 0: g[d][p] = gO[d][y][x+p]
+    // side 1: g[d][p] = gO[80-d][y+dy][x+p+dx]   (d = (dy+4)*9 + dx+4), 0 outside
+    float g[kND * kND][2];
+#pragma unroll
+    for (int d = 0; d < kND * kND; ++d) {
+        const int dy = d / kND - kD, dx = d % kND - kD;
+        float v0 = 0.f, v1 = 0.f;
+        if (live) {
+            if (side == 0) {
+                const float *p = gob + static_cast<int64_t>(d) * plane + y * W + x;
+                if (VEC) { const float2 t = ld2(p); v0 = t.x; v1 = t.y; }
+                else { v0 = p[0]; if (x + 1 < W) v1 = p[1]; }
+            } else {
+                const int yy = y + dy, xx = x + dx;
+                if (yy >= 0 && yy < H) {
+                    const float *p = gob + static_cast<int64_t>(kND * kND - 1 - d) * plane + yy * W + xx;
+                    if (xx >= 0 && xx + 1 < W) { const float2 t = ld2u(p); v0 = t.x; v1 = t.y; }
+                    else {
+                        if (xx >= 0 && xx < W) v0 = p[0];
+                        if (xx + 1 >= 0 && xx + 1 < W) v1 = p[1];
+                    }
+                }
+            }
+        }
+        g[d][0] = v0; g[d][1] = v1;
+    }
+
+    const float nelems = static_cast<float>(C);
+    int it = 0;
+    for (int c0 = c_begin; c0 < c_end; c0 += CC, ++it) {
+        float *buf = smem + (it & 1) * K::BUF;
+        commit(buf);
+        __syncthreads();
+        if (c0 + CC < c_end) prefetch(c0 + CC);
+        const float *wbase = buf + r * K::RS + 2 * sxp;
+#pragma unroll 1
+        for (int i = 0; i < CC; ++i) {
+            if (c0 + i >= c_end) break;
+            const float *wp = wbase + i * K::PS;
+            float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+            for (int dyi = 0; dyi < kND; ++dyi) {
+                float w[10];
+#pragma unroll
+                for (int q = 0; q < 5; ++q) {
+                    const float2 t = ld2(wp + dyi * K::RS + 2 * q);
+                    w[2 * q] = t.x; w[2 * q + 1] = t.y;
+                }
+#pragma unroll
+                for (int dxi = 0; dxi < kND; ++dxi) {
+                    a0 = fmaf(g[dyi * kND + dxi][0], w[dxi], a0);
+                    a1 = fmaf(g[dyi * kND + dxi][1], w[dxi + 1], a1);
+                }
+            }
+            if (live) {
+                float *dst = dstb + static_cast<int64_t>(c0 + i) * plane + y * W + x;
+                if (VEC) {
+                    *reinterpret_cast<float2 *>(dst) = make_float2(a0 / nelems, a1 / nelems);
+                } else {
+                    dst[0] = a0 / nelems;
+                    if (x + 1 < W) dst[1] = a1 / nelems;
+                }
+            }
+        }
+    }
+}
+
+// ---- host side -------------------------------------------------------------
+// LDS above 64 KiB needs an explicit opt-in, once per kernel (flag owned by the call site)
+template <typename Kern>
+int ensure_lds(Kern kern, size_t bytes, bool *done) {
+    if (bytes <= 64 * 1024 || *done) return CERB_OK;
+    *done = true;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       static_cast<int>(bytes));
+    return e == hipSuccess ? CERB_OK : static_cast<int>(e);
+}
+
+template <typename K>
+int launch_fwd(const char *name, const float *x1, const float *x2, float *out, const CorrGeom &g,
+               float slope, int64_t obs, bool vec, hipStream_t s) {
+    const int tiles_x = (g.W + K::TW - 1) / K::TW, tiles_y = (g.H + K::TH - 1) / K::TH;
+    const int64_t blocks = static_cast<int64_t>(g.B) * tiles_x * tiles_y;
+    if (blocks > 0x7fffffff) return CERB_ETOOLARGE;
+    note_kernel(0, name);
+    int rc;
+    static bool lds_v = false, lds_s = false;
+    if (vec) {
+        if ((rc = ensure_lds(corr_fwd_d4_kernel<K, true>, K::LDS_BYTES, &lds_v))) return rc;
+        hipLaunchKernelGGL((corr_fwd_d4_kernel<K, true>), dim3(static_cast<unsigned>(blocks)),
+                           dim3(K::THREADS), K::LDS_BYTES, s, x1, x2, out, g.C, g.H, g.W, tiles_x,
+                           tiles_y, slope, obs);
+    } else {
+        if ((rc = ensure_lds(corr_fwd_d4_kernel<K, false>, K::LDS_BYTES, &lds_s))) return rc;
+        hipLaunchKernelGGL((corr_fwd_d4_kernel<K, false>), dim3(static_cast<unsigned>(blocks)),
+                           dim3(K::THREADS), K::LDS_BYTES, s, x1, x2, out, g.C, g.H, g.W, tiles_x,
+                           tiles_y, slope, obs);
+    }
+    return launch_status();
+}
+
+//                     S  TSX RB CC ROT RS  RS1 PRES
+using FwdA2 = FwdCfg<1, 16, 2, 4, 2, 72, 72, 0>;   // 8x64 tile, fine levels
+using FwdA1 = FwdCfg<1, 16, 1, 4, 2, 72, 72, 0>;   // 4x64 tile
+using FwdB1 = FwdCfg<2, 16, 1, 4, 2, 72, 72, 0>;   // 2x64 tile, 2 channel groups
+using FwdC1 = FwdCfg<4, 16, 1, 4, 0, 72, 64, 0>;   // 1x64 tile, 4 channel groups
+using FwdD1 = FwdCfg<8, 8, 1, 4, 0, 40, 32, 32>;   // 1x32 tile, 8 channel groups
+using FwdE1 = FwdCfg<16, 4, 1, 2, 0, 24, 16, 16>;  // 1x16 tile, 16 channel groups
+
+template <typename K>
+int64_t fwd_tiles(const CorrGeom &g) {
+    return static_cast<int64_t>(g.B) * ((g.W + K::TW - 1) / K::TW) * ((g.H + K::TH - 1) / K::TH);
+}
+
+template <typename K>
+int launch_bwd(const char *name, const float *x1, const float *x2, const float *gout, float *gin1,
+               float *gin2, const CorrGeom &g, bool vec, hipStream_t s) {
+    const int tiles_x = (g.W + K::TW - 1) / K::TW, tiles_y = (g.H + K::TH - 1) / K::TH;
+    const int64_t tiles = static_cast<int64_t>(g.B) * tiles_x * tiles_y;
+    if (tiles > 0x7fffffff) return CERB_ETOOLARGE;
+    // channel slice per workgroup: amortise the 81-register gradOutput gather over
+    // >= 2 chunks, but keep >= ~2048 workgroups in flight when the map is small
+    int cslice = g.C;
+    while (cslice > 8 && tiles * 2 * ((g.C + cslice - 1) / cslice) < 2048) cslice /= 2;
+    if (const int forced = option_value("corr_bwd_cslice")) cslice = forced;
+    cslice = ((cslice + K::CC - 1) / K::CC) * K::CC;
+    const int nslice = (g.C + cslice - 1) / cslice;
+    if (nslice > 65535) return CERB_ETOOLARGE;
+    note_kernel(1, name);
+    const dim3 grid(static_cast<unsigned>(tiles), nslice, 2);
+    int rc;
+    static bool lds_v = false, lds_s = false;
+    if (vec) {
+        if ((rc = ensure_lds(corr_bwd_d4_kernel<K, true>, K::LDS_BYTES, &lds_v))) return rc;
+        hipLaunchKernelGGL((corr_bwd_d4_kernel<K, true>), grid, dim3(K::THREADS), K::LDS_BYTES, s,
+                           x1, x2, gout, gin1, gin2, g.C, g.H, g.W, tiles_x, tiles_y, cslice);
+    } else {
+        if ((rc = ensure_lds(corr_bwd_d4_kernel<K, false>, K::LDS_BYTES, &lds_s))) return rc;
+        hipLaunchKernelGGL((corr_bwd_d4_kernel<K, false>), grid, dim3(K::THREADS), K::LDS_BYTES, s,
+                           x1, x2, gout, gin1, gin2, g.C, g.H, g.W, tiles_x, tiles_y, cslice);
+    }
+    return launch_status();
+}
+
+using BwdWide = BwdCfg<32, 2, 72>;    // 8x64 tile
+using BwdNarrow = BwdCfg<16, 4, 96>;  // 16x32 tile
+
+bool fast_config(const CorrGeom &g, int dtype) {
+    return dtype == CERB_F32 && g.pad == kD && g.maxd == kD && g.ksize == 1 && g.s1 == 1 &&
+           g.s2 == 1 && static_cast<int64_t>(g.C) * g.H * g.W < (1ll << 30);
+}
+
+bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+int corr_d4_forward(const void *in1, const void *in2, void *out, const CorrGeom &g, float slope,
+                    int64_t obs, int dtype, hipStream_t s) {
+    if (!fast_config(g, dtype)) return CERB_EUNSUPPORTED;
+    const float *x1 = static_cast<const float *>(in1), *x2 = static_cast<const float *>(in2);
+    float *o = static_cast<float *>(out);
+    const bool vec = g.W % 4 == 0 && aligned16(in1) && aligned16(in2) && aligned16(out) &&
+                     (obs % 4 == 0);
+    // pick the widest tile that still yields enough workgroups to fill 256 CUs;
+    // fall back to channel-split variants (shuffle reduction) on small maps
+    switch (option_value("corr_fwd_variant")) {  // tuning / test hook
+        case 1: return launch_fwd<FwdA2>("corr_fwd_d4_8x64", x1, x2, o, g, slope, obs, vec, s);
+        case 2: return launch_fwd<FwdA1>("corr_fwd_d4_4x64", x1, x2, o, g, slope, obs, vec, s);
+        case 3: if (g.C % 2 == 0) return launch_fwd<FwdB1>("corr_fwd_d4_2x64_s2", x1, x2, o, g, slope, obs, vec, s); break;
+        case 4: if (g.C % 4 == 0) return launch_fwd<FwdC1>("corr_fwd_d4_1x64_s4", x1, x2, o, g, slope, obs, vec, s); break;
+        case 5: if (g.C % 8 == 0) return launch_fwd<FwdD1>("corr_fwd_d4_1x32_s8", x1, x2, o, g, slope, obs, vec, s); break;
+        case 6: if (g.C % 16 == 0) return launch_fwd<FwdE1>("corr_fwd_d4_1x16_s16", x1, x2, o, g, slope, obs, vec, s); break;
+        default: break;
+    }
+    const int64_t want = 384;
+    if (fwd_tiles<FwdA2>(g) >= 2 * want) return launch_fwd<FwdA2>("corr_fwd_d4_8x64", x1, x2, o, g, slope, obs, vec, s);
+    if (fwd_tiles<FwdA1>(g) >= want || g.C < 16)
+        return launch_fwd<FwdA1>("corr_fwd_d4_4x64", x1, x2, o, g, slope, obs, vec, s);
+    if (g.C % 2 == 0 && (fwd_tiles<FwdB1>(g) >= want || g.C % 4 != 0 || g.C < 32))
+        return launch_fwd<FwdB1>("corr_fwd_d4_2x64_s2", x1, x2, o, g, slope, obs, vec, s);
+    if (g.C % 4 == 0 && (fwd_tiles<FwdC1>(g) >= want || g.C % 8 != 0 || g.C < 64))
+        return launch_fwd<FwdC1>("corr_fwd_d4_1x64_s4", x1, x2, o, g, slope, obs, vec, s);
+    if (g.C % 8 == 0 && (fwd_tiles<FwdD1>(g) >= want || g.C % 16 != 0 || g.C < 128))
+        return launch_fwd<FwdD1>("corr_fwd_d4_1x32_s8", x1, x2, o, g, slope, obs, vec, s);
+    if (g.C % 16 == 0) return launch_fwd<FwdE1>("corr_fwd_d4_1x16_s16", x1, x2, o, g, slope, obs, vec, s);
+    return launch_fwd<FwdA1>("corr_fwd_d4_4x64", x1, x2, o, g, slope, obs, vec, s);
+}
+
+int corr_d4_backward(const void *in1, const void *in2, const void *gout, void *gin1, void *gin2,
+                     const CorrGeom &g, int dtype, hipStream_t s) {
+    if (!fast_config(g, dtype)) return CERB_EUNSUPPORTED;
+    const float *x1 = static_cast<const float *>(in1), *x2 = static_cast<const float *>(in2);
+    const float *go = static_cast<const float *>(gout);
+    float *g1 = static_cast<float *>(gin1), *g2 = static_cast<float *>(gin2);
+    const bool vec = g.W % 4 == 0 && aligned16(in1) && aligned16(in2) && aligned16(gout) &&
+                     aligned16(gin1) && aligned16(gin2);
+    if (g.W <= 32) return launch_bwd<BwdNarrow>("corr_bwd_d4_16x32", x1, x2, go, g1, g2, g, vec, s);
+    return launch_bwd<BwdWide>("corr_bwd_d4_8x64", x1, x2, go, g1, g2, g, vec, s);
+}
+
 }  // namespace cerb
