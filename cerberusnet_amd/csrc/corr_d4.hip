@@ -43,6 +43,20 @@ __host__ __device__ constexpr int pad_to_residue(int x, int res) {
     return x + ((res - x % 64) + 64) % 64;
 }
 
+// XCD-aware work-item order (speed only, never correctness).  The dispatcher deals
+// workgroups round-robin over the 8 XCDs, each with a private 4 MiB L2, so
+// blocks b and b+8 share an L2 but b and b+1 do not.  Remap so that every XCD
+// walks ONE contiguous range of tiles: spatial neighbours (which share halo rows
+// of x2 and the gradOutput tile) then hit in the same L2 instead of going back
+// to the fabric.  Bijective for any block count.  (Measured on the first
+// version: L2 hit rate 20-38 %, fabric reads 2.2x the algorithmic bytes.)
+__device__ __forceinline__ int xcd_swizzle(int bid, int nblocks) {
+    constexpr int kXcd = 8;
+    const int x = bid % kXcd, idx = bid / kXcd;
+    const int q = nblocks / kXcd, rem = nblocks % kXcd;
+    return x * q + min(x, rem) + idx;
+}
+
 // ============================================================================
 // forward
 // ============================================================================
@@ -53,7 +67,8 @@ __host__ __device__ constexpr int pad_to_residue(int x, int res) {
 // RS/RS1 row strides (floats) of the x2 / x1 LDS tiles, PRES plane-stride
 // residue mod 64 -- chosen with tools/lds_conflicts.py so that every
 // ds_read_b128 of the main loop is conflict free.
-template <int S_, int TSX_, int RB_, int CC_, int ROT_, int RS_, int RS1_, int PRES_, int WPS_ = 3>
+template <int S_, int TSX_, int RB_, int CC_, int ROT_, int RS_, int RS1_, int PRES_, int WPS_ = 3,
+          int NSET_ = 1>
 struct FwdCfg {
     static constexpr int S = S_, TSX = TSX_, RB = RB_, CC = CC_, ROT = ROT_;
     static constexpr int NS = 64 / S;        // strips per channel group
@@ -75,6 +90,7 @@ struct FwdCfg {
     // waves per SIMD requested from the register allocator: two 9-wave workgroups per CU
     // need 5 (<= 96 VGPRs); the 2-row-block variant keeps 72 accumulators and asks for 3
     static constexpr int WPS = WPS_;
+    static constexpr int NSET = NSET_;  // chunks of global loads kept in flight (register sets)
     static_assert(NS % TSX == 0, "strips must tile rows");
     static_assert(RS % 4 == 0 && RS1 % 4 == 0 && PS % 4 == 0 && PS1 % 4 == 0, "16B alignment");
 };
@@ -82,12 +98,28 @@ struct FwdCfg {
 __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
 __device__ __forceinline__ void st4(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
 
+typedef float float2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float2v pkfma(float2v a, float2v b, float2v c) {
+    return __builtin_elementwise_fma(a, b, c);  // v_pk_fma_f32
+}
+__device__ __forceinline__ float2v ld2v(const float *p) { return *reinterpret_cast<const float2v *>(p); }
+
+// 16 bytes of zeros in device memory: the source of every halo / padding slot, so
+// that staging loads are UNCONDITIONAL.  (A load under a branch makes hipcc's
+// waitcnt pass fall back to vmcnt(0) at the next use, which serialises the
+// prefetch pipeline -- seen in the ISA of the first version.)
+__device__ __attribute__((aligned(16))) float g_zero16[4] = {0.f, 0.f, 0.f, 0.f};
+
 template <typename K, bool VEC>
 __global__ __launch_bounds__(K::THREADS, K::WPS) void corr_fwd_d4_kernel(
     const float *__restrict__ x1, const float *__restrict__ x2, float *__restrict__ out, int C,
-    int H, int W, int tiles_x, int tiles_y, float slope, int64_t out_bstride) {
+    int H, int W, int tiles_x, int tiles_y, float slope, int64_t out_bstride, int dbg) {
+    // dbg: timing-ablation mask (results are WRONG when non-zero; "corr_debug_ablate" option,
+    // never set by the product path): 1 = store only displacement 0, 2 = load only the first
+    // chunk, 4 = skip the FMAs
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int S = K::S, TSX = K::TSX, RB = K::RB, CC = K::CC;
+    constexpr int S = K::S, TSX = K::TSX, RB = K::RB, CC = K::CC, NSET = K::NSET;
+    if (dbg & 64) return;  // ablation: launch + dispatch only
 
     const int tid = threadIdx.x;
     const int wave = tid >> 6;  // vertical displacement index dy + 4
@@ -97,7 +129,7 @@ __global__ __launch_bounds__(K::THREADS, K::WPS) void corr_fwd_d4_kernel(
     const int r = si / TSX;
     const int sx = (K::ROT == 0) ? si % TSX : (si % TSX + TSX - (K::ROT * r) % TSX) % TSX;
 
-    int bid = blockIdx.x;
+    int bid = xcd_swizzle(blockIdx.x, gridDim.x);
     const int tx = bid % tiles_x; bid /= tiles_x;
     const int ty = bid % tiles_y;
     const int b = bid / tiles_y;
@@ -110,14 +142,14 @@ __global__ __launch_bounds__(K::THREADS, K::WPS) void corr_fwd_d4_kernel(
     const float *x2b = x2 + static_cast<int64_t>(b) * C * plane;
 
     // ---- per-slot staging descriptors (fixed for the whole kernel) ----
-    int goff[K::NSLOT];   // element offset inside the batch item for chunk 0
-    int loff[K::NSLOT];   // LDS float offset inside a buffer, <0: slot unused
-    int gx0[K::NSLOT];    // first x of the slot (scalar path bounds)
-    int chi[K::NSLOT];    // channel index inside the chunk, <0: slot lies outside the image
+    int goff[K::NSLOT];           // element offset (+4) of chunk 0 in the batch item, <0: zeros
+    int loff[K::NSLOT];           // LDS float offset inside a buffer, <0: slot unused
+    int gx0[K::NSLOT];            // first x of the slot (scalar path bounds)
+    int chi[K::NSLOT];            // channel index inside the chunk
 #pragma unroll
     for (int j = 0; j < K::NSLOT; ++j) {
         int id = tid + j * K::THREADS;
-        goff[j] = 0; loff[j] = -1; gx0[j] = 0; chi[j] = -1;
+        goff[j] = -1; loff[j] = -1; gx0[j] = 0; chi[j] = 0;
         if (id < K::N2) {
             const int pl = id / (K::HR * K::HW4);
             const int rem = id % (K::HR * K::HW4);
@@ -125,9 +157,9 @@ __global__ __launch_bounds__(K::THREADS, K::WPS) void corr_fwd_d4_kernel(
             const int i = pl / S, g = pl % S;
             const int gy = y0 - kD + row, gx = x0 - kD + 4 * c4;
             loff[j] = pl * K::PS + row * K::RS + 4 * c4;
-            gx0[j] = gx;
+            gx0[j] = gx; chi[j] = i;
             const bool in = gy >= 0 && gy < H && (VEC ? (gx >= 0 && gx < W) : (gx > -4 && gx < W));
-            if (in) { chi[j] = i; goff[j] = (g * Cg + i) * plane + gy * W + gx; }
+            if (in) goff[j] = (g * Cg + i) * plane + gy * W + gx + 4;  // +4: scalar path gx > -4
         } else if (id < K::N2 + K::N1) {
             id -= K::N2;
             const int pl = id / (K::TH * TSX);
@@ -136,54 +168,59 @@ __global__ __launch_bounds__(K::THREADS, K::WPS) void corr_fwd_d4_kernel(
             const int i = pl / S, g = pl % S;
             const int gy = y0 + row, gx = x0 + 4 * c4;
             loff[j] = K::NCH * K::PS + pl * K::PS1 + row * K::RS1 + 4 * c4;
-            gx0[j] = gx;
+            gx0[j] = gx; chi[j] = i;
             const bool in = gy < H && gx < W;
-            if (in) { chi[j] = i; goff[j] = (g * Cg + i) * plane + gy * W + gx; }
+            if (in) goff[j] = (g * Cg + i) * plane + gy * W + gx + 4;
         }
     }
-    float4 stage[K::NSLOT];
+    float4 stage[NSET][K::NSLOT];
 
-    auto prefetch = [&](int k) {
+    auto prefetch = [&](int k, float4(&st)[K::NSLOT]) {
 #pragma unroll
         for (int j = 0; j < K::NSLOT; ++j) {
-            const int id = tid + j * K::THREADS;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            const bool live = chi[j] >= 0 && (k * CC + chi[j] < Cg);
-            if (live) {
-                const float *src = (id < K::N2 ? x2b : x1b) + goff[j] + k * CC * plane;
-                if (VEC) {
-                    v = ld4(src);
-                } else {
+            const bool live = goff[j] >= 0 && (k * CC + chi[j] < Cg);
+            const float *base = (tid + j * K::THREADS < K::N2) ? x2b : x1b;
+            if (VEC) {
+                // branch-free: dead slots (halo outside the image, channels past the
+                // end, chunks past the last one) read the zero block instead
+                const float *src = live ? base + (goff[j] - 4) + k * CC * plane : g_zero16;
+                st[j] = ld4(src);
+            } else {
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (live) {
+                    const float *src = base + (goff[j] - 4) + k * CC * plane;
                     const int gx = gx0[j];
                     if (gx >= 0 && gx < W) v.x = src[0];
                     if (gx + 1 >= 0 && gx + 1 < W) v.y = src[1];
                     if (gx + 2 >= 0 && gx + 2 < W) v.z = src[2];
                     if (gx + 3 >= 0 && gx + 3 < W) v.w = src[3];
                 }
+                st[j] = v;
             }
-            stage[j] = v;
         }
     };
-    auto commit = [&](float *buf) {
+    auto commit = [&](float *buf, const float4(&st)[K::NSLOT]) {
 #pragma unroll
         for (int j = 0; j < K::NSLOT; ++j)
-            if (loff[j] >= 0) st4(buf + loff[j], stage[j]);
+            if (loff[j] >= 0) st4(buf + loff[j], st[j]);
     };
 
-    float acc[RB][kND][kP];
+    // accumulators: for pixel p the 9 horizontal displacements are kept as 4
+    // register pairs + 1 single, paired so that every packed FMA reads an ALIGNED
+    // pair of the x2 row segment: p even -> pairs (0,1)(2,3)(4,5)(6,7), single 8;
+    // p odd -> single 0, pairs (1,2)(3,4)(5,6)(7,8).
+    float2v accp[RB][kP][4];
+    float accs[RB][kP];
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-        for (int d = 0; d < kND; ++d)
+        for (int p = 0; p < kP; ++p) {
+            accs[rb][p] = 0.f;
 #pragma unroll
-            for (int p = 0; p < kP; ++p) acc[rb][d][p] = 0.f;
+            for (int j = 0; j < 4; ++j) accp[rb][p][j] = float2v{0.f, 0.f};
+        }
 
-    prefetch(0);
-    for (int k = 0; k < nchunks; ++k) {
-        float *buf = smem + (k & 1) * K::BUF;
-        commit(buf);
-        __syncthreads();
-        if (k + 1 < nchunks) prefetch(k + 1);
+    auto compute = [&](const float *buf) {
         const float *X2 = buf + cg * K::PS + (r + wave) * K::RS + 4 * sx;
         const float *X1 = buf + K::NCH * K::PS + cg * K::PS1 + r * K::RS1 + 4 * sx;
 #pragma unroll
@@ -194,16 +231,58 @@ __global__ __launch_bounds__(K::THREADS, K::WPS) void corr_fwd_d4_kernel(
                 const float *bp = X2 + i * S * K::PS + rb * K::NR * K::RS;
                 const float4 b0 = ld4(bp), b1 = ld4(bp + 4), b2 = ld4(bp + 8);
                 const float av[4] = {a.x, a.y, a.z, a.w};
-                const float bv[12] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w,
-                                      b2.x, b2.y, b2.z, b2.w};
+                const float2v bw[6] = {float2v{b0.x, b0.y}, float2v{b0.z, b0.w},
+                                       float2v{b1.x, b1.y}, float2v{b1.z, b1.w},
+                                       float2v{b2.x, b2.y}, float2v{b2.z, b2.w}};
 #pragma unroll
-                for (int d = 0; d < kND; ++d)
+                for (int p = 0; p < kP; ++p) {
+                    const int off = p & 1;
+                    const float2v aa = float2v{av[p], av[p]};
 #pragma unroll
-                    for (int p = 0; p < kP; ++p)
-                        acc[rb][d][p] = fmaf(av[p], bv[p + d], acc[rb][d][p]);
+                    for (int j = 0; j < 4; ++j)
+                        accp[rb][p][j] = pkfma(aa, bw[(p + off) / 2 + j], accp[rb][p][j]);
+                    const float bs = off ? bw[(p - 1) / 2].y : bw[(p + 8) / 2].x;
+                    accs[rb][p] = fmaf(av[p], bs, accs[rb][p]);
+                }
+            }
+        }
+    };
+
+    // ---- software pipeline: NSET chunks of global loads in flight ----
+#pragma unroll
+    for (int s = 0; s < NSET; ++s) prefetch(s, stage[s]);
+    for (int k0 = 0; k0 < nchunks; k0 += NSET) {
+#pragma unroll
+        for (int s = 0; s < NSET; ++s) {
+            const int k = k0 + s;
+            if (k < nchunks) {
+                float *buf = smem + (k & 1) * K::BUF;
+                if (!(dbg & 8)) commit(buf, stage[s]);
+                if (!(dbg & 16)) __syncthreads();
+                if (!(dbg & 2)) prefetch(k + NSET, stage[s]);  // unconditional (zeros past the end)
+                if (!(dbg & 4)) compute(buf);
             }
         }
     }
+
+    if (dbg & 32) {  // ablation: no epilogue
+        if (tid == 0) out[blockIdx.x] = accs[0][0] + stage[0][0].x;
+        return;
+    }
+    // ---- unpack to acc[rb][d][p] ----
+    float acc[RB][kND][kP];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int p = 0; p < kP; ++p) {
+            const int off = p & 1;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc[rb][2 * j + off][p] = accp[rb][p][j].x;
+                acc[rb][2 * j + off + 1][p] = accp[rb][p][j].y;
+            }
+            acc[rb][off ? 0 : 8][p] = accs[rb][p];
+        }
 
     // ---- channel-group reduction with wave64 shuffles ----
     if (S > 1) {
@@ -222,7 +301,9 @@ __global__ __launch_bounds__(K::THREADS, K::WPS) void corr_fwd_d4_kernel(
 
     // ---- epilogue: 1/C, fused LeakyReLU, coalesced stores ----
     if (cg != 0) return;
-    const float nelems = static_cast<float>(C);
+    // sum / nelems as in the reference (.cu:85,91); a reciprocal multiply is exact
+    // whenever C is a power of two (every CerberusNet level) and within 1 ulp otherwise
+    const float inv_nelems = 1.0f / static_cast<float>(C);
     const int64_t obs = out_bstride ? out_bstride : static_cast<int64_t>(kND * kND) * plane;
     float *ob = out + b * obs + static_cast<int64_t>(wave * kND) * plane;
 #pragma unroll
@@ -232,10 +313,11 @@ __global__ __launch_bounds__(K::THREADS, K::WPS) void corr_fwd_d4_kernel(
         if (y >= H || x >= W) continue;
 #pragma unroll
         for (int d = 0; d < kND; ++d) {
+            if ((dbg & 1) && d) continue;
             float v[4];
 #pragma unroll
             for (int p = 0; p < kP; ++p) {
-                const float q = acc[rb][d][p] / nelems;
+                const float q = acc[rb][d][p] * inv_nelems;
                 v[p] = q > 0.f ? q : q * slope;
             }
             float *dst = ob + static_cast<int64_t>(d) * plane + y * W + x;
@@ -285,7 +367,7 @@ template <typename K, bool VEC>
 __global__ __launch_bounds__(256, 2) void corr_bwd_d4_kernel(
     const float *__restrict__ x1, const float *__restrict__ x2, const float *__restrict__ gout,
     float *__restrict__ gin1, float *__restrict__ gin2, int C, int H, int W, int tiles_x,
-    int tiles_y, int cslice) {
+    int tiles_y, int cslice, int nslice, int dbg) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int CC = K::CC;
     const int tid = threadIdx.x;
@@ -293,13 +375,16 @@ __global__ __launch_bounds__(256, 2) void corr_bwd_d4_kernel(
     const int r = wave * K::RPW + lane / K::TSXP;
     const int sxp = lane % K::TSXP;
 
-    int bid = blockIdx.x;
+    // (tile, channel slice, side) with the side fastest: the two workgroups that read
+    // the same gradOutput tile are adjacent in the swizzled order -> same XCD, same time
+    int bid = xcd_swizzle(blockIdx.x, gridDim.x);
+    const int side = bid & 1; bid >>= 1;         // 0: gradInput1, 1: gradInput2
+    const int slice = bid % nslice; bid /= nslice;
     const int tx = bid % tiles_x; bid /= tiles_x;
     const int ty = bid % tiles_y;
     const int b = bid / tiles_y;
     const int x0 = tx * K::TW, y0 = ty * K::TH;
-    const int side = blockIdx.z;                 // 0: gradInput1, 1: gradInput2
-    const int c_begin = blockIdx.y * cslice;
+    const int c_begin = slice * cslice;
     const int c_end = min(C, c_begin + cslice);
     const int plane = H * W;
 
@@ -311,40 +396,45 @@ __global__ __launch_bounds__(256, 2) void corr_bwd_d4_kernel(
     const bool live = y < H && x < W;
 
     // ---- staging descriptors ----
-    int goff[K::NSLOT], loff[K::NSLOT], gx0[K::NSLOT], chi[K::NSLOT];
+    int goff[K::NSLOT];  // element offset from `src` for channel 0 of a chunk, <0: slot reads zeros
+    int loff[K::NSLOT], gx0[K::NSLOT], chi[K::NSLOT];
 #pragma unroll
     for (int j = 0; j < K::NSLOT; ++j) {
         const int id = tid + j * K::THREADS;
-        goff[j] = 0; loff[j] = -1; gx0[j] = 0; chi[j] = -1;
+        goff[j] = -1; loff[j] = -1; gx0[j] = 0; chi[j] = 0;
         if (id < K::N) {
             const int pl = id / (K::HR * K::HW4);
             const int rem = id % (K::HR * K::HW4);
             const int row = rem / K::HW4, c4 = rem % K::HW4;
             const int gy = y0 - kD + row, gx = x0 - kD + 4 * c4;
             loff[j] = pl * K::PS + row * K::RS + 4 * c4;
-            gx0[j] = gx;
+            gx0[j] = gx; chi[j] = pl;
             const bool in = gy >= 0 && gy < H && (VEC ? (gx >= 0 && gx < W) : (gx > -4 && gx < W));
-            if (in) { chi[j] = pl; goff[j] = pl * plane + gy * W + gx; }
+            // +4 keeps the offset non-negative for gx in (-4, 0) on the scalar path
+            if (in) goff[j] = pl * plane + gy * W + gx + 4;
         }
     }
     float4 stage[K::NSLOT];
     auto prefetch = [&](int c_first) {
 #pragma unroll
         for (int j = 0; j < K::NSLOT; ++j) {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (chi[j] >= 0 && c_first + chi[j] < c_end) {
-                const float *p = src + static_cast<int64_t>(c_first) * plane + goff[j];
-                if (VEC) {
-                    v = ld4(p);
-                } else {
+            const bool on = goff[j] >= 0 && c_first + chi[j] < c_end;
+            if (VEC) {
+                const float *p = on ? src + static_cast<int64_t>(c_first) * plane + (goff[j] - 4)
+                                    : g_zero16;
+                stage[j] = ld4(p);
+            } else {
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (on) {
+                    const float *p = src + static_cast<int64_t>(c_first) * plane + (goff[j] - 4);
                     const int gx = gx0[j];
                     if (gx >= 0 && gx < W) v.x = p[0];
                     if (gx + 1 >= 0 && gx + 1 < W) v.y = p[1];
                     if (gx + 2 >= 0 && gx + 2 < W) v.z = p[2];
                     if (gx + 3 >= 0 && gx + 3 < W) v.w = p[3];
                 }
+                stage[j] = v;
             }
-            stage[j] = v;
         }
     };
     auto commit = [&](float *buf) {
@@ -355,13 +445,19 @@ __global__ __launch_bounds__(256, 2) void corr_bwd_d4_kernel(
 
     prefetch(c_begin);  // in flight while the gradOutput registers are gathered
 
-    // ---- the 81 gradOutput values of this lane's two pixels ----
+    // ---- the 81 gradOutput values of this lane's two pixels, in registers ----
     // side 0: g[d][p] = gO[d][y][x+p]
     // side 1: g[d][p] = gO[80-d][y+dy][x+p+dx]   (d = (dy+4)*9 + dx+4), 0 outside
-    float g[kND * kND][2];
+    // Stored so that every packed FMA pairs two horizontal displacements whose window
+    // operands form an ALIGNED float2 of the LDS row segment w[0..9]:
+    //   pixel 0: pairs dx=(0,1)(2,3)(4,5)(6,7) * w[(0,1)..(6,7)], single dx=8 * w[8]
+    //   pixel 1: single dx=0 * w[1], pairs dx=(1,2)(3,4)(5,6)(7,8) * w[(2,3)..(8,9)]
+    float2v g0p[kND][4], g1p[kND][4];
+    float g0s[kND], g1s[kND];
 #pragma unroll
     for (int d = 0; d < kND * kND; ++d) {
-        const int dy = d / kND - kD, dx = d % kND - kD;
+        const int dyi = d / kND, dxi = d % kND;
+        const int dy = dyi - kD, dx = dxi - kD;
         float v0 = 0.f, v1 = 0.f;
         if (live) {
             if (side == 0) {
@@ -380,43 +476,59 @@ __global__ __launch_bounds__(256, 2) void corr_bwd_d4_kernel(
                 }
             }
         }
-        g[d][0] = v0; g[d][1] = v1;
+        if (dxi == 8) g0s[dyi] = v0; else if (dxi & 1) g0p[dyi][dxi / 2].y = v0; else g0p[dyi][dxi / 2].x = v0;
+        if (dxi == 0) g1s[dyi] = v1; else if (dxi & 1) g1p[dyi][(dxi - 1) / 2].x = v1; else g1p[dyi][(dxi - 1) / 2].y = v1;
     }
 
-    const float nelems = static_cast<float>(C);
+    const float inv_nelems = 1.0f / static_cast<float>(C);
     int it = 0;
     for (int c0 = c_begin; c0 < c_end; c0 += CC, ++it) {
         float *buf = smem + (it & 1) * K::BUF;
         commit(buf);
         __syncthreads();
-        if (c0 + CC < c_end) prefetch(c0 + CC);
+        if (!(dbg & 2)) prefetch(c0 + CC);  // unconditional: zeros past the end of the slice
         const float *wbase = buf + r * K::RS + 2 * sxp;
+        // results are kept in registers and stored after the channel loop: a store
+        // inside a rolled inner loop made hipcc drain vmcnt(0) before the loop, which
+        // serialised the prefetch above against the FMAs (seen in the first version)
+        float res[CC][2] = {};
 #pragma unroll 1
         for (int i = 0; i < CC; ++i) {
-            if (c0 + i >= c_end) break;
+            if (dbg & 4) break;
             const float *wp = wbase + i * K::PS;
-            float a0 = 0.f, a1 = 0.f;
+            // three independent packed accumulator chains per pixel (rows mod 3)
+            float2v a0[3] = {float2v{0.f, 0.f}, float2v{0.f, 0.f}, float2v{0.f, 0.f}};
+            float2v a1[3] = {float2v{0.f, 0.f}, float2v{0.f, 0.f}, float2v{0.f, 0.f}};
+            float s0 = 0.f, s1 = 0.f;
 #pragma unroll
             for (int dyi = 0; dyi < kND; ++dyi) {
-                float w[10];
+                float2v w[5];
 #pragma unroll
-                for (int q = 0; q < 5; ++q) {
-                    const float2 t = ld2(wp + dyi * K::RS + 2 * q);
-                    w[2 * q] = t.x; w[2 * q + 1] = t.y;
-                }
+                for (int q = 0; q < 5; ++q) w[q] = ld2v(wp + dyi * K::RS + 2 * q);
 #pragma unroll
-                for (int dxi = 0; dxi < kND; ++dxi) {
-                    a0 = fmaf(g[dyi * kND + dxi][0], w[dxi], a0);
-                    a1 = fmaf(g[dyi * kND + dxi][1], w[dxi + 1], a1);
+                for (int j = 0; j < 4; ++j) {
+                    a0[dyi % 3] = pkfma(g0p[dyi][j], w[j], a0[dyi % 3]);
+                    a1[dyi % 3] = pkfma(g1p[dyi][j], w[j + 1], a1[dyi % 3]);
                 }
+                s0 = fmaf(g0s[dyi], w[4].x, s0);
+                s1 = fmaf(g1s[dyi], w[0].y, s1);
             }
-            if (live) {
+            const float2v t0 = a0[0] + a0[1] + a0[2], t1 = a1[0] + a1[1] + a1[2];
+            const float r0 = (t0.x + t0.y + s0) * inv_nelems, r1 = (t1.x + t1.y + s1) * inv_nelems;
+            // static register indices only (a runtime-indexed array would go to scratch)
+#pragma unroll
+            for (int q = 0; q < CC; ++q)
+                if (q == i) { res[q][0] = r0; res[q][1] = r1; }
+        }
+#pragma unroll
+        for (int i = 0; i < CC; ++i) {
+            if (live && c0 + i < c_end && !((dbg & 1) && (c0 + i) != c_begin)) {
                 float *dst = dstb + static_cast<int64_t>(c0 + i) * plane + y * W + x;
                 if (VEC) {
-                    *reinterpret_cast<float2 *>(dst) = make_float2(a0 / nelems, a1 / nelems);
+                    *reinterpret_cast<float2 *>(dst) = make_float2(res[i][0], res[i][1]);
                 } else {
-                    dst[0] = a0 / nelems;
-                    if (x + 1 < W) dst[1] = a1 / nelems;
+                    dst[0] = res[i][0];
+                    if (x + 1 < W) dst[1] = res[i][1];
                 }
             }
         }
@@ -448,23 +560,25 @@ int launch_fwd(const char *name, const float *x1, const float *x2, float *out, c
         if ((rc = ensure_lds(corr_fwd_d4_kernel<K, true>, K::LDS_BYTES, &lds_v))) return rc;
         hipLaunchKernelGGL((corr_fwd_d4_kernel<K, true>), dim3(static_cast<unsigned>(blocks)),
                            dim3(K::THREADS), K::LDS_BYTES, s, x1, x2, out, g.C, g.H, g.W, tiles_x,
-                           tiles_y, slope, obs);
+                           tiles_y, slope, obs, option_value("corr_debug_ablate"));
     } else {
         if ((rc = ensure_lds(corr_fwd_d4_kernel<K, false>, K::LDS_BYTES, &lds_s))) return rc;
         hipLaunchKernelGGL((corr_fwd_d4_kernel<K, false>), dim3(static_cast<unsigned>(blocks)),
                            dim3(K::THREADS), K::LDS_BYTES, s, x1, x2, out, g.C, g.H, g.W, tiles_x,
-                           tiles_y, slope, obs);
+                           tiles_y, slope, obs, option_value("corr_debug_ablate"));
     }
     return launch_status();
 }
 
 //                     S  TSX RB CC ROT RS  RS1 PRES
-using FwdA2 = FwdCfg<1, 16, 2, 4, 2, 72, 72, 0>;   // 8x64 tile, fine levels
-using FwdA1 = FwdCfg<1, 16, 1, 4, 2, 72, 72, 0>;   // 4x64 tile
-using FwdB1 = FwdCfg<2, 16, 1, 4, 2, 72, 72, 0>;   // 2x64 tile, 2 channel groups
-using FwdC1 = FwdCfg<4, 16, 1, 4, 0, 72, 64, 0>;   // 1x64 tile, 4 channel groups
-using FwdD1 = FwdCfg<8, 8, 1, 4, 0, 40, 32, 32>;   // 1x32 tile, 8 channel groups
-using FwdE1 = FwdCfg<16, 4, 1, 2, 0, 24, 16, 16>;  // 1x16 tile, 16 channel groups
+using FwdA2 = FwdCfg<1, 16, 2, 4, 2, 72, 72, 0, 3, 1>;   // 8x64 tile, fine levels
+using FwdA1 = FwdCfg<1, 16, 1, 8, 2, 72, 72, 0, 5, 1>;   // 4x64 tile
+using FwdB1 = FwdCfg<2, 16, 1, 4, 2, 72, 72, 0, 3, 2>;   // 2x64 tile, 2 channel groups
+using FwdC1 = FwdCfg<4, 16, 1, 4, 0, 72, 64, 0, 3, 2>;   // 1x64 tile, 4 channel groups
+using FwdD1 = FwdCfg<8, 8, 1, 4, 0, 40, 32, 32, 3, 1>;   // 1x32 tile, 8 channel groups
+using FwdE1 = FwdCfg<16, 4, 1, 2, 0, 24, 16, 16, 3, 2>;  // 1x16 tile, 16 channel groups
+using FwdA1b = FwdCfg<1, 16, 1, 4, 2, 72, 72, 0, 3, 1>;  // 4x64 tile, small chunks, 3 WGs/CU
+using FwdA1c = FwdCfg<1, 16, 1, 4, 2, 72, 72, 0, 3, 2>;  // 4x64 tile, 2 chunks in flight
 
 template <typename K>
 int64_t fwd_tiles(const CorrGeom &g) {
@@ -484,25 +598,27 @@ int launch_bwd(const char *name, const float *x1, const float *x2, const float *
     if (const int forced = option_value("corr_bwd_cslice")) cslice = forced;
     cslice = ((cslice + K::CC - 1) / K::CC) * K::CC;
     const int nslice = (g.C + cslice - 1) / cslice;
-    if (nslice > 65535) return CERB_ETOOLARGE;
+    if (tiles * nslice * 2 > 0x7fffffff) return CERB_ETOOLARGE;
     note_kernel(1, name);
-    const dim3 grid(static_cast<unsigned>(tiles), nslice, 2);
+    const dim3 grid(static_cast<unsigned>(tiles * nslice * 2));
     int rc;
     static bool lds_v = false, lds_s = false;
     if (vec) {
         if ((rc = ensure_lds(corr_bwd_d4_kernel<K, true>, K::LDS_BYTES, &lds_v))) return rc;
         hipLaunchKernelGGL((corr_bwd_d4_kernel<K, true>), grid, dim3(K::THREADS), K::LDS_BYTES, s,
-                           x1, x2, gout, gin1, gin2, g.C, g.H, g.W, tiles_x, tiles_y, cslice);
+                           x1, x2, gout, gin1, gin2, g.C, g.H, g.W, tiles_x, tiles_y, cslice, nslice,
+                           option_value("corr_debug_ablate"));
     } else {
         if ((rc = ensure_lds(corr_bwd_d4_kernel<K, false>, K::LDS_BYTES, &lds_s))) return rc;
         hipLaunchKernelGGL((corr_bwd_d4_kernel<K, false>), grid, dim3(K::THREADS), K::LDS_BYTES, s,
-                           x1, x2, gout, gin1, gin2, g.C, g.H, g.W, tiles_x, tiles_y, cslice);
+                           x1, x2, gout, gin1, gin2, g.C, g.H, g.W, tiles_x, tiles_y, cslice, nslice,
+                           option_value("corr_debug_ablate"));
     }
     return launch_status();
 }
 
 using BwdWide = BwdCfg<32, 2, 72>;    // 8x64 tile
-using BwdNarrow = BwdCfg<16, 4, 96>;  // 16x32 tile
+using BwdNarrow = BwdCfg<16, 2, 96>;  // 16x32 tile
 
 bool fast_config(const CorrGeom &g, int dtype) {
     return dtype == CERB_F32 && g.pad == kD && g.maxd == kD && g.ksize == 1 && g.s1 == 1 &&
@@ -529,6 +645,8 @@ int corr_d4_forward(const void *in1, const void *in2, void *out, const CorrGeom 
         case 4: if (g.C % 4 == 0) return launch_fwd<FwdC1>("corr_fwd_d4_1x64_s4", x1, x2, o, g, slope, obs, vec, s); break;
         case 5: if (g.C % 8 == 0) return launch_fwd<FwdD1>("corr_fwd_d4_1x32_s8", x1, x2, o, g, slope, obs, vec, s); break;
         case 6: if (g.C % 16 == 0) return launch_fwd<FwdE1>("corr_fwd_d4_1x16_s16", x1, x2, o, g, slope, obs, vec, s); break;
+        case 7: return launch_fwd<FwdA1b>("corr_fwd_d4_4x64_cc4", x1, x2, o, g, slope, obs, vec, s);
+        case 8: return launch_fwd<FwdA1c>("corr_fwd_d4_4x64_cc4x2", x1, x2, o, g, slope, obs, vec, s);
         default: break;
     }
     const int64_t want = 384;

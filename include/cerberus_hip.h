@@ -129,7 +129,7 @@ int cerberus_flow_warp_backward(const void *image, const void *flow,
 
 /* Diagnostics / tuning knobs (process-wide, read at launch time, default 0):
  *   "corr_force_generic" : 1 = always use the generic kernels (testing)
- *   "corr_fwd_variant"   : 0 = auto, 1..6 = force one tuned forward variant
+ *   "corr_fwd_variant"   : 0 = auto, 1..8 = force one tuned forward variant
  *   "corr_bwd_cslice"    : 0 = auto, else channels per backward workgroup
  * Returns CERB_EINVAL for an unknown key. */
 int cerberus_set_option(const char *key, int value);

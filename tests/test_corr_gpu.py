@@ -136,7 +136,7 @@ def test_config1_forward_against_reference_checksums(golden):
 @pytest.mark.parametrize("lvl", [0, 1, 2, 3])
 def test_fullsize_batch4_properties(lvl):
     """B=4 (config 4 per-GPU batch): size-independent properties.
-    (1) batch items are independent: item n of the B=4 call is bit-identical to
+    (1) batch items are independent: item n of the B=4 call is equal (to fp32 rounding) to
         the B=1 call on item n; (2) bilinearity: corr(a*x1, x2) == a*corr(x1, x2)
         exactly for a power of two; (3) adjoint identity ties backward to forward:
         <corr(x1,x2), gO> == <x1, g1> == <x2, g2>."""
@@ -149,10 +149,14 @@ def test_fullsize_batch4_properties(lvl):
     out = torch.ops.cerberus.correlation(x1, x2, *p)
     g1, g2 = torch.ops.cerberus.correlation_backward(x1, x2, go, *p)
     for n in (0, 3):
-        assert torch.equal(torch.ops.cerberus.correlation(x1[n:n + 1], x2[n:n + 1], *p)[0], out[n])
+        # the B=1 call may dispatch to a different tile / channel-split variant
+        # (different summation order), so compare to rounding, not bit-for-bit
+        o1 = torch.ops.cerberus.correlation(x1[n:n + 1], x2[n:n + 1], *p)[0]
+        assert rel_err(o1.cpu().numpy(), out[n].cpu().numpy()) < 1e-6
         h1, h2 = torch.ops.cerberus.correlation_backward(x1[n:n + 1], x2[n:n + 1],
                                                          go[n:n + 1], *p)
-        assert torch.equal(h1[0], g1[n]) and torch.equal(h2[0], g2[n])
+        assert rel_err(h1[0].cpu().numpy(), g1[n].cpu().numpy()) < 1e-6
+        assert rel_err(h2[0].cpu().numpy(), g2[n].cpu().numpy()) < 1e-6
     assert torch.equal(torch.ops.cerberus.correlation(x1 * 4.0, x2, *p), out * 4.0)
     lhs = (out.double() * go.double()).sum().item()
     # fp32 results summed over ~1e7 terms: scale the tolerance by the sum of magnitudes
@@ -285,7 +289,7 @@ def test_native_library_is_loaded():
     assert "libcerberus_hip.so" in maps
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 8])
 @pytest.mark.parametrize("shape", [(2, 32, 13, 72), (1, 16, 9, 64), (1, 48, 20, 33),
                                    (2, 64, 5, 16), (1, 16, 3, 130)])
 def test_every_tuned_forward_variant(variant, shape):
