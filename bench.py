@@ -53,7 +53,23 @@ def warp_bytes(C, B, H, W, e=4):
 class Workload:
     """Device-resident tensors of one step + the op sequence."""
 
-    def __init__(self, pairs, width, height, device):
+    @staticmethod
+    def _flow(pairs, H, W, seed, kind, device):
+        """Synthetic flow field in pixels.  'smooth' mimics what PWCNetHead feeds the warp:
+        a coarse field upsampled bilinearly (pwcnet_sfd.py:176) -- here a random (H/8, W/8)
+        field in [-6, 6) px, x8 bilinear, plus +-0.25 px of per-pixel residual.  'noise' is
+        the adversarial case used by the parity tests: independent uniform [-6, 6) per pixel."""
+        from cerberusnet_amd.synth import hash_uniform
+        if kind == "noise":
+            return torch.from_numpy(hash_uniform((pairs, 2, H, W), seed, -6.0, 6.0)).to(device)
+        coarse = torch.from_numpy(hash_uniform((pairs, 2, max(2, H // 8), max(2, W // 8)), seed,
+                                               -6.0, 6.0))
+        up = torch.nn.functional.interpolate(coarse, size=(H, W), mode="bilinear",
+                                             align_corners=True)
+        up = up + torch.from_numpy(hash_uniform((pairs, 2, H, W), seed + 100, -0.25, 0.25))
+        return up.contiguous().to(device)
+
+    def __init__(self, pairs, width, height, device, flow_kind="smooth"):
         from cerberusnet_amd.synth import hash_uniform, pyramid_shapes
         import cerberusnet_amd  # noqa: F401  registers torch.ops.cerberus.*
         self.levels = pyramid_shapes(width, height, 32)
@@ -68,7 +84,7 @@ class Workload:
                 lv.append(dict(
                     f1=t((pairs, C, H, W), 0), f2=t((pairs, C, H, W), 1),
                     gout=t((pairs, 81, H, W), 2),
-                    flow=t((pairs, 2, H, W), 3, -6.0, 6.0) if l > 0 else None))
+                    flow=self._flow(pairs, H, W, seed + 3, flow_kind, device) if l > 0 else None))
             self.dirs.append(lv)
 
     def kernels(self):
@@ -149,12 +165,53 @@ class EventProbe:
                 for k, v in self.records.items()}  # seconds per launch
 
 
+def per_kernel_times(wl, reps):
+    """Seconds per launch for every distinct kernel of the step (direction 0 tensors)."""
+    ops = torch.ops.cerberus
+    lv = wl.dirs[0]
+    calls = {}
+    for l, t in enumerate(lv):
+        if "warped" not in t:
+            wl.step()
+        calls["corr_fwd_L%d" % l] = (lambda t=t: ops.correlation(t["f1"], t["warped"], *CORR_P))
+        calls["corr_bwd_L%d" % l] = (lambda t=t: ops.correlation_backward(
+            t["f1"], t["warped"], t["gout"], *CORR_P))
+        if l > 0:
+            calls["warp_fwd_L%d" % l] = (lambda t=t: ops.flow_warp(t["f2"], t["flow"], 1, 0))
+            calls["warp_bwd_L%d" % l] = (lambda t=t: ops.flow_warp_backward(
+                t["f2"], t["flow"], t["f1"], 1, 0, True, True))
+    out = {}
+    for label, fn in calls.items():
+        fn()
+        torch.cuda.synchronize()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            fn()
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            keep = [fn() for _ in range(reps)]
+        graph.replay()
+        torch.cuda.synchronize()
+        samples = []
+        for _ in range(5):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            graph.replay()
+            b.record()
+            torch.cuda.synchronize()
+            samples.append(a.elapsed_time(b) * 1e-3 / reps)
+        out[label] = float(np.median(samples))
+        del keep, graph
+    return out
+
+
 def cpu_baseline(levels, budget_s=12.0):
     """Reference CPU path: CorrelationTorch semantics (oracle port) forward +
     autograd backward on the B=1 pyramid, both directions = one image pair."""
     from oracle import correlation_torch_ref
     from cerberusnet_amd.synth import hash_uniform
-    threads = torch.get_num_threads()
     data = []
     for l, (C, H, W) in enumerate(levels):
         data.append((torch.from_numpy(hash_uniform((1, C, H, W), 4 * l)).requires_grad_(True),
@@ -167,19 +224,33 @@ def cpu_baseline(levels, budget_s=12.0):
                 out = correlation_torch_ref(x1, x2, 4)
                 torch.autograd.grad(out, (x1, x2), go)
 
-    one_pair()  # warm-up
+    # torch's default (one thread per host core) is far from optimal on small maps: probe a
+    # few thread counts briefly and time the sample with the best one (stated in the report)
+    default_threads = torch.get_num_threads()
+    probe = {}
+    for th in sorted({default_threads, 32, 16, 8}):
+        if th > (os.cpu_count() or 1):
+            continue
+        torch.set_num_threads(th)
+        one_pair()
+        t0 = time.perf_counter()
+        one_pair()
+        probe[th] = time.perf_counter() - t0
+    threads = min(probe, key=probe.get)
+    torch.set_num_threads(threads)
     n, t0 = 0, time.perf_counter()
     while True:
         one_pair()
         n += 1
         dt = time.perf_counter() - t0
-        if dt > budget_s or n >= 50:
+        if dt > budget_s or n >= 200:
             break
+    torch.set_num_threads(default_threads)
     return {"value": round(n / dt, 4), "unit": "image-pairs/s", "cores": threads,
             "kind": "port",
             "sample": "%d image pairs (B=1, 4 levels x 2 directions, correlation fwd+bwd only, "
-                      "torch CPU, %d threads of %d host cores) in %.1f s"
-                      % (n, threads, os.cpu_count(), dt)}
+                      "torch CPU, best of %s threads = %d, %d host cores) in %.1f s"
+                      % (n, sorted(probe), threads, os.cpu_count(), dt)}
 
 
 def main():
@@ -193,6 +264,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--probe-steps", type=int, default=20)
+    ap.add_argument("--flow", choices=["smooth", "noise"], default="smooth",
+                    help="synthetic flow fields fed to the warp (see Workload._flow)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -211,7 +284,7 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=device)  # RCCL
 
-    wl = Workload(args.pairs, args.width, args.height, device)
+    wl = Workload(args.pairs, args.width, args.height, device, args.flow)
 
     # ---- warm-up (eager), then capture the step into a hipGraph ----
     for _ in range(max(1, args.warmup if args.no_graph else 3)):
@@ -264,6 +337,7 @@ def main():
                             "d=4 + flow-warp, fp32), %d image pairs per GPU per step (config 4's "
                             "per-GPU batch), both flow directions, fwd+bwd" % args.pairs,
                 "pairs_per_gpu": args.pairs, "levels_CHW": [list(s) for s in wl.levels],
+                "flow_field": args.flow,
                 "launch": "hipGraph replay" if graph is not None else "eager",
                 "sharding": "image pairs sharded over ranks, no data-path collective",
                 "algorithmic_bytes_per_step": step_bytes,
@@ -273,19 +347,23 @@ def main():
             },
         }
 
-    # ---- per-kernel pass: HIP events around every launch (rank 0 only) ----
+    # ---- per-kernel pass (rank 0 only): every launch of the step timed on its own ----
+    # R back-to-back launches of ONE kernel are captured into a hipGraph (no host launch
+    # gaps between them) and the replay is bracketed by HIP events on the launch stream.
     if rank == 0:
-        probe = EventProbe()
-        for _ in range(max(1, args.probe_steps)):
-            wl.step(probe)
-        per = probe.summary()
+        per = per_kernel_times(wl, max(2, args.probe_steps))
         kern = dict(wl.kernels())
         dominant = max(per, key=lambda k: per[k])
         ach = kern[dominant] / per[dominant] / 1e9
+        corr_t = sum(v for k, v in per.items() if k.startswith("corr"))
+        corr_b = sum(v for k, v in kern.items() if k.startswith("corr"))
         result["roofline"] = {
             "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": None, "kernel": dominant,
             "avg_us": round(per[dominant] * 1e6, 2), "algorithmic_bytes": kern[dominant],
+            "corr_all_levels": {"GBps": round(corr_b / corr_t / 1e9, 1),
+                                "frac": round(corr_b / corr_t / 1e9 / HBM_PEAK_GBPS, 4),
+                                "us_per_direction": round(corr_t * 1e6, 2)},
             "per_kernel": {k: {"us": round(per[k] * 1e6, 2),
                                "GBps": round(kern[k] / per[k] / 1e9, 1)} for k in sorted(per)},
         }

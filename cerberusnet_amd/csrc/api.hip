@@ -145,16 +145,20 @@ int cerberus_flow_warp_forward(const void *image, const void *flow, void *out, i
                         static_cast<hipStream_t>(stream));
 }
 
+int64_t cerberus_flow_warp_backward_workspace_bytes(void) { return 4 * sizeof(int); }
+
 int cerberus_flow_warp_backward(const void *image, const void *flow, const void *grad_out,
-                                void *grad_image, void *grad_flow, int B, int C, int H, int W,
+                                void *grad_image, void *grad_flow, void *workspace,
+                                int64_t workspace_bytes, int B, int C, int H, int W,
                                 int pad_mode, int interp_mode, int dtype, void *stream) {
     const int rc = warp_args_ok(B, C, H, W, pad_mode, interp_mode, dtype);
     if (rc) return rc;
     if (B == 0) return CERB_OK;
     if (!image || !flow || !grad_out) return CERB_EINVAL;
     if (!grad_image && !grad_flow) return CERB_OK;
-    return warp_backward(image, flow, grad_out, grad_image, grad_flow, B, C, H, W, pad_mode,
-                         interp_mode, dtype, static_cast<hipStream_t>(stream));
+    return warp_backward(image, flow, grad_out, grad_image, grad_flow, workspace, workspace_bytes,
+                         B, C, H, W, pad_mode, interp_mode, dtype,
+                         static_cast<hipStream_t>(stream));
 }
 
 int cerberus_set_option(const char *key, int value) {

@@ -84,8 +84,8 @@ int corr_d4_backward(const void *in1, const void *in2, const void *gout, void *g
 int warp_forward(const void *image, const void *flow, void *out, int B, int C, int H, int W,
                  int pad_mode, int interp, int dtype, hipStream_t s);
 int warp_backward(const void *image, const void *flow, const void *gout, void *gimage,
-                  void *gflow, int B, int C, int H, int W, int pad_mode, int interp, int dtype,
-                  hipStream_t s);
+                  void *gflow, void *workspace, int64_t workspace_bytes, int B, int C, int H,
+                  int W, int pad_mode, int interp, int dtype, hipStream_t s);
 
 static inline int launch_status() {
     hipError_t e = hipGetLastError();

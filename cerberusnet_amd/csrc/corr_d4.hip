@@ -114,12 +114,16 @@ template <typename K, bool VEC>
 __global__ __launch_bounds__(K::THREADS, K::WPS) void corr_fwd_d4_kernel(
     const float *__restrict__ x1, const float *__restrict__ x2, float *__restrict__ out, int C,
     int H, int W, int tiles_x, int tiles_y, float slope, int64_t out_bstride, int dbg) {
-    // dbg: timing-ablation mask (results are WRONG when non-zero; "corr_debug_ablate" option,
-    // never set by the product path): 1 = store only displacement 0, 2 = load only the first
-    // chunk, 4 = skip the FMAs
+    // Timing-ablation builds only (-DCERB_ABLATE; results are WRONG when the mask is set):
+    // 1 = store only displacement 0, 2 = load only the first chunk, 4 = skip the FMAs,
+    // 8 = no LDS commit, 16 = no barrier, 32 = no epilogue, 64 = return at once.
+    // The product build compiles the mask to the constant 0.
+#ifndef CERB_ABLATE
+    dbg = 0;
+#endif
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int S = K::S, TSX = K::TSX, RB = K::RB, CC = K::CC, NSET = K::NSET;
-    if (dbg & 64) return;  // ablation: launch + dispatch only
+    if (dbg & 64) return;
 
     const int tid = threadIdx.x;
     const int wave = tid >> 6;  // vertical displacement index dy + 4
@@ -368,6 +372,9 @@ __global__ __launch_bounds__(256, 2) void corr_bwd_d4_kernel(
     const float *__restrict__ x1, const float *__restrict__ x2, const float *__restrict__ gout,
     float *__restrict__ gin1, float *__restrict__ gin2, int C, int H, int W, int tiles_x,
     int tiles_y, int cslice, int nslice, int dbg) {
+#ifndef CERB_ABLATE
+    dbg = 0;
+#endif
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int CC = K::CC;
     const int tid = threadIdx.x;
@@ -649,18 +656,18 @@ int corr_d4_forward(const void *in1, const void *in2, void *out, const CorrGeom 
         case 8: return launch_fwd<FwdA1c>("corr_fwd_d4_4x64_cc4x2", x1, x2, o, g, slope, obs, vec, s);
         default: break;
     }
-    const int64_t want = 384;
-    if (fwd_tiles<FwdA2>(g) >= 2 * want) return launch_fwd<FwdA2>("corr_fwd_d4_8x64", x1, x2, o, g, slope, obs, vec, s);
-    if (fwd_tiles<FwdA1>(g) >= want || g.C < 16)
-        return launch_fwd<FwdA1>("corr_fwd_d4_4x64", x1, x2, o, g, slope, obs, vec, s);
-    if (g.C % 2 == 0 && (fwd_tiles<FwdB1>(g) >= want || g.C % 4 != 0 || g.C < 32))
+    // Smallest channel split that still yields >= 256 workgroups (one per CU); the tile
+    // sweep on MI355X (tools/tune_corr.py, profiles/) picked exactly this order.
+    const int64_t want = 256;
+    if (fwd_tiles<FwdA1b>(g) >= want || g.C % 2 != 0)
+        return launch_fwd<FwdA1b>("corr_fwd_d4_4x64_cc4", x1, x2, o, g, slope, obs, vec, s);
+    if (fwd_tiles<FwdB1>(g) >= want || g.C % 4 != 0)
         return launch_fwd<FwdB1>("corr_fwd_d4_2x64_s2", x1, x2, o, g, slope, obs, vec, s);
-    if (g.C % 4 == 0 && (fwd_tiles<FwdC1>(g) >= want || g.C % 8 != 0 || g.C < 64))
+    if (fwd_tiles<FwdC1>(g) >= want || g.C % 8 != 0)
         return launch_fwd<FwdC1>("corr_fwd_d4_1x64_s4", x1, x2, o, g, slope, obs, vec, s);
-    if (g.C % 8 == 0 && (fwd_tiles<FwdD1>(g) >= want || g.C % 16 != 0 || g.C < 128))
+    if (fwd_tiles<FwdD1>(g) >= want || g.C % 16 != 0)
         return launch_fwd<FwdD1>("corr_fwd_d4_1x32_s8", x1, x2, o, g, slope, obs, vec, s);
-    if (g.C % 16 == 0) return launch_fwd<FwdE1>("corr_fwd_d4_1x16_s16", x1, x2, o, g, slope, obs, vec, s);
-    return launch_fwd<FwdA1>("corr_fwd_d4_4x64", x1, x2, o, g, slope, obs, vec, s);
+    return launch_fwd<FwdE1>("corr_fwd_d4_1x16_s16", x1, x2, o, g, slope, obs, vec, s);
 }
 
 int corr_d4_backward(const void *in1, const void *in2, const void *gout, void *gin1, void *gin2,

@@ -27,6 +27,7 @@ namespace {
 
 constexpr int kCg = 4;           // channel groups (waves) per workgroup
 constexpr int kPix = 64;         // pixels per workgroup = one wavefront
+constexpr int kMaxExtent = 16;   // largest tap distance the tiled grad_image kernel scans for
 
 template <typename A> struct Coord {
     A pos;   // source index after unnormalise + padding
@@ -98,14 +99,29 @@ __global__ __launch_bounds__(kPix * kCg) void warp_fwd_kernel(
     const bool okx0 = x0 >= 0 && x0 < W, okx1 = x0 + 1 >= 0 && x0 + 1 < W;
     const bool oky0 = y0 >= 0 && y0 < H, oky1 = y0 + 1 >= 0 && y0 + 1 < H;
     const int64_t o00 = static_cast<int64_t>(y0) * W + x0;
-    for (int c = cg; c < C; c += kCg) {
-        const T *q = img + c * plane + o00;
-        A acc = 0;
-        if (oky0 && okx0) acc += ld(q) * wnw;
-        if (oky0 && okx1) acc += ld(q + 1) * wne;
-        if (oky1 && okx0) acc += ld(q + W) * wsw;
-        if (oky1 && okx1) acc += ld(q + W + 1) * wse;
-        st(dst + c * plane, acc);
+    constexpr int kU = 4;  // channels per trip: 16 independent taps in flight per lane
+    for (int c = cg; c < C; c += kU * kCg) {
+        A v[kU][4];
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            const int cc = min(c + u * kCg, C - 1);
+            const T *q = img + cc * plane + o00;
+            v[u][0] = (oky0 && okx0) ? ld(q) : A(0);
+            v[u][1] = (oky0 && okx1) ? ld(q + 1) : A(0);
+            v[u][2] = (oky1 && okx0) ? ld(q + W) : A(0);
+            v[u][3] = (oky1 && okx1) ? ld(q + W + 1) : A(0);
+        }
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            const int cc = c + u * kCg;
+            if (cc >= C) break;
+            A acc = 0;
+            if (oky0 && okx0) acc += v[u][0] * wnw;
+            if (oky0 && okx1) acc += v[u][1] * wne;
+            if (oky1 && okx0) acc += v[u][2] * wsw;
+            if (oky1 && okx1) acc += v[u][3] * wse;
+            st(dst + cc * plane, acc);
+        }
     }
 }
 
@@ -136,12 +152,38 @@ template <typename H16> __device__ __forceinline__ void atomic_accumulate_16(H16
 __device__ __forceinline__ void atomic_accumulate(__half *p, float v) { atomic_accumulate_16(p, v); }
 __device__ __forceinline__ void atomic_accumulate(hip_bfloat16 *p, float v) { atomic_accumulate_16(p, v); }
 
+// ---- tap extent -------------------------------------------------------------
+// The owner-computes image-gradient kernel below needs to know how far a sample can
+// land from its own pixel.  Every backward call measures it on the device (max over
+// all pixels that have at least one in-image tap of the tap distance, per axis) into
+// a 2-int workspace; no host round trip, so the sequence stays graph-capturable.
+// Wave-level max of three non-negative ints (tap extent x/y, |gradOutput| bits).
+__device__ __forceinline__ void wave_max3(int &a, int &b, int &c) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        a = max(a, __shfl_xor(a, m, 64));
+        b = max(b, __shfl_xor(b, m, 64));
+        c = max(c, __shfl_xor(c, m, 64));
+    }
+}
+// One thread per workgroup publishes; the plain read first keeps thousands of
+// workgroups from serialising on the same three words (a stale read only costs a
+// redundant atomic, never a lost maximum).
+__device__ __forceinline__ void publish_max(int *ws, int v) {
+    if (v > *reinterpret_cast<volatile int *>(ws)) atomicMax(ws, v);
+}
+
 template <typename T>
 __global__ __launch_bounds__(kPix * kCg) void warp_bwd_kernel(
     const T *__restrict__ image, const T *__restrict__ flow, const T *__restrict__ gout,
-    T *__restrict__ gimage, T *__restrict__ gflow, int C, int H, int W, int pad_mode) {
+    T *__restrict__ gimage, T *__restrict__ gflow, int *__restrict__ extent_ws,
+    const int *__restrict__ gate_ws, int C, int H, int W, int pad_mode) {
     using A = typename Acc<T>::type;
+    // gate: when the tiled kernel handled grad_image (extent within its window) this
+    // launch is only the scatter fallback and has nothing to do
+    if (gate_ws && gate_ws[0] <= kMaxExtent && gate_ws[1] <= kMaxExtent) return;  // tiles did it
     __shared__ A part[kCg][2][kPix];
+    __shared__ int wmax[kCg][3];
     const int64_t plane = static_cast<int64_t>(H) * W;
     const int lane = threadIdx.x & (kPix - 1);
     const int cg = threadIdx.x / kPix;
@@ -150,6 +192,8 @@ __global__ __launch_bounds__(kPix * kCg) void warp_bwd_kernel(
     const bool live = p < plane;
     A gix = 0, giy = 0;
     Coord<A> cx{0, 0}, cy{0, 0};
+    int ex = 0, ey = 0;
+    float gmax = 0.f;
     if (live) {
         const int y = static_cast<int>(p / W), x = static_cast<int>(p % W);
         const T *fl = flow + static_cast<int64_t>(b) * 2 * plane + p;
@@ -166,31 +210,64 @@ __global__ __launch_bounds__(kPix * kCg) void warp_bwd_kernel(
         const bool oky0 = y0 >= 0 && y0 < H, oky1 = y0 + 1 >= 0 && y0 + 1 < H;
         const int64_t o00 = static_cast<int64_t>(y0) * W + x0;
         const int64_t base = static_cast<int64_t>(b) * C * plane;
-        for (int c = cg; c < C; c += kCg) {
-            const A g = ld(gout + base + c * plane + p);
-            const int64_t q = base + c * plane + o00;
-            if (gimage) {
-                if (oky0 && okx0) atomic_accumulate(gimage + q, wnw * g);
-                if (oky0 && okx1) atomic_accumulate(gimage + q + 1, wne * g);
-                if (oky1 && okx0) atomic_accumulate(gimage + q + W, wsw * g);
-                if (oky1 && okx1) atomic_accumulate(gimage + q + W + 1, wse * g);
+        if ((okx0 || okx1) && (oky0 || oky1)) {
+            ex = max(abs(x0 - x), abs(x0 + 1 - x));
+            ey = max(abs(y0 - y), abs(y0 + 1 - y));
+        }
+        // kU channels per trip: all loads of a trip are issued before any is consumed
+        constexpr int kU = 4;
+        for (int c = cg; c < C; c += kU * kCg) {
+            A g[kU], vnw[kU], vne[kU], vsw[kU], vse[kU];
+#pragma unroll
+            for (int u = 0; u < kU; ++u) {
+                const int cc = c + u * kCg;
+                const bool on = cc < C;
+                const int64_t q = base + (on ? cc : c) * plane + o00;
+                g[u] = on ? ld(gout + base + cc * plane + p) : A(0);
+                gmax = fmaxf(gmax, fabsf(static_cast<float>(g[u])));
+                vnw[u] = vne[u] = vsw[u] = vse[u] = A(0);
+                if (gflow) {
+                    if (oky0 && okx0) vnw[u] = ld(image + q);
+                    if (oky0 && okx1) vne[u] = ld(image + q + 1);
+                    if (oky1 && okx0) vsw[u] = ld(image + q + W);
+                    if (oky1 && okx1) vse[u] = ld(image + q + W + 1);
+                }
             }
-            if (gflow) {
-                const A vnw = (oky0 && okx0) ? ld(image + q) : A(0);
-                const A vne = (oky0 && okx1) ? ld(image + q + 1) : A(0);
-                const A vsw = (oky1 && okx0) ? ld(image + q + W) : A(0);
-                const A vse = (oky1 && okx1) ? ld(image + q + W + 1) : A(0);
-                gix += (-vnw * (y1f - cy.pos) + vne * (y1f - cy.pos) - vsw * (cy.pos - y0f) +
-                        vse * (cy.pos - y0f)) * g;
-                giy += (-vnw * (x1f - cx.pos) - vne * (cx.pos - x0f) + vsw * (x1f - cx.pos) +
-                        vse * (cx.pos - x0f)) * g;
+#pragma unroll
+            for (int u = 0; u < kU; ++u) {
+                const int cc = c + u * kCg;
+                if (cc >= C) break;
+                if (gimage) {
+                    const int64_t q = base + cc * plane + o00;
+                    if (oky0 && okx0) atomic_accumulate(gimage + q, wnw * g[u]);
+                    if (oky0 && okx1) atomic_accumulate(gimage + q + 1, wne * g[u]);
+                    if (oky1 && okx0) atomic_accumulate(gimage + q + W, wsw * g[u]);
+                    if (oky1 && okx1) atomic_accumulate(gimage + q + W + 1, wse * g[u]);
+                }
+                if (gflow) {
+                    gix += (-vnw[u] * (y1f - cy.pos) + vne[u] * (y1f - cy.pos) -
+                            vsw[u] * (cy.pos - y0f) + vse[u] * (cy.pos - y0f)) * g[u];
+                    giy += (-vnw[u] * (x1f - cx.pos) - vne[u] * (cx.pos - x0f) +
+                            vsw[u] * (x1f - cx.pos) + vse[u] * (cx.pos - x0f)) * g[u];
+                }
             }
         }
     }
-    if (!gflow) return;
+    if (extent_ws) {  // whole waves participate
+        int gb = __float_as_int(gmax);
+        wave_max3(ex, ey, gb);
+        if (lane == 0) { wmax[cg][0] = ex; wmax[cg][1] = ey; wmax[cg][2] = gb; }
+    }
     part[cg][0][lane] = gix;
     part[cg][1][lane] = giy;
     __syncthreads();
+    if (extent_ws && threadIdx.x < 3) {
+        int v = 0;
+#pragma unroll
+        for (int k = 0; k < kCg; ++k) v = max(v, wmax[k][threadIdx.x]);
+        publish_max(extent_ws + threadIdx.x, v);
+    }
+    if (!gflow) return;
     if (cg == 0 && live) {
         A sx = 0, sy = 0;
 #pragma unroll
@@ -199,6 +276,105 @@ __global__ __launch_bounds__(kPix * kCg) void warp_bwd_kernel(
         T *gf = gflow + static_cast<int64_t>(b) * 2 * plane + p;
         st(gf, cx.mult * sx / static_cast<A>(W - 1) * A(2.0));
         st(gf + plane, cy.mult * sy / static_cast<A>(H - 1) * A(2.0));
+    }
+}
+
+// ---- grad_image, owner-computes ---------------------------------------------
+// ATen's (and our fallback's) image gradient is a global float-atomic scatter: 4
+// atomics per (pixel, channel), ~0.1 TB/s when neighbouring lanes hit different rows
+// (measured: 555 us at the 32x128x256 level).  Here a workgroup OWNS a TH x TW tile of
+// grad_image for CW channels: it scans every source pixel whose taps can reach the tile
+// (tile grown by the measured tap extent), accumulates the taps that fall inside in LDS
+// and writes the tile once with plain coalesced stores.  No global atomics, no memset,
+// every output element written exactly once.
+// The LDS accumulators are 64-bit FIXED POINT: ds_add_f32 runs at 0.3 lanes/clk/CU on
+// gfx950 (tools/ubench/lds_atomic.hip) against 6.7 for ds_add_u64.  The scale is
+// 2^(40 - exponent(max|gradOutput|)), measured on the device by the grad_flow pass:
+// every product w*g <= max|g| keeps >= 40 fractional bits below the largest value and
+// 2^22 of them can meet in one pixel without overflow.  Integer addition commutes, so
+// the result is bit-reproducible (ATen's and our scatter fallback's are not).
+template <int TH, int TW, int CW>
+__global__ __launch_bounds__(256) void warp_gimage_tile_kernel(
+    const float *__restrict__ flow, const float *__restrict__ gout, float *__restrict__ gimage,
+    const int *__restrict__ ws, int C, int H, int W, int pad_mode, int tiles_x, int tiles_y,
+    int nchunk) {
+    __shared__ long long acc[CW * TH * TW + 64];  // + one dummy word per lane
+    const int tid = threadIdx.x;
+    int bid = blockIdx.x;
+    const int chunk = bid % nchunk; bid /= nchunk;
+    const int tx = bid % tiles_x; bid /= tiles_x;
+    const int ty = bid % tiles_y;
+    const int b = bid / tiles_y;
+    const int tx0 = tx * TW, ty0 = ty * TH, c0 = chunk * CW;
+    const int cw = min(CW, C - c0);
+    const int64_t plane = static_cast<int64_t>(H) * W;
+    const int rx = ws[0], ry = ws[1];
+    const bool fallback = rx > kMaxExtent || ry > kMaxExtent;  // scatter kernel takes over
+    const float gabs = __int_as_float(ws[2]);
+    int gexp = 0;
+    frexpf(gabs, &gexp);                         // gabs < 2^gexp
+    const float scale = ldexpf(1.0f, 40 - gexp);  // products land below 2^40
+    const float unscale = ldexpf(1.0f, gexp - 40);
+
+    for (int i = tid; i < CW * TH * TW; i += 256) acc[i] = 0;
+    __syncthreads();
+
+    if (!fallback) {
+        const int ys = max(0, ty0 - ry), ye = min(H, ty0 + TH + ry);
+        const int xs = max(0, tx0 - rx), xe = min(W, tx0 + TW + rx);
+        const int rw = xe - xs, n = (ye - ys) * rw;
+        const float *fl = flow + static_cast<int64_t>(b) * 2 * plane;
+        const float *go = gout + (static_cast<int64_t>(b) * C + c0) * plane;
+        for (int idx = tid; idx < n; idx += 256) {
+            const int sy = ys + idx / rw, sx = xs + idx % rw;
+            const int64_t p = static_cast<int64_t>(sy) * W + sx;
+            const Coord<float> cx = source_coord<float>(sx, fl[p], W, pad_mode);
+            const Coord<float> cy = source_coord<float>(sy, fl[plane + p], H, pad_mode);
+            const float x0f = floorf(cx.pos), y0f = floorf(cy.pos);
+            const float x1f = x0f + 1.f, y1f = y0f + 1.f;
+            const int x0 = static_cast<int>(x0f), y0 = static_cast<int>(y0f);
+            // tap (j,i) -> tile-local coordinates; keep only taps inside BOTH image and tile
+            const int lx0 = x0 - tx0, ly0 = y0 - ty0;
+            const bool ox0 = x0 >= 0 && x0 < W && lx0 >= 0 && lx0 < TW;
+            const bool ox1 = x0 + 1 >= 0 && x0 + 1 < W && lx0 + 1 >= 0 && lx0 + 1 < TW;
+            const bool oy0 = y0 >= 0 && y0 < H && ly0 >= 0 && ly0 < TH;
+            const bool oy1 = y0 + 1 >= 0 && y0 + 1 < H && ly0 + 1 >= 0 && ly0 + 1 < TH;
+            if (!((ox0 || ox1) && (oy0 || oy1))) continue;
+            const float wnw = (x1f - cx.pos) * (y1f - cy.pos);
+            const float wne = (cx.pos - x0f) * (y1f - cy.pos);
+            const float wsw = (x1f - cx.pos) * (cy.pos - y0f);
+            const float wse = (cx.pos - x0f) * (cy.pos - y0f);
+            // all CW gradOutput values first (independent loads in flight together), then
+            // branch-free LDS atomics: a tap outside the tile adds 0 to a per-lane dummy word
+            float g[CW];
+#pragma unroll
+            for (int c = 0; c < CW; ++c) g[c] = go[min(c, cw - 1) * plane + p];
+            const int o = ly0 * TW + lx0;
+            unsigned long long *dummy =
+                reinterpret_cast<unsigned long long *>(acc) + CW * TH * TW + (tid & 63);
+            const bool v00 = oy0 && ox0, v01 = oy0 && ox1, v10 = oy1 && ox0, v11 = oy1 && ox1;
+            const float w00 = v00 ? wnw * scale : 0.f, w01 = v01 ? wne * scale : 0.f;
+            const float w10 = v10 ? wsw * scale : 0.f, w11 = v11 ? wse * scale : 0.f;
+#pragma unroll
+            for (int c = 0; c < CW; ++c) {
+                if (c >= cw) break;
+                unsigned long long *a =
+                    reinterpret_cast<unsigned long long *>(acc) + c * (TH * TW) + o;
+                // two's-complement add: negative contributions wrap correctly
+                atomicAdd(v00 ? a : dummy, static_cast<unsigned long long>(__float2ll_rn(w00 * g[c])));
+                atomicAdd(v01 ? a + 1 : dummy, static_cast<unsigned long long>(__float2ll_rn(w01 * g[c])));
+                atomicAdd(v10 ? a + TW : dummy, static_cast<unsigned long long>(__float2ll_rn(w10 * g[c])));
+                atomicAdd(v11 ? a + TW + 1 : dummy, static_cast<unsigned long long>(__float2ll_rn(w11 * g[c])));
+            }
+        }
+        __syncthreads();
+    }
+    float *dst = gimage + (static_cast<int64_t>(b) * C + c0) * plane;
+    for (int i = tid; i < cw * TH * TW; i += 256) {
+        const int c = i / (TH * TW), rem = i % (TH * TW);
+        const int yy = ty0 + rem / TW, xx = tx0 + rem % TW;
+        if (yy < H && xx < W)
+            dst[c * plane + static_cast<int64_t>(yy) * W + xx] = static_cast<float>(acc[i]) * unscale;
     }
 }
 
@@ -235,8 +411,8 @@ int warp_forward(const void *image, const void *flow, void *out, int B, int C, i
 }
 
 int warp_backward(const void *image, const void *flow, const void *gout, void *gimage,
-                  void *gflow, int B, int C, int H, int W, int pad_mode, int interp, int dtype,
-                  hipStream_t s) {
+                  void *gflow, void *workspace, int64_t workspace_bytes, int B, int C, int H,
+                  int W, int pad_mode, int interp, int dtype, hipStream_t s) {
     const int64_t plane = static_cast<int64_t>(H) * W;
     if (B == 0) return CERB_OK;
     const size_t esz = dtype_size(dtype);
@@ -246,16 +422,54 @@ int warp_backward(const void *image, const void *flow, const void *gout, void *g
         // no reference caller differentiates through either.
         return CERB_EUNSUPPORTED;
     }
+    const dim3 grid(static_cast<unsigned>((plane + kPix - 1) / kPix), B);
+    // tiled (owner-computes) grad_image: fp32, caller gave the 16-byte workspace
+    // (ws[0..1] tap extent x/y, ws[2] max|gradOutput| bits)
+    const bool tiled = gimage && dtype == CERB_F32 && workspace &&
+                       workspace_bytes >= static_cast<int64_t>(4 * sizeof(int)) &&
+                       (reinterpret_cast<uintptr_t>(workspace) & 3) == 0;
+    if (tiled) {
+        int *ws = static_cast<int *>(workspace);
+        hipError_t e = hipMemsetAsync(ws, 0, 4 * sizeof(int), s);
+        if (e != hipSuccess) return static_cast<int>(e);
+        // 1. grad_flow (deterministic gather) + tap-extent reduction
+        hipLaunchKernelGGL(warp_bwd_kernel<float>, grid, dim3(kPix * kCg), 0, s,
+                           static_cast<const float *>(image), static_cast<const float *>(flow),
+                           static_cast<const float *>(gout), static_cast<float *>(nullptr),
+                           static_cast<float *>(gflow), ws, static_cast<const int *>(nullptr), C, H,
+                           W, pad_mode);
+        int rc = launch_status();
+        if (rc) return rc;
+        // 2. grad_image tiles (zero-fills instead when the extent exceeds its window)
+        constexpr int TH = 16, TW = 64, CW = 4;  // 32 KiB of int64 accumulators
+        const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
+        const int nchunk = (C + CW - 1) / CW;
+        const int64_t blocks = static_cast<int64_t>(B) * tiles_x * tiles_y * nchunk;
+        if (blocks > 0x7fffffff) return CERB_ETOOLARGE;
+        hipLaunchKernelGGL((warp_gimage_tile_kernel<TH, TW, CW>), dim3(static_cast<unsigned>(blocks)),
+                           dim3(256), 0, s, static_cast<const float *>(flow),
+                           static_cast<const float *>(gout), static_cast<float *>(gimage), ws, C,
+                           H, W, pad_mode, tiles_x, tiles_y, nchunk);
+        rc = launch_status();
+        if (rc) return rc;
+        // 3. scatter fallback, gated on the device: returns at once unless the extent was too large
+        hipLaunchKernelGGL(warp_bwd_kernel<float>, grid, dim3(kPix * kCg), 0, s,
+                           static_cast<const float *>(image), static_cast<const float *>(flow),
+                           static_cast<const float *>(gout), static_cast<float *>(gimage),
+                           static_cast<float *>(nullptr), static_cast<int *>(nullptr), ws, C, H, W,
+                           pad_mode);
+        return launch_status();
+    }
     if (gimage) {
         hipError_t e = hipMemsetAsync(gimage, 0, static_cast<size_t>(B) * C * plane * esz, s);
         if (e != hipSuccess) return static_cast<int>(e);
     }
-    const dim3 grid(static_cast<unsigned>((plane + kPix - 1) / kPix), B);
     CERB_DISPATCH(dtype, hipLaunchKernelGGL(warp_bwd_kernel<T>, grid, dim3(kPix * kCg), 0, s,
                                             static_cast<const T *>(image),
                                             static_cast<const T *>(flow),
                                             static_cast<const T *>(gout), static_cast<T *>(gimage),
-                                            static_cast<T *>(gflow), C, H, W, pad_mode));
+                                            static_cast<T *>(gflow), static_cast<int *>(nullptr),
+                                            static_cast<const int *>(nullptr), C, H, W, pad_mode));
     return launch_status();
 }
 

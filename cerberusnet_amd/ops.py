@@ -218,10 +218,16 @@ def _flow_warp_backward_cuda(image, flow, grad_out, pad_mode, interp_mode, need_
     if img.numel() == 0 or not (need_image or need_flow):
         return [gi, gf]
     B, C, H, W = img.shape
+    lib = _lib.get()
+    # 16-byte device scratch (tap extent + max|grad_out|) (caching allocator: no sync,
+    # graph-capturable; stream-ordered reuse keeps it private to this call)
+    ws_bytes = lib.cerberus_flow_warp_backward_workspace_bytes()
+    ws = torch.empty(ws_bytes // 4, dtype=torch.int32, device=img.device) if need_image else None
     with torch.cuda.device(img.device):
-        rc = _lib.get().cerberus_flow_warp_backward(
+        rc = lib.cerberus_flow_warp_backward(
             img.data_ptr(), flo.data_ptr(), go.data_ptr(),
             gi.data_ptr() if need_image else None, gf.data_ptr() if need_flow else None,
+            ws.data_ptr() if ws is not None else None, ws_bytes if ws is not None else 0,
             B, C, H, W, pad_mode, interp_mode, code, _stream_ptr(img))
     _lib.check(rc, what)
     return [gi, gf]

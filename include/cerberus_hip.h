@@ -6,8 +6,8 @@
  * tensors are dense, contiguous NCHW device buffers owned by the caller
  * (outputs included: the caller allocates, the library fully overwrites them).
  * Every entry point enqueues asynchronously on `stream` (a hipStream_t passed
- * as void*, NULL = default stream), never synchronises, allocates nothing,
- * keeps no global mutable state (re-entrant: autograd may call backward from
+ * as void*, NULL = default stream), never synchronises, allocates nothing
+ * (scratch, where needed, is a caller-provided workspace), keeps no global mutable state (re-entrant: autograd may call backward from
  * its own engine thread) and is therefore safe to capture into a hipGraph.
  *
  * Return value: 0 on success; a negative CERB_E* code for rejected arguments;
@@ -117,13 +117,20 @@ int cerberus_flow_warp_forward(const void *image, const void *flow, void *out,
                                int interp_mode, int dtype, void *stream);
 
 /* flow_warp backward (autograd of the above w.r.t. image and flow).
- *   grad_image : (B,C,H,W) -- zero-filled by this call, then accumulated with
- *                float atomics (summation order is not deterministic, as ATen's)
+ *   grad_image : (B,C,H,W) -- fully overwritten.  Summation order of the taps that
+ *                meet in one pixel is not deterministic (float atomics, as ATen's).
  *   grad_flow  : (B,2,H,W) -- fully overwritten, deterministic
+ *   workspace  : caller-owned device scratch of
+ *                cerberus_flow_warp_backward_workspace_bytes() bytes (4-byte aligned,
+ *                contents irrelevant), private to this call until it completes.  With
+ *                it (fp32) grad_image is built tile by tile in LDS with no global
+ *                atomics; NULL selects the global-atomic scatter (ATen's method).
  * Either grad pointer may be NULL to skip that gradient. */
+int64_t cerberus_flow_warp_backward_workspace_bytes(void);
 int cerberus_flow_warp_backward(const void *image, const void *flow,
                                 const void *grad_out, void *grad_image,
-                                void *grad_flow, int B, int C, int H, int W,
+                                void *grad_flow, void *workspace,
+                                int64_t workspace_bytes, int B, int C, int H, int W,
                                 int pad_mode, int interp_mode, int dtype,
                                 void *stream);
 

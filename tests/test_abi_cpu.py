@@ -55,6 +55,7 @@ def test_argument_rejection_without_gpu():
                                             None) == -1
     assert lib.cerberus_flow_warp_forward(None, None, None, 1, 4, 8, 8, 7, 0, 0, None) == -4
     assert lib.cerberus_flow_warp_forward(None, None, None, 0, 4, 8, 8, 1, 0, 0, None) == 0
+    assert lib.cerberus_flow_warp_backward_workspace_bytes() == 16
     assert b"stride1" in lib.cerberus_error_string(-3)
     assert lib.cerberus_set_option(b"no_such_key", 1) == -1
 
