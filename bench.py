@@ -357,9 +357,15 @@ def main():
         ach = kern[dominant] / per[dominant] / 1e9
         corr_t = sum(v for k, v in per.items() if k.startswith("corr"))
         corr_b = sum(v for k, v in kern.items() if k.startswith("corr"))
+        traffic = None
+        tpath = os.path.join(REPO, "profiles", "r01_pmc_traffic.json")
+        if os.path.exists(tpath) and args.pairs == 4 and (args.width, args.height) == (1024, 512):
+            # HBM-side bytes per launch from the committed rocprofv3 PMC passes
+            # (tools/collect_profiles.sh: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)
+            traffic = json.load(open(tpath)).get(dominant, {}).get("traffic_bytes")
         result["roofline"] = {
             "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-            "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": None, "kernel": dominant,
+            "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": traffic, "kernel": dominant,
             "avg_us": round(per[dominant] * 1e6, 2), "algorithmic_bytes": kern[dominant],
             "corr_all_levels": {"GBps": round(corr_b / corr_t / 1e9, 1),
                                 "frac": round(corr_b / corr_t / 1e9 / HBM_PEAK_GBPS, 4),

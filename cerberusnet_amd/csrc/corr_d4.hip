@@ -598,10 +598,11 @@ int launch_bwd(const char *name, const float *x1, const float *x2, const float *
     const int tiles_x = (g.W + K::TW - 1) / K::TW, tiles_y = (g.H + K::TH - 1) / K::TH;
     const int64_t tiles = static_cast<int64_t>(g.B) * tiles_x * tiles_y;
     if (tiles > 0x7fffffff) return CERB_ETOOLARGE;
-    // channel slice per workgroup: amortise the 81-register gradOutput gather over
-    // >= 2 chunks, but keep >= ~2048 workgroups in flight when the map is small
+    // channel slice per workgroup: every slice repeats the 81-value gradOutput gather, so
+    // slice only as far as needed to put ~2 workgroups on each of the 256 CUs (sweep on
+    // MI355X: 32 / 16 / 8 / 8 channels for the four W32 levels at batch 4)
     int cslice = g.C;
-    while (cslice > 8 && tiles * 2 * ((g.C + cslice - 1) / cslice) < 2048) cslice /= 2;
+    while (cslice > 8 && tiles * 2 * ((g.C + cslice - 1) / cslice) < 512) cslice /= 2;
     if (const int forced = option_value("corr_bwd_cslice")) cslice = forced;
     cslice = ((cslice + K::CC - 1) / K::CC) * K::CC;
     const int nslice = (g.C + cslice - 1) / cslice;
