@@ -46,3 +46,20 @@ def pyramid_shapes(width: int = 1024, height: int = 512, base_ch: int = 32):
     (strides 32,16,8,4; channels 8w,4w,2w,w)."""
     return tuple((base_ch * (8 >> lvl), height // (32 >> lvl),
                   width // (32 >> lvl)) for lvl in range(4))
+
+
+def fill_parameters(module, seed: int = 1000) -> None:
+    """Deterministic, framework-RNG-free weights: parameter i (in named_parameters order) is
+    hash_uniform(seed + i) scaled by 0.7/sqrt(fan_in) (weights) or 0.05 (biases).  Used to put
+    identical weights into the reference's modules (in-container, for goldens) and into this
+    repository's counterparts (anywhere)."""
+    import math
+    import torch
+    for i, (_, p) in enumerate(module.named_parameters()):
+        if p.dim() > 1:
+            fan_in = int(np.prod(p.shape[1:]))
+            scale = 0.7 / math.sqrt(fan_in)
+        else:
+            scale = 0.05
+        with torch.no_grad():
+            p.copy_(torch.from_numpy(hash_uniform(tuple(p.shape), seed + i) * scale))

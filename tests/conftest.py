@@ -41,3 +41,13 @@ def rel_err(a, ref):
     ref = np.asarray(ref, dtype=np.float64)
     denom = np.abs(ref).max()
     return float(np.abs(a - ref).max() / (denom if denom > 0 else 1.0))
+
+
+def l2_err(a, ref):
+    """||a-ref||_2 / ||ref||_2 -- for gradients that pass through the warp: a last-bit change
+    of a flow value can flip a floor() in the bilinear taps and move a handful of pixels by
+    O(1e-3) of the maximum, so the max-norm is not a stable yardstick there."""
+    a = np.asarray(a, dtype=np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
+    den = np.sqrt((ref * ref).sum())
+    return float(np.sqrt(((a - ref) ** 2).sum()) / (den if den > 0 else 1.0))

@@ -1,0 +1,67 @@
+"""Caller row on the GPU: PWCNetHead on the HIP ops vs goldens from the REFERENCE head and vs
+the same head on the pure-torch backend (same MIOpen convolutions, so any difference is the
+hot-path ops)."""
+import numpy as np
+import pytest
+import torch
+
+from cerberusnet_amd.nnet_models import PWCNetHead
+from cerberusnet_amd.synth import fill_parameters
+from conftest import rel_err, l2_err
+from test_pwchead_cpu import CHANS, build, pyramids
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.mark.parametrize("est,tag", [("FlowEstimatorLite", "lite"), ("FlowEstimatorDense", "dense")])
+@pytest.mark.parametrize("fuse", [True, False])
+def test_hip_head_matches_reference_goldens(golden, est, tag, fuse):
+    g = golden("pwchead_" + tag)
+    head = build(est, fuse_leaky=fuse).to(DEV)
+    p1, p2 = pyramids(g, DEV)
+    flows = head((None, p1), (None, p2))
+    for i, f in enumerate(flows):
+        # GPU convolutions (MIOpen) differ from the CPU ones in summation order: 1e-4
+        assert rel_err(f.detach().cpu().numpy(), g["flow_%d" % i]) < 1e-4
+    loss = sum((f * f).mean() for f in flows)
+    assert abs(loss.item() - float(g["loss"])) < 1e-4 * abs(float(g["loss"]))
+    grads = torch.autograd.grad(loss, p1 + p2 + list(head.parameters()))
+    for l in range(4):
+        assert l2_err(grads[l].cpu().numpy(), g["g_im1_%d" % l]) < 2e-3
+        assert l2_err(grads[4 + l].cpu().numpy(), g["g_im2_%d" % l]) < 2e-3
+    norms = np.array([float(x.double().norm()) for x in grads[8:]])
+    assert np.allclose(norms, g["param_grad_norms"], rtol=2e-3, atol=1e-9)
+
+
+def test_hip_and_torch_backends_agree_on_device(golden):
+    g = golden("pwchead_lite")
+    res = {}
+    for backend in ("hip", "torch"):
+        head = build("FlowEstimatorLite", correlation_backend=backend).to(DEV)
+        p1, p2 = pyramids(g, DEV)
+        flows = head((None, p1), (None, p2))
+        loss = sum((f * f).mean() for f in flows)
+        grads = torch.autograd.grad(loss, p1 + p2 + list(head.parameters()))
+        res[backend] = ([f.detach().cpu().numpy() for f in flows],
+                        [x.cpu().numpy() for x in grads])
+    for a, b in zip(res["hip"][0], res["torch"][0]):
+        assert rel_err(a, b) < 2e-5
+    for a, b in zip(res["hip"][1], res["torch"][1]):
+        assert l2_err(a, b) < 2e-3
+
+
+def test_both_directions_training_step_runs_and_is_finite():
+    head = build("FlowEstimatorLite").to(DEV)
+    opt = torch.optim.Adam(head.parameters(), lr=1e-4, betas=(0.9, 0.99), weight_decay=1e-6)
+    feats1 = [torch.randn(2, c, 8 * 2 ** l, 16 * 2 ** l, device=DEV) for l, c in enumerate(reversed(CHANS))]
+    feats2 = [torch.randn(2, c, 8 * 2 ** l, 16 * 2 ** l, device=DEV) for l, c in enumerate(reversed(CHANS))]
+    for _ in range(2):
+        opt.zero_grad()
+        fw = head((None, feats1), (None, feats2))
+        bw = head((None, feats2), (None, feats1))
+        loss = sum(f.abs().mean() for f in fw + bw)
+        loss.backward()
+        opt.step()
+    assert torch.isfinite(loss)
+    assert all(torch.isfinite(p.grad).all() for p in head.parameters())

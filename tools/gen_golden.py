@@ -63,6 +63,25 @@ def import_reference():
     return corr, unflow
 
 
+def import_reference_pwc_head(corr_mod):
+    """PWCNetHead from the reference tree (Appendix A step 3), with Correlation.forward routed
+    to the reference's own CorrelationTorch (torch.ops.cerberus does not exist on CPU)."""
+    pkg = types.ModuleType("nnet_training.nnet_models")
+    pkg.__path__ = [os.path.join(REF, "nnet_models")]
+    sys.modules["nnet_training.nnet_models"] = pkg
+    for name in ("pwcnet_modules", "nnet_ops", "fast_scnn"):
+        _load("nnet_training.nnet_models." + name, os.path.join(REF, "nnet_models", name + ".py"))
+
+    def torch_forward(self, a, b):
+        assert self.pad_size == self.max_displacement and self.kernel_size == 1
+        assert self.stride1 == 1 and self.stride2 == 1
+        return corr_mod.CorrelationTorch(self.max_displacement)(a, b)
+    corr_mod.Correlation.forward = torch_forward
+    mod = _load("nnet_training.nnet_models.pwcnet_sfd",
+                os.path.join(REF, "nnet_models", "pwcnet_sfd.py"))
+    return mod.PWCNetHead
+
+
 def sampled(arr, n=64):
     flat = arr.reshape(-1)
     idx = (np.arange(n, dtype=np.int64) * 2654435761 + 12345) % flat.size
@@ -123,6 +142,41 @@ def main():
     q2 = unflow.flow_warp(ramp, torch.zeros(1, 2, 4, 6))
     np.savez_compressed(os.path.join(OUT, "warp_q2.npz"), image=ramp.numpy(),
                         out=q2.numpy())
+
+    # ---------------- PWCNetHead (the caller of both ops) ----------------
+    from cerberusnet_amd.synth import fill_parameters
+    Head = import_reference_pwc_head(corr_mod)
+    chans = [8, 12, 16, 24]                      # HRNet order: high resolution first
+    sizes = [(4, 6), (8, 12), (16, 24), (32, 48)]  # pyramid order: low resolution first
+    for est in ("FlowEstimatorLite", "FlowEstimatorDense"):
+        head = Head(chans, upsample=True,
+                    correlation_args=dict(pad_size=4, kernel_size=1, max_displacement=4,
+                                          stride1=1, stride2=1, corr_multiply=1),
+                    flow_est_network=dict(type=est, args={}),
+                    context_network=dict(type="ContextNetwork", args={}),
+                    **{"1x1_conv_out": 32})
+        fill_parameters(head, 1000)
+        head.train()
+        rec = {"keys": np.array(list(head.state_dict().keys())),
+               "shapes": np.array([str(tuple(v.shape)) for v in head.state_dict().values()])}
+        pyr1, pyr2 = [], []
+        for lvl, ((h, w), c) in enumerate(zip(sizes, reversed(chans))):
+            a = hash_uniform((1, c, h, w), 70 + lvl)
+            b = hash_uniform((1, c, h, w), 80 + lvl)
+            rec["im1_%d" % lvl], rec["im2_%d" % lvl] = a, b
+            pyr1.append(torch.from_numpy(a).requires_grad_(True))
+            pyr2.append(torch.from_numpy(b).requires_grad_(True))
+        flows = head((None, pyr1), (None, pyr2))
+        loss = sum((f * f).mean() for f in flows)
+        grads = torch.autograd.grad(loss, pyr1 + pyr2 + list(head.parameters()))
+        for i, f in enumerate(flows):
+            rec["flow_%d" % i] = f.detach().numpy()
+        rec["loss"] = np.float64(loss.item())
+        for lvl in range(4):
+            rec["g_im1_%d" % lvl] = grads[lvl].numpy()
+            rec["g_im2_%d" % lvl] = grads[4 + lvl].numpy()
+        rec["param_grad_norms"] = np.array([float(g.double().norm()) for g in grads[8:]])
+        np.savez_compressed(os.path.join(OUT, "pwchead_%s.npz" % est[13:].lower()), **rec)
 
     # ---------------- full-size checksums ----------------
     rec = {}
