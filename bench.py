@@ -69,7 +69,7 @@ class Workload:
         up = up + torch.from_numpy(hash_uniform((pairs, 2, H, W), seed + 100, -0.25, 0.25))
         return up.contiguous().to(device)
 
-    def __init__(self, pairs, width, height, device, flow_kind="smooth"):
+    def __init__(self, pairs, width, height, device, flow_kind="smooth", fuse=False):
         from cerberusnet_amd.synth import hash_uniform, pyramid_shapes
         import cerberusnet_amd  # noqa: F401  registers torch.ops.cerberus.*
         self.levels = pyramid_shapes(width, height, 32)
@@ -86,83 +86,61 @@ class Workload:
                     gout=t((pairs, 81, H, W), 2),
                     flow=self._flow(pairs, H, W, seed + 3, flow_kind, device) if l > 0 else None))
             self.dirs.append(lv)
+        if fuse:
+            # both directions as ONE batched call per op (2*pairs items): what a caller does
+            # that stacks (enc, enc_bw) and (enc_bw, enc) before entering the head
+            fused = []
+            for a, b in zip(*self.dirs):
+                fused.append({k: (torch.cat([a[k], b[k]], 0) if a[k] is not None else None)
+                              for k in ("f1", "f2", "gout", "flow")})
+            self.dirs = [fused]
 
     def kernels(self):
-        """(label, algorithmic bytes) of every launch in one step."""
+        """(label, algorithmic bytes) of every launch of one direction (or of the fused call)."""
         out = []
+        nb = self.dirs[0][0]["f1"].shape[0]
         for l, (C, H, W) in enumerate(self.levels):
-            cf, cb = corr_bytes(C, self.pairs, H, W)
+            cf, cb = corr_bytes(C, nb, H, W)
             out += [("corr_fwd_L%d" % l, cf), ("corr_bwd_L%d" % l, cb)]
             if l > 0:
-                wf, wb = warp_bytes(C, self.pairs, H, W)
+                wf, wb = warp_bytes(C, nb, H, W)
                 out += [("warp_fwd_L%d" % l, wf), ("warp_bwd_L%d" % l, wb)]
         return out
 
-    def step(self, probe=None):
-        """Run one step. `probe(label)` returns a context manager used by the
-        per-kernel timing pass; None on the timed path."""
+    def _direction(self, lv, keep):
         ops = torch.ops.cerberus
+        # forward, coarse to fine
+        for l, t in enumerate(lv):
+            t["warped"] = ops.flow_warp(t["f2"], t["flow"], 1, 0) if l > 0 else t["f2"]
+            t["out"] = ops.correlation(t["f1"], t["warped"], *CORR_P)
+        # backward, fine to coarse
+        for l in reversed(range(len(lv))):
+            t = lv[l]
+            g1, g2 = ops.correlation_backward(t["f1"], t["warped"], t["gout"], *CORR_P)
+            keep.append(g1)
+            if l > 0:
+                keep += ops.flow_warp_backward(t["f2"], t["flow"], g2, 1, 0, True, True)
+            else:
+                keep.append(g2)
+
+    def step(self, streams=None):
+        """One step.  The two flow directions are independent (cerberus.py:131,135 run the
+        same head on swapped inputs): with `streams` they are issued on two HIP streams
+        (fork/join with events, capturable into one hipGraph) so that the latency-bound
+        coarse-level kernels of one direction overlap the other's."""
         keep = []
-        for lv in self.dirs:
-            # forward, coarse to fine
-            for l, t in enumerate(lv):
-                if l > 0:
-                    with probe("warp_fwd_L%d" % l) if probe else _null:
-                        t["warped"] = ops.flow_warp(t["f2"], t["flow"], 1, 0)
-                else:
-                    t["warped"] = t["f2"]
-                with probe("corr_fwd_L%d" % l) if probe else _null:
-                    t["out"] = ops.correlation(t["f1"], t["warped"], *CORR_P)
-            # backward, fine to coarse
-            for l in reversed(range(len(lv))):
-                t = lv[l]
-                with probe("corr_bwd_L%d" % l) if probe else _null:
-                    g1, g2 = ops.correlation_backward(t["f1"], t["warped"], t["gout"], *CORR_P)
-                keep.append(g1)
-                if l > 0:
-                    with probe("warp_bwd_L%d" % l) if probe else _null:
-                        gi, gf = ops.flow_warp_backward(t["f2"], t["flow"], g2, 1, 0, True, True)
-                    keep += [gi, gf]
-                else:
-                    keep.append(g2)
+        if not streams or len(self.dirs) == 1:
+            for lv in self.dirs:
+                self._direction(lv, keep)
+            return keep
+        main = torch.cuda.current_stream()
+        side = streams[0]
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            self._direction(self.dirs[1], keep)
+        self._direction(self.dirs[0], keep)
+        main.wait_stream(side)
         return keep
-
-
-class _Null:
-    def __enter__(self): return self
-    def __exit__(self, *a): return False
-
-
-_null = _Null()
-
-
-class EventProbe:
-    """HIP-event brackets on the launch stream (torch's current stream IS the
-    stream every cerberus op launches on, ops.py:_stream_ptr)."""
-
-    def __init__(self):
-        self.records = {}
-
-    def __call__(self, label):
-        probe = self
-
-        class _Ctx:
-            def __enter__(self_inner):
-                self_inner.a = torch.cuda.Event(enable_timing=True)
-                self_inner.b = torch.cuda.Event(enable_timing=True)
-                self_inner.a.record()
-                return self_inner
-
-            def __exit__(self_inner, *exc):
-                self_inner.b.record()
-                probe.records.setdefault(label, []).append((self_inner.a, self_inner.b))
-                return False
-        return _Ctx()
-
-    def summary(self):
-        torch.cuda.synchronize()
-        return {k: float(np.mean([a.elapsed_time(b) for a, b in v])) * 1e-3
-                for k, v in self.records.items()}  # seconds per launch
 
 
 def per_kernel_times(wl, reps):
@@ -170,9 +148,9 @@ def per_kernel_times(wl, reps):
     ops = torch.ops.cerberus
     lv = wl.dirs[0]
     calls = {}
+    if "warped" not in lv[-1]:
+        wl.step()
     for l, t in enumerate(lv):
-        if "warped" not in t:
-            wl.step()
         calls["corr_fwd_L%d" % l] = (lambda t=t: ops.correlation(t["f1"], t["warped"], *CORR_P))
         calls["corr_bwd_L%d" % l] = (lambda t=t: ops.correlation_backward(
             t["f1"], t["warped"], t["gout"], *CORR_P))
@@ -262,6 +240,10 @@ def main():
     ap.add_argument("--width", type=int, default=1024)
     ap.add_argument("--height", type=int, default=512)
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--fuse-directions", action="store_true",
+                    help="stack both flow directions into one batched call per op")
+    ap.add_argument("--serial-directions", action="store_true",
+                    help="issue both flow directions on one stream (default: two streams)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--probe-steps", type=int, default=20)
     ap.add_argument("--flow", choices=["smooth", "noise"], default="smooth",
@@ -284,25 +266,26 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=device)  # RCCL
 
-    wl = Workload(args.pairs, args.width, args.height, device, args.flow)
+    wl = Workload(args.pairs, args.width, args.height, device, args.flow, args.fuse_directions)
 
     # ---- warm-up (eager), then capture the step into a hipGraph ----
+    streams = None if args.serial_directions else [torch.cuda.Stream()]
     for _ in range(max(1, args.warmup if args.no_graph else 3)):
-        wl.step()
+        wl.step(streams)
     torch.cuda.synchronize()
     graph = None
     if not args.no_graph:
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            wl.step()
-        torch.cuda.current_stream().wait_stream(side)
+        cap = torch.cuda.Stream()
+        cap.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(cap):
+            wl.step(streams)
+        torch.cuda.current_stream().wait_stream(cap)
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
-            held = wl.step()  # noqa: F841  keep outputs alive for the graph's pool
+            held = wl.step(streams)  # noqa: F841  keep outputs alive for the graph's pool
         for _ in range(args.warmup):
             graph.replay()
-    run = graph.replay if graph is not None else wl.step
+    run = graph.replay if graph is not None else (lambda: wl.step(streams))
 
     def fence():
         torch.cuda.synchronize()
@@ -325,8 +308,9 @@ def main():
     if rank == 0:
         pairs_total = args.pairs * world * args.steps
         kern = dict(wl.kernels())
-        step_bytes = 2 * sum(kern.values())                       # two directions
-        corr_step_bytes = 2 * sum(v for k, v in kern.items() if k.startswith("corr"))
+        ndir = len(wl.dirs)                                       # 2, or 1 when fused (2x batch)
+        step_bytes = ndir * sum(kern.values())
+        corr_step_bytes = ndir * sum(v for k, v in kern.items() if k.startswith("corr"))
         result = {
             "metric": METRIC, "value": round(pairs_total / elapsed, 2), "unit": "image-pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -338,7 +322,9 @@ def main():
                             "per-GPU batch), both flow directions, fwd+bwd" % args.pairs,
                 "pairs_per_gpu": args.pairs, "levels_CHW": [list(s) for s in wl.levels],
                 "flow_field": args.flow,
-                "launch": "hipGraph replay" if graph is not None else "eager",
+                "launch": ("hipGraph replay" if graph is not None else "eager") +
+                          (", directions fused into one batched call" if args.fuse_directions else
+                           ", 2 streams (one per flow direction)" if streams else ", 1 stream"),
                 "sharding": "image pairs sharded over ranks, no data-path collective",
                 "algorithmic_bytes_per_step": step_bytes,
                 "step_algorithmic_GBps_per_gpu": round(step_bytes * args.steps / elapsed / 1e9, 1),
@@ -353,13 +339,16 @@ def main():
     if rank == 0:
         per = per_kernel_times(wl, max(2, args.probe_steps))
         kern = dict(wl.kernels())
-        dominant = max(per, key=lambda k: per[k])
+        # dominant single KERNEL: warp_bwd is a sequence of three kernels + a memset, so the
+        # longest individual launch of the step is a correlation kernel
+        dominant = max((k for k in per if k.startswith("corr")), key=lambda k: per[k])
         ach = kern[dominant] / per[dominant] / 1e9
         corr_t = sum(v for k, v in per.items() if k.startswith("corr"))
         corr_b = sum(v for k, v in kern.items() if k.startswith("corr"))
         traffic = None
         tpath = os.path.join(REPO, "profiles", "r01_pmc_traffic.json")
-        if os.path.exists(tpath) and args.pairs == 4 and (args.width, args.height) == (1024, 512):
+        if (os.path.exists(tpath) and args.pairs == 4 and not args.fuse_directions and
+                (args.width, args.height) == (1024, 512)):
             # HBM-side bytes per launch from the committed rocprofv3 PMC passes
             # (tools/collect_profiles.sh: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)
             traffic = json.load(open(tpath)).get(dominant, {}).get("traffic_bytes")
