@@ -1,93 +1,81 @@
-"""Drop-in for ``nnet_training/correlation_package/correlation.py``.
+"""Drop-in for ``nnet_training/correlation_package/correlation.py`` (public surface only).
 
-Same three public classes, same constructor / forward signatures and defaults:
+Three names, with the reference's constructor / call signatures and defaults:
 
-  * ``CorrelationTorch(max_displacement=4)``          reference :4-21
-  * ``CorrelationFunction.apply(input1, input2, pad_size=3, kernel_size=3,
-        max_displacement=20, stride1=1, stride2=2, corr_multiply=1)``  :23-57
-  * ``Correlation(pad_size=0, kernel_size=0, max_displacement=0, stride1=1,
-        stride2=2, corr_multiply=1)``                 :60-80
+  ``CorrelationTorch(max_displacement=4)``                                  reference :4-21
+  ``CorrelationFunction.apply(input1, input2, pad_size=3, kernel_size=3,
+        max_displacement=20, stride1=1, stride2=2, corr_multiply=1)``       reference :23-57
+  ``Correlation(pad_size=0, kernel_size=0, max_displacement=0, stride1=1,
+        stride2=2, corr_multiply=1)``                                       reference :60-80
 
-The import-time ``torch.ops.load_library(<cwd-relative cpython-38 path>)`` of
-the reference (:2) is replaced by importing ``cerberusnet_amd.ops``, which
-registers ``torch.ops.cerberus.correlation{,_backward}`` on top of
-libcerberus_hip.so (resolved relative to the package, any CWD, any CPython).
+Where the reference loads a CUDA extension by a CWD-relative, CPython-3.8-specific path
+at import time (:2), importing this module registers ``torch.ops.cerberus.correlation``
+and ``torch.ops.cerberus.correlation_backward`` through ``cerberusnet_amd.ops`` (HIP
+kernels behind a C ABI, located relative to the package).
 """
 import torch
+import torch.nn.functional as F
 
-from .. import ops as _ops  # noqa: F401  (registers torch.ops.cerberus.*)
+from .. import ops as _ops  # noqa: F401  -- side effect: torch.ops.cerberus.* exist
+
+_HYPER = ("pad_size", "kernel_size", "max_displacement", "stride1", "stride2", "corr_multiply")
 
 
 class CorrelationTorch(torch.nn.Module):
-    """Pure-PyTorch cost volume (device-agnostic), as the reference ships it."""
+    """Cost volume in stock PyTorch ops (any device): the semantic anchor of the HIP op at
+    pad = d, kernel 1, strides 1.  Output channel ``i * (2d+1) + j`` is the channel mean of
+    ``x1 * x2`` shifted by ``i - d`` rows and ``j - d`` columns (zero outside)."""
 
     def __init__(self, max_displacement=4, *args, **kwargs):
         super().__init__()
         self.max_displacement = max_displacement
-        self.output_dim = 2 * self.max_displacement + 1
-        self.pad_size = self.max_displacement
+        self.pad_size = max_displacement
+        self.output_dim = 2 * max_displacement + 1
 
     def forward(self, x1, x2):
-        height, width = x1.shape[2], x1.shape[3]
-        padded = torch.nn.functional.pad(x2, [self.pad_size] * 4)
-        volume = [
-            torch.mean(x1 * padded[:, :, dy:dy + height, dx:dx + width], 1, keepdim=True)
-            for dy in range(self.output_dim) for dx in range(self.output_dim)
-        ]
-        return torch.cat(volume, 1)
+        rows, cols = x1.shape[-2:]
+        span, border = self.output_dim, self.pad_size
+        x2_padded = F.pad(x2, (border, border, border, border))
+        out = x1.new_empty((x1.shape[0], span * span, rows, cols))
+        for k in range(span * span):
+            i, j = divmod(k, span)  # i: vertical (slow), j: horizontal (fast)
+            out[:, k] = (x1 * x2_padded[..., i:i + rows, j:j + cols]).mean(dim=1)
+        return out
 
 
 class CorrelationFunction(torch.autograd.Function):
-    """
-    Typical Parameters: pad_size=3, kernel_size=3, max_displacement=20,
-    stride1=1, stride2=2, corr_multiply=1
-    """
+    """autograd glue around the two raw ops.  Only the inputs are saved: callers apply an
+    in-place ``leaky_relu`` to the output (pwcnet_sfd.py:182), so it must not be needed
+    by backward.  Runs in the caller's dtype under autocast (no input cast)."""
 
     @staticmethod
     @torch.amp.custom_fwd(device_type="cuda")
-    def forward(ctx, input1, input2, pad_size=3, kernel_size=3,
-                max_displacement=20, stride1=1, stride2=2, corr_multiply=1):
-        # only the two inputs are saved (the output is NOT: callers apply an
-        # in-place leaky_relu to it, pwcnet_sfd.py:182)
+    def forward(ctx, input1, input2, pad_size=3, kernel_size=3, max_displacement=20,
+                stride1=1, stride2=2, corr_multiply=1):
+        ctx.hyper = (pad_size, kernel_size, max_displacement, stride1, stride2, corr_multiply)
         ctx.save_for_backward(input1, input2)
-        ctx.pad_size = pad_size
-        ctx.kernel_size = kernel_size
-        ctx.max_displacement = max_displacement
-        ctx.stride1 = stride1
-        ctx.stride2 = stride2
-        ctx.corr_multiply = corr_multiply
-        return torch.ops.cerberus.correlation(
-            input1, input2, pad_size, kernel_size,
-            max_displacement, stride1, stride2, corr_multiply)
+        return torch.ops.cerberus.correlation(input1, input2, *ctx.hyper)
 
     @staticmethod
     @torch.amp.custom_bwd(device_type="cuda")
-    def backward(ctx, grad_outputs):
-        input1, input2 = ctx.saved_tensors
-        grad_input1, grad_input2 = torch.ops.cerberus.correlation_backward(
-            input1, input2, grad_outputs, ctx.pad_size, ctx.kernel_size,
-            ctx.max_displacement, ctx.stride1, ctx.stride2, ctx.corr_multiply)
-        return grad_input1, grad_input2, None, None, None, None, None, None
+    def backward(ctx, grad_output):
+        grads = torch.ops.cerberus.correlation_backward(*ctx.saved_tensors, grad_output,
+                                                        *ctx.hyper)
+        return (grads[0], grads[1]) + (None,) * len(_HYPER)
 
 
 class Correlation(torch.nn.Module):
-    """Parameter-free module; nothing enters ``state_dict``."""
+    """Stateless module (nothing in ``state_dict``): training mode goes through
+    ``CorrelationFunction`` (differentiable), eval mode calls the raw op."""
 
     def __init__(self, pad_size=0, kernel_size=0, max_displacement=0,
                  stride1=1, stride2=2, corr_multiply=1):
         super().__init__()
-        self.pad_size = pad_size
-        self.kernel_size = kernel_size
-        self.max_displacement = max_displacement
-        self.stride1 = stride1
-        self.stride2 = stride2
-        self.corr_multiply = corr_multiply
+        for name, value in zip(_HYPER, (pad_size, kernel_size, max_displacement, stride1,
+                                        stride2, corr_multiply)):
+            setattr(self, name, value)
 
     def forward(self, input1, input2):
-        if self.training:
-            return CorrelationFunction.apply(
-                input1, input2, self.pad_size, self.kernel_size,
-                self.max_displacement, self.stride1, self.stride2, self.corr_multiply)
-        return torch.ops.cerberus.correlation(
-            input1, input2, self.pad_size, self.kernel_size,
-            self.max_displacement, self.stride1, self.stride2, self.corr_multiply)
+        hyper = tuple(getattr(self, name) for name in _HYPER)
+        run = CorrelationFunction.apply if self.training else torch.ops.cerberus.correlation
+        return run(input1, input2, *hyper)

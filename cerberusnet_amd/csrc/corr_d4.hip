@@ -98,6 +98,67 @@ struct FwdCfg {
 __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
 __device__ __forceinline__ void st4(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
 
+// ---- global-memory element types ------------------------------------------------------
+// fp16 / bf16 are STORAGE formats: values are widened when staged into LDS / registers,
+// every product and sum is fp32 (the reference accumulates fp16 in fp16),
+// results are rounded once on the way out.  LDS always holds fp32.
+template <typename T> struct Gmem;
+template <> struct Gmem<float> {
+    static __device__ __forceinline__ float load1(const float *p) { return *p; }
+    static __device__ __forceinline__ float2 load2(const float *p) { return *reinterpret_cast<const float2 *>(p); }
+    static __device__ __forceinline__ float4 load4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+    static __device__ __forceinline__ void store1(float *p, float v) { *p = v; }
+    static __device__ __forceinline__ void store2(float *p, float a, float b) { *reinterpret_cast<float2 *>(p) = make_float2(a, b); }
+    static __device__ __forceinline__ void store4(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
+};
+template <> struct Gmem<__half> {
+    static __device__ __forceinline__ float load1(const __half *p) { return __half2float(*p); }
+    static __device__ __forceinline__ float2 load2(const __half *p) { return __half22float2(*reinterpret_cast<const __half2 *>(p)); }
+    static __device__ __forceinline__ float4 load4(const __half *p) {
+        const uint2 raw = *reinterpret_cast<const uint2 *>(p);
+        const float2 lo = __half22float2(*reinterpret_cast<const __half2 *>(&raw.x));
+        const float2 hi = __half22float2(*reinterpret_cast<const __half2 *>(&raw.y));
+        return make_float4(lo.x, lo.y, hi.x, hi.y);
+    }
+    static __device__ __forceinline__ void store1(__half *p, float v) { *p = __float2half(v); }
+    static __device__ __forceinline__ void store2(__half *p, float a, float b) { *reinterpret_cast<__half2 *>(p) = __floats2half2_rn(a, b); }
+    static __device__ __forceinline__ void store4(__half *p, float4 v) {
+        uint2 raw;
+        *reinterpret_cast<__half2 *>(&raw.x) = __floats2half2_rn(v.x, v.y);
+        *reinterpret_cast<__half2 *>(&raw.y) = __floats2half2_rn(v.z, v.w);
+        *reinterpret_cast<uint2 *>(p) = raw;
+    }
+};
+template <> struct Gmem<hip_bfloat16> {
+    static __device__ __forceinline__ float widen(unsigned short b) { return __uint_as_float(static_cast<unsigned int>(b) << 16); }
+    static __device__ __forceinline__ unsigned short narrow(float v) {
+        const hip_bfloat16 h(v);  // round to nearest even, NaN stays NaN
+        unsigned short b;
+        __builtin_memcpy(&b, &h, 2);
+        return b;
+    }
+    static __device__ __forceinline__ float load1(const hip_bfloat16 *p) { return widen(*reinterpret_cast<const unsigned short *>(p)); }
+    static __device__ __forceinline__ float2 load2(const hip_bfloat16 *p) {
+        const unsigned int raw = *reinterpret_cast<const unsigned int *>(p);
+        return make_float2(__uint_as_float(raw << 16), __uint_as_float(raw & 0xFFFF0000u));
+    }
+    static __device__ __forceinline__ float4 load4(const hip_bfloat16 *p) {
+        const uint2 raw = *reinterpret_cast<const uint2 *>(p);
+        return make_float4(__uint_as_float(raw.x << 16), __uint_as_float(raw.x & 0xFFFF0000u),
+                           __uint_as_float(raw.y << 16), __uint_as_float(raw.y & 0xFFFF0000u));
+    }
+    static __device__ __forceinline__ void store1(hip_bfloat16 *p, float v) { *reinterpret_cast<unsigned short *>(p) = narrow(v); }
+    static __device__ __forceinline__ void store2(hip_bfloat16 *p, float a, float b) {
+        *reinterpret_cast<unsigned int *>(p) = narrow(a) | (static_cast<unsigned int>(narrow(b)) << 16);
+    }
+    static __device__ __forceinline__ void store4(hip_bfloat16 *p, float4 v) {
+        uint2 raw;
+        raw.x = narrow(v.x) | (static_cast<unsigned int>(narrow(v.y)) << 16);
+        raw.y = narrow(v.z) | (static_cast<unsigned int>(narrow(v.w)) << 16);
+        *reinterpret_cast<uint2 *>(p) = raw;
+    }
+};
+
 typedef float float2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float2v pkfma(float2v a, float2v b, float2v c) {
     return __builtin_elementwise_fma(a, b, c);  // v_pk_fma_f32
@@ -117,9 +178,9 @@ __device__ __forceinline__ float2v ld2v_nomerge(const float *p) {
 // prefetch pipeline -- seen in the ISA of the first version.)
 __device__ __attribute__((aligned(16))) float g_zero16[4] = {0.f, 0.f, 0.f, 0.f};
 
-template <typename K, bool VEC>
+template <typename K, typename T, bool VEC>
 __global__ __launch_bounds__(K::THREADS, K::WPS) void corr_fwd_d4_kernel(
-    const float *__restrict__ x1, const float *__restrict__ x2, float *__restrict__ out, int C,
+    const T *__restrict__ x1, const T *__restrict__ x2, T *__restrict__ out, int C,
     int H, int W, int tiles_x, int tiles_y, float slope, int64_t out_bstride, int dbg) {
     // Timing-ablation builds only (-DCERB_ABLATE; results are WRONG when the mask is set):
     // 1 = store only displacement 0, 2 = load only the first chunk, 4 = skip the FMAs,
@@ -149,8 +210,8 @@ __global__ __launch_bounds__(K::THREADS, K::WPS) void corr_fwd_d4_kernel(
     const int plane = H * W;
     const int Cg = C / S;  // channels per group (launcher guarantees C % S == 0)
     const int nchunks = (Cg + CC - 1) / CC;
-    const float *x1b = x1 + static_cast<int64_t>(b) * C * plane;
-    const float *x2b = x2 + static_cast<int64_t>(b) * C * plane;
+    const T *x1b = x1 + static_cast<int64_t>(b) * C * plane;
+    const T *x2b = x2 + static_cast<int64_t>(b) * C * plane;
 
     // ---- per-slot staging descriptors (fixed for the whole kernel) ----
     int goff[K::NSLOT];           // element offset (+4) of chunk 0 in the batch item, <0: zeros
@@ -190,21 +251,22 @@ __global__ __launch_bounds__(K::THREADS, K::WPS) void corr_fwd_d4_kernel(
 #pragma unroll
         for (int j = 0; j < K::NSLOT; ++j) {
             const bool live = goff[j] >= 0 && (k * CC + chi[j] < Cg);
-            const float *base = (tid + j * K::THREADS < K::N2) ? x2b : x1b;
+            const T *base = (tid + j * K::THREADS < K::N2) ? x2b : x1b;
             if (VEC) {
                 // branch-free: dead slots (halo outside the image, channels past the
                 // end, chunks past the last one) read the zero block instead
-                const float *src = live ? base + (goff[j] - 4) + k * CC * plane : g_zero16;
-                st[j] = ld4(src);
+                const T *src = live ? base + (goff[j] - 4) + k * CC * plane
+                                    : reinterpret_cast<const T *>(g_zero16);
+                st[j] = Gmem<T>::load4(src);
             } else {
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (live) {
-                    const float *src = base + (goff[j] - 4) + k * CC * plane;
+                    const T *src = base + (goff[j] - 4) + k * CC * plane;
                     const int gx = gx0[j];
-                    if (gx >= 0 && gx < W) v.x = src[0];
-                    if (gx + 1 >= 0 && gx + 1 < W) v.y = src[1];
-                    if (gx + 2 >= 0 && gx + 2 < W) v.z = src[2];
-                    if (gx + 3 >= 0 && gx + 3 < W) v.w = src[3];
+                    if (gx >= 0 && gx < W) v.x = Gmem<T>::load1(src);
+                    if (gx + 1 >= 0 && gx + 1 < W) v.y = Gmem<T>::load1(src + 1);
+                    if (gx + 2 >= 0 && gx + 2 < W) v.z = Gmem<T>::load1(src + 2);
+                    if (gx + 3 >= 0 && gx + 3 < W) v.w = Gmem<T>::load1(src + 3);
                 }
                 st[j] = v;
             }
@@ -277,7 +339,7 @@ __global__ __launch_bounds__(K::THREADS, K::WPS) void corr_fwd_d4_kernel(
     }
 
     if (dbg & 32) {  // ablation: no epilogue
-        if (tid == 0) out[blockIdx.x] = accs[0][0] + stage[0][0].x;
+        if (tid == 0) Gmem<T>::store1(out + blockIdx.x, accs[0][0] + stage[0][0].x);
         return;
     }
     // ---- unpack to acc[rb][d][p] ----
@@ -316,7 +378,7 @@ __global__ __launch_bounds__(K::THREADS, K::WPS) void corr_fwd_d4_kernel(
     // whenever C is a power of two (every CerberusNet level) and within 1 ulp otherwise
     const float inv_nelems = 1.0f / static_cast<float>(C);
     const int64_t obs = out_bstride ? out_bstride : static_cast<int64_t>(kND * kND) * plane;
-    float *ob = out + b * obs + static_cast<int64_t>(wave * kND) * plane;
+    T *ob = out + b * obs + static_cast<int64_t>(wave * kND) * plane;
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) {
         const int y = y0 + r + rb * K::NR;
@@ -331,13 +393,13 @@ __global__ __launch_bounds__(K::THREADS, K::WPS) void corr_fwd_d4_kernel(
                 const float q = acc[rb][d][p] * inv_nelems;
                 v[p] = q > 0.f ? q : q * slope;
             }
-            float *dst = ob + static_cast<int64_t>(d) * plane + y * W + x;
+            T *dst = ob + static_cast<int64_t>(d) * plane + y * W + x;
             if (VEC) {
-                st4(dst, make_float4(v[0], v[1], v[2], v[3]));
+                Gmem<T>::store4(dst, make_float4(v[0], v[1], v[2], v[3]));
             } else {
 #pragma unroll
                 for (int p = 0; p < kP; ++p)
-                    if (x + p < W) dst[p] = v[p];
+                    if (x + p < W) Gmem<T>::store1(dst + p, v[p]);
             }
         }
     }
@@ -374,10 +436,10 @@ __device__ __forceinline__ float2 ld2u(const float *p) {
     return make_float2(t.x, t.y);
 }
 
-template <typename K, bool VEC>
+template <typename K, typename T, bool VEC>
 __global__ __launch_bounds__(256, 2) void corr_bwd_d4_kernel(
-    const float *__restrict__ x1, const float *__restrict__ x2, const float *__restrict__ gout,
-    float *__restrict__ gin1, float *__restrict__ gin2, int C, int H, int W, int tiles_x,
+    const T *__restrict__ x1, const T *__restrict__ x2, const T *__restrict__ gout,
+    T *__restrict__ gin1, T *__restrict__ gin2, int C, int H, int W, int tiles_x,
     int tiles_y, int cslice, int nslice, int dbg) {
 #ifndef CERB_ABLATE
     dbg = 0;
@@ -402,9 +464,9 @@ __global__ __launch_bounds__(256, 2) void corr_bwd_d4_kernel(
     const int c_end = min(C, c_begin + cslice);
     const int plane = H * W;
 
-    const float *src = (side == 0 ? x2 : x1) + static_cast<int64_t>(b) * C * plane;
-    float *dstb = (side == 0 ? gin1 : gin2) + static_cast<int64_t>(b) * C * plane;
-    const float *gob = gout + static_cast<int64_t>(b) * (kND * kND) * plane;
+    const T *src = (side == 0 ? x2 : x1) + static_cast<int64_t>(b) * C * plane;
+    T *dstb = (side == 0 ? gin1 : gin2) + static_cast<int64_t>(b) * C * plane;
+    const T *gob = gout + static_cast<int64_t>(b) * (kND * kND) * plane;
 
     const int y = y0 + r, x = x0 + 2 * sxp;
     const bool live = y < H && x < W;
@@ -434,18 +496,18 @@ __global__ __launch_bounds__(256, 2) void corr_bwd_d4_kernel(
         for (int j = 0; j < K::NSLOT; ++j) {
             const bool on = goff[j] >= 0 && c_first + chi[j] < c_end;
             if (VEC) {
-                const float *p = on ? src + static_cast<int64_t>(c_first) * plane + (goff[j] - 4)
-                                    : g_zero16;
-                stage[j] = ld4(p);
+                const T *p = on ? src + static_cast<int64_t>(c_first) * plane + (goff[j] - 4)
+                                : reinterpret_cast<const T *>(g_zero16);
+                stage[j] = Gmem<T>::load4(p);
             } else {
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (on) {
-                    const float *p = src + static_cast<int64_t>(c_first) * plane + (goff[j] - 4);
+                    const T *p = src + static_cast<int64_t>(c_first) * plane + (goff[j] - 4);
                     const int gx = gx0[j];
-                    if (gx >= 0 && gx < W) v.x = p[0];
-                    if (gx + 1 >= 0 && gx + 1 < W) v.y = p[1];
-                    if (gx + 2 >= 0 && gx + 2 < W) v.z = p[2];
-                    if (gx + 3 >= 0 && gx + 3 < W) v.w = p[3];
+                    if (gx >= 0 && gx < W) v.x = Gmem<T>::load1(p);
+                    if (gx + 1 >= 0 && gx + 1 < W) v.y = Gmem<T>::load1(p + 1);
+                    if (gx + 2 >= 0 && gx + 2 < W) v.z = Gmem<T>::load1(p + 2);
+                    if (gx + 3 >= 0 && gx + 3 < W) v.w = Gmem<T>::load1(p + 3);
                 }
                 stage[j] = v;
             }
@@ -475,17 +537,19 @@ __global__ __launch_bounds__(256, 2) void corr_bwd_d4_kernel(
         float v0 = 0.f, v1 = 0.f;
         if (live) {
             if (side == 0) {
-                const float *p = gob + static_cast<int64_t>(d) * plane + y * W + x;
-                if (VEC) { const float2 t = ld2(p); v0 = t.x; v1 = t.y; }
-                else { v0 = p[0]; if (x + 1 < W) v1 = p[1]; }
+                const T *p = gob + static_cast<int64_t>(d) * plane + y * W + x;
+                if (VEC) { const float2 t = Gmem<T>::load2(p); v0 = t.x; v1 = t.y; }
+                else { v0 = Gmem<T>::load1(p); if (x + 1 < W) v1 = Gmem<T>::load1(p + 1); }
             } else {
                 const int yy = y + dy, xx = x + dx;
                 if (yy >= 0 && yy < H) {
-                    const float *p = gob + static_cast<int64_t>(kND * kND - 1 - d) * plane + yy * W + xx;
-                    if (xx >= 0 && xx + 1 < W) { const float2 t = ld2u(p); v0 = t.x; v1 = t.y; }
-                    else {
-                        if (xx >= 0 && xx < W) v0 = p[0];
-                        if (xx + 1 >= 0 && xx + 1 < W) v1 = p[1];
+                    const T *p = gob + static_cast<int64_t>(kND * kND - 1 - d) * plane + yy * W + xx;
+                    if (sizeof(T) == 4 && xx >= 0 && xx + 1 < W) {
+                        const float2 t = ld2u(reinterpret_cast<const float *>(p));  // dword-aligned pair
+                        v0 = t.x; v1 = t.y;
+                    } else {
+                        if (xx >= 0 && xx < W) v0 = Gmem<T>::load1(p);
+                        if (xx + 1 >= 0 && xx + 1 < W) v1 = Gmem<T>::load1(p + 1);
                     }
                 }
             }
@@ -537,12 +601,12 @@ __global__ __launch_bounds__(256, 2) void corr_bwd_d4_kernel(
 #pragma unroll
         for (int i = 0; i < CC; ++i) {
             if (live && c0 + i < c_end && !((dbg & 1) && (c0 + i) != c_begin)) {
-                float *dst = dstb + static_cast<int64_t>(c0 + i) * plane + y * W + x;
+                T *dst = dstb + static_cast<int64_t>(c0 + i) * plane + y * W + x;
                 if (VEC) {
-                    *reinterpret_cast<float2 *>(dst) = make_float2(res[i][0], res[i][1]);
+                    Gmem<T>::store2(dst, res[i][0], res[i][1]);
                 } else {
-                    dst[0] = res[i][0];
-                    if (x + 1 < W) dst[1] = res[i][1];
+                    Gmem<T>::store1(dst, res[i][0]);
+                    if (x + 1 < W) Gmem<T>::store1(dst + 1, res[i][1]);
                 }
             }
         }
@@ -561,32 +625,40 @@ int ensure_lds(Kern kern, size_t bytes, bool *done) {
     return e == hipSuccess ? CERB_OK : static_cast<int>(e);
 }
 
-template <typename K>
-int launch_fwd(const char *name, const float *x1, const float *x2, float *out, const CorrGeom &g,
+// 16-bit storage is only instantiated for the vector (aligned, W % 4 == 0) path; other
+// shapes of those dtypes take the generic kernels.
+template <typename K, typename T>
+int launch_fwd(const char *name, const void *in1, const void *in2, void *outp, const CorrGeom &g,
                float slope, int64_t obs, bool vec, hipStream_t s) {
+    const T *x1 = static_cast<const T *>(in1), *x2 = static_cast<const T *>(in2);
+    T *out = static_cast<T *>(outp);
     const int tiles_x = (g.W + K::TW - 1) / K::TW, tiles_y = (g.H + K::TH - 1) / K::TH;
     const int64_t blocks = static_cast<int64_t>(g.B) * tiles_x * tiles_y;
     if (blocks > 0x7fffffff) return CERB_ETOOLARGE;
-    note_kernel(0, name);
     int rc;
     static bool lds_v = false, lds_s = false;
+    const int dbg = option_value("corr_debug_ablate");
     if (vec) {
-        if ((rc = ensure_lds(corr_fwd_d4_kernel<K, true>, K::LDS_BYTES, &lds_v))) return rc;
-        hipLaunchKernelGGL((corr_fwd_d4_kernel<K, true>), dim3(static_cast<unsigned>(blocks)),
+        note_kernel(0, name);
+        if ((rc = ensure_lds(corr_fwd_d4_kernel<K, T, true>, K::LDS_BYTES, &lds_v))) return rc;
+        hipLaunchKernelGGL((corr_fwd_d4_kernel<K, T, true>), dim3(static_cast<unsigned>(blocks)),
                            dim3(K::THREADS), K::LDS_BYTES, s, x1, x2, out, g.C, g.H, g.W, tiles_x,
-                           tiles_y, slope, obs, option_value("corr_debug_ablate"));
+                           tiles_y, slope, obs, dbg);
+    } else if constexpr (sizeof(T) == 4) {
+        note_kernel(0, name);
+        if ((rc = ensure_lds(corr_fwd_d4_kernel<K, T, false>, K::LDS_BYTES, &lds_s))) return rc;
+        hipLaunchKernelGGL((corr_fwd_d4_kernel<K, T, false>), dim3(static_cast<unsigned>(blocks)),
+                           dim3(K::THREADS), K::LDS_BYTES, s, x1, x2, out, g.C, g.H, g.W, tiles_x,
+                           tiles_y, slope, obs, dbg);
     } else {
-        if ((rc = ensure_lds(corr_fwd_d4_kernel<K, false>, K::LDS_BYTES, &lds_s))) return rc;
-        hipLaunchKernelGGL((corr_fwd_d4_kernel<K, false>), dim3(static_cast<unsigned>(blocks)),
-                           dim3(K::THREADS), K::LDS_BYTES, s, x1, x2, out, g.C, g.H, g.W, tiles_x,
-                           tiles_y, slope, obs, option_value("corr_debug_ablate"));
+        return CERB_EUNSUPPORTED;
     }
     return launch_status();
 }
 
-//                     S  TSX RB CC ROT RS  RS1 PRES
-using FwdA2 = FwdCfg<1, 16, 2, 4, 2, 72, 72, 0, 3, 1>;   // 8x64 tile, fine levels
-using FwdA1 = FwdCfg<1, 16, 1, 8, 2, 72, 72, 0, 5, 1>;   // 4x64 tile
+//                     S  TSX RB CC ROT RS  RS1 PRES WPS NSET
+using FwdA2 = FwdCfg<1, 16, 2, 4, 2, 72, 72, 0, 3, 1>;   // 8x64 tile
+using FwdA1 = FwdCfg<1, 16, 1, 8, 2, 72, 72, 0, 5, 1>;   // 4x64 tile, 8-channel chunks
 using FwdB1 = FwdCfg<2, 16, 1, 4, 2, 72, 72, 0, 3, 2>;   // 2x64 tile, 2 channel groups
 using FwdC1 = FwdCfg<4, 16, 1, 4, 0, 72, 64, 0, 3, 2>;   // 1x64 tile, 4 channel groups
 using FwdD1 = FwdCfg<8, 8, 1, 4, 0, 40, 32, 32, 3, 1>;   // 1x32 tile, 8 channel groups
@@ -599,9 +671,12 @@ int64_t fwd_tiles(const CorrGeom &g) {
     return static_cast<int64_t>(g.B) * ((g.W + K::TW - 1) / K::TW) * ((g.H + K::TH - 1) / K::TH);
 }
 
-template <typename K>
-int launch_bwd(const char *name, const float *x1, const float *x2, const float *gout, float *gin1,
-               float *gin2, const CorrGeom &g, bool vec, hipStream_t s) {
+template <typename K, typename T>
+int launch_bwd(const char *name, const void *in1, const void *in2, const void *goutp, void *g1p,
+               void *g2p, const CorrGeom &g, bool vec, hipStream_t s) {
+    const T *x1 = static_cast<const T *>(in1), *x2 = static_cast<const T *>(in2);
+    const T *gout = static_cast<const T *>(goutp);
+    T *gin1 = static_cast<T *>(g1p), *gin2 = static_cast<T *>(g2p);
     const int tiles_x = (g.W + K::TW - 1) / K::TW, tiles_y = (g.H + K::TH - 1) / K::TH;
     const int64_t tiles = static_cast<int64_t>(g.B) * tiles_x * tiles_y;
     if (tiles > 0x7fffffff) return CERB_ETOOLARGE;
@@ -614,20 +689,24 @@ int launch_bwd(const char *name, const float *x1, const float *x2, const float *
     cslice = ((cslice + K::CC - 1) / K::CC) * K::CC;
     const int nslice = (g.C + cslice - 1) / cslice;
     if (tiles * nslice * 2 > 0x7fffffff) return CERB_ETOOLARGE;
-    note_kernel(1, name);
     const dim3 grid(static_cast<unsigned>(tiles * nslice * 2));
     int rc;
     static bool lds_v = false, lds_s = false;
+    const int dbg = option_value("corr_debug_ablate");
     if (vec) {
-        if ((rc = ensure_lds(corr_bwd_d4_kernel<K, true>, K::LDS_BYTES, &lds_v))) return rc;
-        hipLaunchKernelGGL((corr_bwd_d4_kernel<K, true>), grid, dim3(K::THREADS), K::LDS_BYTES, s,
-                           x1, x2, gout, gin1, gin2, g.C, g.H, g.W, tiles_x, tiles_y, cslice, nslice,
-                           option_value("corr_debug_ablate"));
+        note_kernel(1, name);
+        if ((rc = ensure_lds(corr_bwd_d4_kernel<K, T, true>, K::LDS_BYTES, &lds_v))) return rc;
+        hipLaunchKernelGGL((corr_bwd_d4_kernel<K, T, true>), grid, dim3(K::THREADS), K::LDS_BYTES,
+                           s, x1, x2, gout, gin1, gin2, g.C, g.H, g.W, tiles_x, tiles_y, cslice,
+                           nslice, dbg);
+    } else if constexpr (sizeof(T) == 4) {
+        note_kernel(1, name);
+        if ((rc = ensure_lds(corr_bwd_d4_kernel<K, T, false>, K::LDS_BYTES, &lds_s))) return rc;
+        hipLaunchKernelGGL((corr_bwd_d4_kernel<K, T, false>), grid, dim3(K::THREADS), K::LDS_BYTES,
+                           s, x1, x2, gout, gin1, gin2, g.C, g.H, g.W, tiles_x, tiles_y, cslice,
+                           nslice, dbg);
     } else {
-        if ((rc = ensure_lds(corr_bwd_d4_kernel<K, false>, K::LDS_BYTES, &lds_s))) return rc;
-        hipLaunchKernelGGL((corr_bwd_d4_kernel<K, false>), grid, dim3(K::THREADS), K::LDS_BYTES, s,
-                           x1, x2, gout, gin1, gin2, g.C, g.H, g.W, tiles_x, tiles_y, cslice, nslice,
-                           option_value("corr_debug_ablate"));
+        return CERB_EUNSUPPORTED;
     }
     return launch_status();
 }
@@ -636,58 +715,79 @@ using BwdWide = BwdCfg<32, 2, 72>;    // 8x64 tile
 using BwdNarrow = BwdCfg<16, 2, 96>;  // 16x32 tile
 
 bool fast_config(const CorrGeom &g, int dtype) {
-    return dtype == CERB_F32 && g.pad == kD && g.maxd == kD && g.ksize == 1 && g.s1 == 1 &&
-           g.s2 == 1 && static_cast<int64_t>(g.C) * g.H * g.W < (1ll << 30);
+    return (dtype == CERB_F32 || dtype == CERB_F16 || dtype == CERB_BF16) && g.pad == kD &&
+           g.maxd == kD && g.ksize == 1 && g.s1 == 1 && g.s2 == 1 &&
+           static_cast<int64_t>(g.C) * g.H * g.W < (1ll << 30);
 }
 
-bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+// a 4-element group must be naturally aligned: 16 B (fp32) or 8 B (16-bit storage)
+bool aligned_group(const void *p, int dtype) {
+    return (reinterpret_cast<uintptr_t>(p) & (dtype == CERB_F32 ? 15 : 7)) == 0;
+}
 
-}  // namespace
-
-int corr_d4_forward(const void *in1, const void *in2, void *out, const CorrGeom &g, float slope,
-                    int64_t obs, int dtype, hipStream_t s) {
-    if (!fast_config(g, dtype)) return CERB_EUNSUPPORTED;
-    const float *x1 = static_cast<const float *>(in1), *x2 = static_cast<const float *>(in2);
-    float *o = static_cast<float *>(out);
-    const bool vec = g.W % 4 == 0 && aligned16(in1) && aligned16(in2) && aligned16(out) &&
-                     (obs % 4 == 0);
-    // pick the widest tile that still yields enough workgroups to fill 256 CUs;
-    // fall back to channel-split variants (shuffle reduction) on small maps
+template <typename T>
+int fwd_dispatch(const void *x1, const void *x2, void *o, const CorrGeom &g, float slope,
+                 int64_t obs, bool vec, hipStream_t s) {
     switch (option_value("corr_fwd_variant")) {  // tuning / test hook
-        case 1: return launch_fwd<FwdA2>("corr_fwd_d4_8x64", x1, x2, o, g, slope, obs, vec, s);
-        case 2: return launch_fwd<FwdA1>("corr_fwd_d4_4x64", x1, x2, o, g, slope, obs, vec, s);
-        case 3: if (g.C % 2 == 0) return launch_fwd<FwdB1>("corr_fwd_d4_2x64_s2", x1, x2, o, g, slope, obs, vec, s); break;
-        case 4: if (g.C % 4 == 0) return launch_fwd<FwdC1>("corr_fwd_d4_1x64_s4", x1, x2, o, g, slope, obs, vec, s); break;
-        case 5: if (g.C % 8 == 0) return launch_fwd<FwdD1>("corr_fwd_d4_1x32_s8", x1, x2, o, g, slope, obs, vec, s); break;
-        case 6: if (g.C % 16 == 0) return launch_fwd<FwdE1>("corr_fwd_d4_1x16_s16", x1, x2, o, g, slope, obs, vec, s); break;
-        case 7: return launch_fwd<FwdA1b>("corr_fwd_d4_4x64_cc4", x1, x2, o, g, slope, obs, vec, s);
-        case 8: return launch_fwd<FwdA1c>("corr_fwd_d4_4x64_cc4x2", x1, x2, o, g, slope, obs, vec, s);
+        case 1: return launch_fwd<FwdA2, T>("corr_fwd_d4_8x64", x1, x2, o, g, slope, obs, vec, s);
+        case 2: return launch_fwd<FwdA1, T>("corr_fwd_d4_4x64", x1, x2, o, g, slope, obs, vec, s);
+        case 3: if (g.C % 2 == 0) return launch_fwd<FwdB1, T>("corr_fwd_d4_2x64_s2", x1, x2, o, g, slope, obs, vec, s); break;
+        case 4: if (g.C % 4 == 0) return launch_fwd<FwdC1, T>("corr_fwd_d4_1x64_s4", x1, x2, o, g, slope, obs, vec, s); break;
+        case 5: if (g.C % 8 == 0) return launch_fwd<FwdD1, T>("corr_fwd_d4_1x32_s8", x1, x2, o, g, slope, obs, vec, s); break;
+        case 6: if (g.C % 16 == 0) return launch_fwd<FwdE1, T>("corr_fwd_d4_1x16_s16", x1, x2, o, g, slope, obs, vec, s); break;
+        case 7: return launch_fwd<FwdA1b, T>("corr_fwd_d4_4x64_cc4", x1, x2, o, g, slope, obs, vec, s);
+        case 8: return launch_fwd<FwdA1c, T>("corr_fwd_d4_4x64_cc4x2", x1, x2, o, g, slope, obs, vec, s);
         default: break;
     }
     // Smallest channel split that still yields >= 256 workgroups (one per CU); the tile
     // sweep on MI355X (tools/tune_corr.py, profiles/) picked exactly this order.
     const int64_t want = 256;
     if (fwd_tiles<FwdA1b>(g) >= want || g.C % 2 != 0)
-        return launch_fwd<FwdA1b>("corr_fwd_d4_4x64_cc4", x1, x2, o, g, slope, obs, vec, s);
+        return launch_fwd<FwdA1b, T>("corr_fwd_d4_4x64_cc4", x1, x2, o, g, slope, obs, vec, s);
     if (fwd_tiles<FwdB1>(g) >= want || g.C % 4 != 0)
-        return launch_fwd<FwdB1>("corr_fwd_d4_2x64_s2", x1, x2, o, g, slope, obs, vec, s);
+        return launch_fwd<FwdB1, T>("corr_fwd_d4_2x64_s2", x1, x2, o, g, slope, obs, vec, s);
     if (fwd_tiles<FwdC1>(g) >= want || g.C % 8 != 0)
-        return launch_fwd<FwdC1>("corr_fwd_d4_1x64_s4", x1, x2, o, g, slope, obs, vec, s);
+        return launch_fwd<FwdC1, T>("corr_fwd_d4_1x64_s4", x1, x2, o, g, slope, obs, vec, s);
     if (fwd_tiles<FwdD1>(g) >= want || g.C % 16 != 0)
-        return launch_fwd<FwdD1>("corr_fwd_d4_1x32_s8", x1, x2, o, g, slope, obs, vec, s);
-    return launch_fwd<FwdE1>("corr_fwd_d4_1x16_s16", x1, x2, o, g, slope, obs, vec, s);
+        return launch_fwd<FwdD1, T>("corr_fwd_d4_1x32_s8", x1, x2, o, g, slope, obs, vec, s);
+    return launch_fwd<FwdE1, T>("corr_fwd_d4_1x16_s16", x1, x2, o, g, slope, obs, vec, s);
+}
+
+template <typename T>
+int bwd_dispatch(const void *x1, const void *x2, const void *go, void *g1, void *g2,
+                 const CorrGeom &g, bool vec, hipStream_t s) {
+    if (g.W <= 32)
+        return launch_bwd<BwdNarrow, T>("corr_bwd_d4_16x32", x1, x2, go, g1, g2, g, vec, s);
+    return launch_bwd<BwdWide, T>("corr_bwd_d4_8x64", x1, x2, go, g1, g2, g, vec, s);
+}
+
+}  // namespace
+
+int corr_d4_forward(const void *in1, const void *in2, void *out, const CorrGeom &g, float slope,
+                    int64_t obs, int dtype, hipStream_t s) {
+    if (!fast_config(g, dtype)) return CERB_EUNSUPPORTED;
+    const bool vec = g.W % 4 == 0 && aligned_group(in1, dtype) && aligned_group(in2, dtype) &&
+                     aligned_group(out, dtype) && (obs % 4 == 0);
+    switch (dtype) {
+        case CERB_F32: return fwd_dispatch<float>(in1, in2, out, g, slope, obs, vec, s);
+        case CERB_F16: return fwd_dispatch<__half>(in1, in2, out, g, slope, obs, vec, s);
+        case CERB_BF16: return fwd_dispatch<hip_bfloat16>(in1, in2, out, g, slope, obs, vec, s);
+        default: return CERB_EUNSUPPORTED;
+    }
 }
 
 int corr_d4_backward(const void *in1, const void *in2, const void *gout, void *gin1, void *gin2,
                      const CorrGeom &g, int dtype, hipStream_t s) {
     if (!fast_config(g, dtype)) return CERB_EUNSUPPORTED;
-    const float *x1 = static_cast<const float *>(in1), *x2 = static_cast<const float *>(in2);
-    const float *go = static_cast<const float *>(gout);
-    float *g1 = static_cast<float *>(gin1), *g2 = static_cast<float *>(gin2);
-    const bool vec = g.W % 4 == 0 && aligned16(in1) && aligned16(in2) && aligned16(gout) &&
-                     aligned16(gin1) && aligned16(gin2);
-    if (g.W <= 32) return launch_bwd<BwdNarrow>("corr_bwd_d4_16x32", x1, x2, go, g1, g2, g, vec, s);
-    return launch_bwd<BwdWide>("corr_bwd_d4_8x64", x1, x2, go, g1, g2, g, vec, s);
+    const bool vec = g.W % 4 == 0 && aligned_group(in1, dtype) && aligned_group(in2, dtype) &&
+                     aligned_group(gout, dtype) && aligned_group(gin1, dtype) &&
+                     aligned_group(gin2, dtype);
+    switch (dtype) {
+        case CERB_F32: return bwd_dispatch<float>(in1, in2, gout, gin1, gin2, g, vec, s);
+        case CERB_F16: return bwd_dispatch<__half>(in1, in2, gout, gin1, gin2, g, vec, s);
+        case CERB_BF16: return bwd_dispatch<hip_bfloat16>(in1, in2, gout, gin1, gin2, g, vec, s);
+        default: return CERB_EUNSUPPORTED;
+    }
 }
 
 }  // namespace cerb

@@ -334,3 +334,34 @@ def test_headline_shapes_use_the_tuned_kernels():
         assert _lib.last_kernel(0).startswith("corr_fwd_d4"), _lib.last_kernel(0)
         torch.ops.cerberus.correlation_backward(a, a, out, 4, 1, 4, 1, 1, 1)
         assert _lib.last_kernel(1).startswith("corr_bwd_d4"), _lib.last_kernel(1)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float16, 2e-3), (torch.bfloat16, 1.6e-2)])
+@pytest.mark.parametrize("lvl", [0, 3])
+def test_half_storage_takes_the_tuned_kernels(dtype, tol, lvl):
+    """AMP configuration (BASELINE config 5 uses fp16): 16-bit storage runs on the tuned
+    kernels (fp32 accumulation), checked against the fp64 oracle on the rounded inputs."""
+    C, H, W = W32_PYRAMID_1024x512[lvl]
+    H, W = min(H, 32), min(W, 64)          # keep the CPU oracle fast
+    shp = (1, C, H, W)
+    x1 = torch.from_numpy(hash_uniform(shp, 51)).to(dtype)
+    x2 = torch.from_numpy(hash_uniform(shp, 52)).to(dtype)
+    go = torch.from_numpy(hash_uniform((1, 81, H, W), 53)).to(dtype)
+    p = (4, 1, 4, 1, 1)
+    out = torch.ops.cerberus.correlation(x1.to(DEV), x2.to(DEV), *p, 1)
+    assert _lib.last_kernel(0).startswith("corr_fwd_d4"), _lib.last_kernel(0)
+    g1, g2 = torch.ops.cerberus.correlation_backward(x1.to(DEV), x2.to(DEV), go.to(DEV), *p, 1)
+    assert _lib.last_kernel(1).startswith("corr_bwd_d4"), _lib.last_kernel(1)
+    assert out.dtype == dtype and g1.dtype == dtype
+    ref = oracle.corr_forward_ref(x1.double().numpy(), x2.double().numpy(), *p)
+    r1, r2 = oracle.corr_backward_ref(x1.double().numpy(), x2.double().numpy(),
+                                      go.double().numpy(), *p)
+    assert rel_err(out.double().cpu().numpy(), ref) < tol
+    assert rel_err(g1.double().cpu().numpy(), r1) < tol
+    assert rel_err(g2.double().cpu().numpy(), r2) < tol
+    # odd width -> no 8-byte groups -> generic kernels, same numbers
+    xo1, xo2 = x1[..., :W - 1].contiguous().to(DEV), x2[..., :W - 1].contiguous().to(DEV)
+    outo = torch.ops.cerberus.correlation(xo1, xo2, *p, 1)
+    assert _lib.last_kernel(0) == "corr_fwd_generic"
+    refo = oracle.corr_forward_ref(xo1.double().cpu().numpy(), xo2.double().cpu().numpy(), *p)
+    assert rel_err(outo.double().cpu().numpy(), refo) < tol
