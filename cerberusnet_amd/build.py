@@ -54,7 +54,7 @@ def build(force: bool = False, verbose: bool = False, extra_flags=()):
     """Compile every HIP source for gfx950 and link the shared library."""
     os.makedirs(OBJDIR, exist_ok=True)
     os.makedirs(LIBDIR, exist_ok=True)
-    extra = list(extra_flags)
+    extra = list(extra_flags) + os.environ.get("CERB_EXTRA_HIPCC_FLAGS", "").split()
     with concurrent.futures.ThreadPoolExecutor(max_workers=4) as pool:
         results = list(pool.map(lambda s: _compile(s, force, verbose, extra), SOURCES))
     objs = [o for o, _ in results]

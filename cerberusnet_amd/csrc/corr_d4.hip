@@ -446,6 +446,7 @@ __global__ __launch_bounds__(256, 2) void corr_bwd_d4_kernel(
 #endif
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int CC = K::CC;
+    if (dbg & 64) return;
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     const int r = wave * K::RPW + lane / K::TSXP;
@@ -530,34 +531,60 @@ __global__ __launch_bounds__(256, 2) void corr_bwd_d4_kernel(
     //   pixel 1: single dx=0 * w[1], pairs dx=(1,2)(3,4)(5,6)(7,8) * w[(2,3)..(8,9)]
     float2v g0p[kND][4], g1p[kND][4];
     float g0s[kND], g1s[kND];
+    {
+        // Branch-free gather (the first version, one guarded load per value, spent ~14 us of
+        // EVERY backward launch here: 1300 basic blocks of bounds checks).  The address of
+        // value d is  gob + [uniform offset of d] + [per-lane pixel offset]; validity of the
+        // shifted taps is three 9-bit masks computed once per lane; dead lanes read their
+        // own pixel of plane 0 (always in bounds) and the value is zeroed afterwards.
+        const int lane_off = live ? y * W + x : 0;
+        unsigned ymask = 0, xmask0 = 0, xmask1 = 0;
 #pragma unroll
-    for (int d = 0; d < kND * kND; ++d) {
-        const int dyi = d / kND, dxi = d % kND;
-        const int dy = dyi - kD, dx = dxi - kD;
-        float v0 = 0.f, v1 = 0.f;
-        if (live) {
-            if (side == 0) {
-                const T *p = gob + static_cast<int64_t>(d) * plane + y * W + x;
-                if (VEC) { const float2 t = Gmem<T>::load2(p); v0 = t.x; v1 = t.y; }
-                else { v0 = Gmem<T>::load1(p); if (x + 1 < W) v1 = Gmem<T>::load1(p + 1); }
-            } else {
-                const int yy = y + dy, xx = x + dx;
-                if (yy >= 0 && yy < H) {
-                    const T *p = gob + static_cast<int64_t>(kND * kND - 1 - d) * plane + yy * W + xx;
-                    if (sizeof(T) == 4 && xx >= 0 && xx + 1 < W) {
-                        const float2 t = ld2u(reinterpret_cast<const float *>(p));  // dword-aligned pair
-                        v0 = t.x; v1 = t.y;
-                    } else {
-                        if (xx >= 0 && xx < W) v0 = Gmem<T>::load1(p);
-                        if (xx + 1 >= 0 && xx + 1 < W) v1 = Gmem<T>::load1(p + 1);
-                    }
-                }
-            }
+        for (int k = 0; k < kND; ++k) {
+            const int yy = y + k - kD, xx = x + k - kD;
+            if (yy >= 0 && yy < H) ymask |= 1u << k;
+            if (xx >= 0 && xx < W) xmask0 |= 1u << k;
+            if (xx + 1 >= 0 && xx + 1 < W) xmask1 |= 1u << k;
         }
-        if (dxi == 8) g0s[dyi] = v0; else if (dxi & 1) g0p[dyi][dxi / 2].y = v0; else g0p[dyi][dxi / 2].x = v0;
-        if (dxi == 0) g1s[dyi] = v1; else if (dxi & 1) g1p[dyi][(dxi - 1) / 2].x = v1; else g1p[dyi][(dxi - 1) / 2].y = v1;
+        if (!live) ymask = 0;
+        const bool pair_ok = live && (VEC || x + 1 < W);
+#pragma unroll
+        for (int d = 0; d < kND * kND; ++d) {
+            const int dyi = d / kND, dxi = d % kND;
+            float v0, v1;
+            // no arithmetic on the loaded values: a select after the load would make every
+            // load wait for its data before the next one issues (162 serialised round trips)
+            if (side == 0) {  // wave-uniform
+                const T *pd = gob + static_cast<int64_t>(d) * plane;  // scalar base
+                if (VEC) {
+                    const float2 t = Gmem<T>::load2(pd + lane_off);  // dead lanes: value unused
+                    v0 = t.x; v1 = t.y;
+                } else {
+                    v0 = Gmem<T>::load1(pd + lane_off);
+                    v1 = Gmem<T>::load1(pd + (pair_ok ? lane_off + 1 : lane_off));
+                }
+            } else {
+                // gO[80-d][y+dy][x+dx (+1)]; taps outside the image read the zero block
+                const int uni = (kND * kND - 1 - d) * plane + (dyi - kD) * W + (dxi - kD);
+                const bool oky = (ymask >> dyi) & 1u;
+                const bool ok0 = oky && ((xmask0 >> dxi) & 1u);
+                const bool ok1 = oky && ((xmask1 >> dxi) & 1u);
+                const T *zero = reinterpret_cast<const T *>(g_zero16);
+                // two dword loads, no branch: a pair load plus a patch branch for border lanes
+                // was tried and re-serialised the whole gather (59 vs 46 us at level 3)
+                v0 = Gmem<T>::load1(ok0 ? gob + (uni + lane_off) : zero);
+                v1 = Gmem<T>::load1(ok1 ? gob + (uni + lane_off + 1) : zero);
+            }
+            if (dxi == 8) g0s[dyi] = v0; else if (dxi & 1) g0p[dyi][dxi / 2].y = v0; else g0p[dyi][dxi / 2].x = v0;
+            if (dxi == 0) g1s[dyi] = v1; else if (dxi & 1) g1p[dyi][(dxi - 1) / 2].x = v1; else g1p[dyi][(dxi - 1) / 2].y = v1;
+        }
     }
 
+    if (dbg & 32) {  // ablation: gather only
+        if (live) Gmem<T>::store1(dstb + static_cast<int64_t>(c_begin) * plane + y * W + x,
+                                  g0s[0] + g1s[8] + g0p[4][2].x + stage[0].x);
+        return;
+    }
     const float inv_nelems = 1.0f / static_cast<float>(C);
     int it = 0;
     for (int c0 = c_begin; c0 < c_end; c0 += CC, ++it) {
@@ -717,7 +744,8 @@ using BwdNarrow = BwdCfg<16, 2, 96>;  // 16x32 tile
 bool fast_config(const CorrGeom &g, int dtype) {
     return (dtype == CERB_F32 || dtype == CERB_F16 || dtype == CERB_BF16) && g.pad == kD &&
            g.maxd == kD && g.ksize == 1 && g.s1 == 1 && g.s2 == 1 &&
-           static_cast<int64_t>(g.C) * g.H * g.W < (1ll << 30);
+           static_cast<int64_t>(g.C) * g.H * g.W < (1ll << 30) &&
+           static_cast<int64_t>(kND * kND) * g.H * g.W < (1ll << 30);  // 32-bit offsets
 }
 
 // a 4-element group must be naturally aligned: 16 B (fp32) or 8 B (16-bit storage)

@@ -64,7 +64,35 @@ __device__ __forceinline__ Coord<A> source_coord(int pix, A flow, int size, int 
     return {p, m};
 }
 
+// Branch-free tap fetch: a tap outside the image reads a block of zeros instead of being
+// skipped.  (A branch around a load -- or a select on its result -- makes hipcc wait for
+// that load before issuing the next one; measured on the correlation backward gather:
+// 162 serialised round trips.  Exact zeros, so NaN/Inf in neighbouring pixels cannot leak.)
+__device__ __attribute__((aligned(16))) float g_warp_zero[4] = {0.f, 0.f, 0.f, 0.f};
 template <typename T>
+__device__ __forceinline__ const T *tap_ptr(const T *real, bool ok) {
+    return ok ? real : reinterpret_cast<const T *>(g_warp_zero);
+}
+// Variant: the two horizontal taps as ONE dword-aligned 8-byte load when both are inside
+// (fp32), separate guarded loads at the border.  Fewer gather instructions, but a branch.
+struct __attribute__((packed, aligned(4))) f32x2_u { float a, b; };
+template <bool PAIR, typename T, typename A>
+__device__ __forceinline__ void load_taps(const T *q, bool ok0, bool ok1, A &v0, A &v1) {
+    if constexpr (PAIR && sizeof(T) == 4 && sizeof(A) == 4) {
+        if (ok0 && ok1) {
+            const f32x2_u t = *reinterpret_cast<const f32x2_u *>(q);
+            v0 = t.a; v1 = t.b;
+        } else {
+            v0 = ok0 ? ld(q) : A(0);
+            v1 = ok1 ? ld(q + 1) : A(0);
+        }
+    } else {
+        v0 = ld(tap_ptr(q, ok0));
+        v1 = ld(tap_ptr(q + 1, ok1));
+    }
+}
+
+template <typename T, bool PAIR>
 __global__ __launch_bounds__(kPix * kCg) void warp_fwd_kernel(
     const T *__restrict__ image, const T *__restrict__ flow, T *__restrict__ out, int C, int H,
     int W, int pad_mode, int interp) {
@@ -106,20 +134,18 @@ __global__ __launch_bounds__(kPix * kCg) void warp_fwd_kernel(
         for (int u = 0; u < kU; ++u) {
             const int cc = min(c + u * kCg, C - 1);
             const T *q = img + cc * plane + o00;
-            v[u][0] = (oky0 && okx0) ? ld(q) : A(0);
-            v[u][1] = (oky0 && okx1) ? ld(q + 1) : A(0);
-            v[u][2] = (oky1 && okx0) ? ld(q + W) : A(0);
-            v[u][3] = (oky1 && okx1) ? ld(q + W + 1) : A(0);
+            load_taps<PAIR, T, A>(q, oky0 && okx0, oky0 && okx1, v[u][0], v[u][1]);
+            load_taps<PAIR, T, A>(q + W, oky1 && okx0, oky1 && okx1, v[u][2], v[u][3]);
         }
 #pragma unroll
         for (int u = 0; u < kU; ++u) {
             const int cc = c + u * kCg;
             if (cc >= C) break;
-            A acc = 0;
-            if (oky0 && okx0) acc += v[u][0] * wnw;
-            if (oky0 && okx1) acc += v[u][1] * wne;
-            if (oky1 && okx0) acc += v[u][2] * wsw;
-            if (oky1 && okx1) acc += v[u][3] * wse;
+            // same summation order as before; absent taps contribute exact zeros
+            A acc = v[u][0] * wnw;
+            acc += v[u][1] * wne;
+            acc += v[u][2] * wsw;
+            acc += v[u][3] * wse;
             st(dst + cc * plane, acc);
         }
     }
@@ -173,7 +199,7 @@ __device__ __forceinline__ void publish_max(int *ws, int v) {
     if (v > *reinterpret_cast<volatile int *>(ws)) atomicMax(ws, v);
 }
 
-template <typename T>
+template <typename T, bool PAIR>
 __global__ __launch_bounds__(kPix * kCg) void warp_bwd_kernel(
     const T *__restrict__ image, const T *__restrict__ flow, const T *__restrict__ gout,
     T *__restrict__ gimage, T *__restrict__ gflow, int *__restrict__ extent_ws,
@@ -223,20 +249,18 @@ __global__ __launch_bounds__(kPix * kCg) void warp_bwd_kernel(
                 const int cc = c + u * kCg;
                 const bool on = cc < C;
                 const int64_t q = base + (on ? cc : c) * plane + o00;
-                g[u] = on ? ld(gout + base + cc * plane + p) : A(0);
-                gmax = fmaxf(gmax, fabsf(static_cast<float>(g[u])));
+                g[u] = ld(tap_ptr(gout + base + (on ? cc : c) * plane + p, on));
                 vnw[u] = vne[u] = vsw[u] = vse[u] = A(0);
-                if (gflow) {
-                    if (oky0 && okx0) vnw[u] = ld(image + q);
-                    if (oky0 && okx1) vne[u] = ld(image + q + 1);
-                    if (oky1 && okx0) vsw[u] = ld(image + q + W);
-                    if (oky1 && okx1) vse[u] = ld(image + q + W + 1);
+                if (gflow) {  // kernel-uniform
+                    load_taps<PAIR, T, A>(image + q, oky0 && okx0, oky0 && okx1, vnw[u], vne[u]);
+                    load_taps<PAIR, T, A>(image + q + W, oky1 && okx0, oky1 && okx1, vsw[u], vse[u]);
                 }
             }
 #pragma unroll
             for (int u = 0; u < kU; ++u) {
                 const int cc = c + u * kCg;
                 if (cc >= C) break;
+                gmax = fmaxf(gmax, fabsf(static_cast<float>(g[u])));
                 if (gimage) {
                     const int64_t q = base + cc * plane + o00;
                     if (oky0 && okx0) atomic_accumulate(gimage + q, wnw * g[u]);
@@ -403,10 +427,17 @@ int warp_forward(const void *image, const void *flow, void *out, int B, int C, i
     const int64_t plane = static_cast<int64_t>(H) * W;
     if (B == 0) return CERB_OK;
     const dim3 grid(static_cast<unsigned>((plane + kPix - 1) / kPix), B);
-    CERB_DISPATCH(dtype, hipLaunchKernelGGL(warp_fwd_kernel<T>, grid, dim3(kPix * kCg), 0, s,
-                                            static_cast<const T *>(image),
-                                            static_cast<const T *>(flow), static_cast<T *>(out), C,
-                                            H, W, pad_mode, interp));
+    if (option_value("warp_pair_taps") != 2) {  // default: paired taps in the forward gather
+        CERB_DISPATCH(dtype, hipLaunchKernelGGL((warp_fwd_kernel<T, true>), grid, dim3(kPix * kCg), 0,
+                                                s, static_cast<const T *>(image),
+                                                static_cast<const T *>(flow), static_cast<T *>(out),
+                                                C, H, W, pad_mode, interp));
+    } else {
+        CERB_DISPATCH(dtype, hipLaunchKernelGGL((warp_fwd_kernel<T, false>), grid, dim3(kPix * kCg), 0,
+                                                s, static_cast<const T *>(image),
+                                                static_cast<const T *>(flow), static_cast<T *>(out),
+                                                C, H, W, pad_mode, interp));
+    }
     return launch_status();
 }
 
@@ -433,11 +464,19 @@ int warp_backward(const void *image, const void *flow, const void *gout, void *g
         hipError_t e = hipMemsetAsync(ws, 0, 4 * sizeof(int), s);
         if (e != hipSuccess) return static_cast<int>(e);
         // 1. grad_flow (deterministic gather) + tap-extent reduction
-        hipLaunchKernelGGL(warp_bwd_kernel<float>, grid, dim3(kPix * kCg), 0, s,
-                           static_cast<const float *>(image), static_cast<const float *>(flow),
-                           static_cast<const float *>(gout), static_cast<float *>(nullptr),
-                           static_cast<float *>(gflow), ws, static_cast<const int *>(nullptr), C, H,
-                           W, pad_mode);
+        if (option_value("warp_pair_taps") == 1) {
+            hipLaunchKernelGGL((warp_bwd_kernel<float, true>), grid, dim3(kPix * kCg), 0, s,
+                               static_cast<const float *>(image), static_cast<const float *>(flow),
+                               static_cast<const float *>(gout), static_cast<float *>(nullptr),
+                               static_cast<float *>(gflow), ws, static_cast<const int *>(nullptr),
+                               C, H, W, pad_mode);
+        } else {
+            hipLaunchKernelGGL((warp_bwd_kernel<float, false>), grid, dim3(kPix * kCg), 0, s,
+                               static_cast<const float *>(image), static_cast<const float *>(flow),
+                               static_cast<const float *>(gout), static_cast<float *>(nullptr),
+                               static_cast<float *>(gflow), ws, static_cast<const int *>(nullptr),
+                               C, H, W, pad_mode);
+        }
         int rc = launch_status();
         if (rc) return rc;
         // 2. grad_image tiles (zero-fills instead when the extent exceeds its window)
@@ -453,7 +492,7 @@ int warp_backward(const void *image, const void *flow, const void *gout, void *g
         rc = launch_status();
         if (rc) return rc;
         // 3. scatter fallback, gated on the device: returns at once unless the extent was too large
-        hipLaunchKernelGGL(warp_bwd_kernel<float>, grid, dim3(kPix * kCg), 0, s,
+        hipLaunchKernelGGL((warp_bwd_kernel<float, false>), grid, dim3(kPix * kCg), 0, s,
                            static_cast<const float *>(image), static_cast<const float *>(flow),
                            static_cast<const float *>(gout), static_cast<float *>(gimage),
                            static_cast<float *>(nullptr), static_cast<int *>(nullptr), ws, C, H, W,
@@ -464,7 +503,7 @@ int warp_backward(const void *image, const void *flow, const void *gout, void *g
         hipError_t e = hipMemsetAsync(gimage, 0, static_cast<size_t>(B) * C * plane * esz, s);
         if (e != hipSuccess) return static_cast<int>(e);
     }
-    CERB_DISPATCH(dtype, hipLaunchKernelGGL(warp_bwd_kernel<T>, grid, dim3(kPix * kCg), 0, s,
+    CERB_DISPATCH(dtype, hipLaunchKernelGGL((warp_bwd_kernel<T, false>), grid, dim3(kPix * kCg), 0, s,
                                             static_cast<const T *>(image),
                                             static_cast<const T *>(flow),
                                             static_cast<const T *>(gout), static_cast<T *>(gimage),

@@ -138,6 +138,7 @@ int cerberus_flow_warp_backward(const void *image, const void *flow,
  *   "corr_force_generic" : 1 = always use the generic kernels (testing)
  *   "corr_fwd_variant"   : 0 = auto, 1..8 = force one tuned forward variant
  *   "corr_bwd_cslice"    : 0 = auto, else channels per backward workgroup
+ *   "warp_pair_taps"     : warp gather variant (0 default, 1 paired everywhere, 2 unpaired)
  * Returns CERB_EINVAL for an unknown key. */
 int cerberus_set_option(const char *key, int value);
 int cerberus_get_option(const char *key, int *value);
