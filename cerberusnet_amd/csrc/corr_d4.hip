@@ -413,16 +413,17 @@ __global__ __launch_bounds__(K::THREADS, K::WPS) void corr_fwd_d4_kernel(
 // RS is the halo row stride: TW+8 for TSXP=32 (each 32-lane half of a
 // ds_read_b64 is one row = 64 consecutive dwords), 96 for TSXP=16 (rows r,r+1
 // of a half must differ by 32 banks).
-template <int TSXP_, int CC_, int RS_>
+template <int TSXP_, int CC_, int RS_, int NW_ = 4>
 struct BwdCfg {
     static constexpr int TSXP = TSXP_, CC = CC_, RS = RS_;
     static constexpr int TW = 2 * TSXP;
     static constexpr int RPW = 64 / TSXP;      // rows per wavefront
-    static constexpr int TH = 4 * RPW;         // 4 wavefronts
+    static constexpr int NW = NW_;             // wavefronts per workgroup (stacked vertically)
+    static constexpr int TH = NW * RPW;
     static constexpr int HR = TH + 2 * kD;
     static constexpr int HW4 = (TW + 2 * kD) / 4;
     static constexpr int PS = HR * RS;
-    static constexpr int THREADS = 256;
+    static constexpr int THREADS = 64 * NW;
     static constexpr int N = CC * HR * HW4;
     static constexpr int NSLOT = (N + THREADS - 1) / THREADS;
     static constexpr int BUF = CC * PS;
@@ -437,7 +438,7 @@ __device__ __forceinline__ float2 ld2u(const float *p) {
 }
 
 template <typename K, typename T, bool VEC>
-__global__ __launch_bounds__(256, 2) void corr_bwd_d4_kernel(
+__global__ __launch_bounds__(K::THREADS, 2) void corr_bwd_d4_kernel(
     const T *__restrict__ x1, const T *__restrict__ x2, const T *__restrict__ gout,
     T *__restrict__ gin1, T *__restrict__ gin2, int C, int H, int W, int tiles_x,
     int tiles_y, int cslice, int nslice, int dbg) {
@@ -739,6 +740,9 @@ int launch_bwd(const char *name, const void *in1, const void *in2, const void *g
 }
 
 using BwdWide = BwdCfg<32, 2, 72>;    // 8x64 tile
+// Tried and rejected on MI355X (level 3 / level 2, 4 pairs): 16x64 tiles with 8 wavefronts
+// (55.8 / 39.0 us vs 45.6 / 29.2: fewer workgroups in flight outweighs the smaller halo) and
+// 4x64 tiles with 2 wavefronts (spills; 83 / 50 us).
 using BwdNarrow = BwdCfg<16, 2, 96>;  // 16x32 tile
 
 bool fast_config(const CorrGeom &g, int dtype) {

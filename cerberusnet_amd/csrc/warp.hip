@@ -313,10 +313,14 @@ __global__ __launch_bounds__(kPix * kCg) void warp_bwd_kernel(
 // every output element written exactly once.
 // The LDS accumulators are 64-bit FIXED POINT: ds_add_f32 runs at 0.3 lanes/clk/CU on
 // gfx950 (tools/ubench/lds_atomic.hip) against 6.7 for ds_add_u64.  The scale is
-// 2^(40 - exponent(max|gradOutput|)), measured on the device by the grad_flow pass:
-// every product w*g <= max|g| keeps >= 40 fractional bits below the largest value and
-// 2^22 of them can meet in one pixel without overflow.  Integer addition commutes, so
+// 2^(30 - exponent(max|gradOutput|)), measured on the device by the grad_flow pass:
+// every product w*g <= max|g| is an int32 with a resolution of 2^-30 of the largest
+// gradient (fp32 itself resolves 2^-24), and 2^33 of them can meet in one pixel.  Integer addition commutes, so
 // the result is bit-reproducible (ATen's and our scatter fallback's are not).
+__device__ __forceinline__ unsigned long long fixed64(float scaled) {
+    return static_cast<unsigned long long>(static_cast<long long>(__float2int_rn(scaled)));
+}
+
 template <int TH, int TW, int CW>
 __global__ __launch_bounds__(256) void warp_gimage_tile_kernel(
     const float *__restrict__ flow, const float *__restrict__ gout, float *__restrict__ gimage,
@@ -337,8 +341,11 @@ __global__ __launch_bounds__(256) void warp_gimage_tile_kernel(
     const float gabs = __int_as_float(ws[2]);
     int gexp = 0;
     frexpf(gabs, &gexp);                         // gabs < 2^gexp
-    const float scale = ldexpf(1.0f, 40 - gexp);  // products land below 2^40
-    const float unscale = ldexpf(1.0f, gexp - 40);
+    // products land below 2^30: one v_cvt_i32_f32 per contribution (a 64-bit float->int
+    // conversion is a 12-instruction sequence), sign-extended into the 64-bit accumulator,
+    // which leaves 2^33 of headroom for taps piling up on one pixel
+    const float scale = ldexpf(1.0f, 30 - gexp);
+    const float unscale = ldexpf(1.0f, gexp - 30);
 
     for (int i = tid; i < CW * TH * TW; i += 256) acc[i] = 0;
     __syncthreads();
@@ -385,10 +392,10 @@ __global__ __launch_bounds__(256) void warp_gimage_tile_kernel(
                 unsigned long long *a =
                     reinterpret_cast<unsigned long long *>(acc) + c * (TH * TW) + o;
                 // two's-complement add: negative contributions wrap correctly
-                atomicAdd(v00 ? a : dummy, static_cast<unsigned long long>(__float2ll_rn(w00 * g[c])));
-                atomicAdd(v01 ? a + 1 : dummy, static_cast<unsigned long long>(__float2ll_rn(w01 * g[c])));
-                atomicAdd(v10 ? a + TW : dummy, static_cast<unsigned long long>(__float2ll_rn(w10 * g[c])));
-                atomicAdd(v11 ? a + TW + 1 : dummy, static_cast<unsigned long long>(__float2ll_rn(w11 * g[c])));
+                atomicAdd(v00 ? a : dummy, fixed64(w00 * g[c]));
+                atomicAdd(v01 ? a + 1 : dummy, fixed64(w01 * g[c]));
+                atomicAdd(v10 ? a + TW : dummy, fixed64(w10 * g[c]));
+                atomicAdd(v11 ? a + TW + 1 : dummy, fixed64(w11 * g[c]));
             }
         }
         __syncthreads();
