@@ -25,7 +25,7 @@
 namespace cerb {
 namespace {
 
-constexpr int kCg = 4;           // channel groups (waves) per workgroup
+constexpr int kCgMax = 16;       // channel groups (waves) per workgroup: 4, or 16 for >= 128 channels
 constexpr int kPix = 64;         // pixels per workgroup = one wavefront
 constexpr int kMaxExtent = 16;   // largest tap distance the tiled grad_image kernel scans for
 
@@ -92,7 +92,7 @@ __device__ __forceinline__ void load_taps(const T *q, bool ok0, bool ok1, A &v0,
     }
 }
 
-template <typename T, bool PAIR>
+template <typename T, bool PAIR, int kCg>
 __global__ __launch_bounds__(kPix * kCg) void warp_fwd_kernel(
     const T *__restrict__ image, const T *__restrict__ flow, T *__restrict__ out, int C, int H,
     int W, int pad_mode, int interp) {
@@ -199,7 +199,7 @@ __device__ __forceinline__ void publish_max(int *ws, int v) {
     if (v > *reinterpret_cast<volatile int *>(ws)) atomicMax(ws, v);
 }
 
-template <typename T, bool PAIR>
+template <typename T, bool PAIR, int kCg>
 __global__ __launch_bounds__(kPix * kCg) void warp_bwd_kernel(
     const T *__restrict__ image, const T *__restrict__ flow, const T *__restrict__ gout,
     T *__restrict__ gimage, T *__restrict__ gflow, int *__restrict__ extent_ws,
@@ -429,21 +429,27 @@ size_t dtype_size(int dtype) {
         default: return CERB_EDTYPE;                                \
     }
 
+// channel groups per workgroup: keep ~8 channels (two 4-channel trips) per lane so that the
+// per-lane chain of dependent gather round trips stays short on the wide, small levels
+#define CERB_PICK_CG(C, ...)                                   \
+    if ((C) >= 128) { constexpr int CG = 16; __VA_ARGS__; }    \
+    else { constexpr int CG = 4; __VA_ARGS__; }
+
 int warp_forward(const void *image, const void *flow, void *out, int B, int C, int H, int W,
                  int pad_mode, int interp, int dtype, hipStream_t s) {
     const int64_t plane = static_cast<int64_t>(H) * W;
     if (B == 0) return CERB_OK;
     const dim3 grid(static_cast<unsigned>((plane + kPix - 1) / kPix), B);
     if (option_value("warp_pair_taps") != 2) {  // default: paired taps in the forward gather
-        CERB_DISPATCH(dtype, hipLaunchKernelGGL((warp_fwd_kernel<T, true>), grid, dim3(kPix * kCg), 0,
-                                                s, static_cast<const T *>(image),
-                                                static_cast<const T *>(flow), static_cast<T *>(out),
-                                                C, H, W, pad_mode, interp));
+        CERB_PICK_CG(C, CERB_DISPATCH(dtype, hipLaunchKernelGGL(
+            (warp_fwd_kernel<T, true, CG>), grid, dim3(kPix * CG), 0, s,
+            static_cast<const T *>(image), static_cast<const T *>(flow), static_cast<T *>(out), C, H,
+            W, pad_mode, interp)))
     } else {
-        CERB_DISPATCH(dtype, hipLaunchKernelGGL((warp_fwd_kernel<T, false>), grid, dim3(kPix * kCg), 0,
-                                                s, static_cast<const T *>(image),
-                                                static_cast<const T *>(flow), static_cast<T *>(out),
-                                                C, H, W, pad_mode, interp));
+        CERB_PICK_CG(C, CERB_DISPATCH(dtype, hipLaunchKernelGGL(
+            (warp_fwd_kernel<T, false, CG>), grid, dim3(kPix * CG), 0, s,
+            static_cast<const T *>(image), static_cast<const T *>(flow), static_cast<T *>(out), C, H,
+            W, pad_mode, interp)))
     }
     return launch_status();
 }
@@ -472,17 +478,19 @@ int warp_backward(const void *image, const void *flow, const void *gout, void *g
         if (e != hipSuccess) return static_cast<int>(e);
         // 1. grad_flow (deterministic gather) + tap-extent reduction
         if (option_value("warp_pair_taps") == 1) {
-            hipLaunchKernelGGL((warp_bwd_kernel<float, true>), grid, dim3(kPix * kCg), 0, s,
-                               static_cast<const float *>(image), static_cast<const float *>(flow),
-                               static_cast<const float *>(gout), static_cast<float *>(nullptr),
-                               static_cast<float *>(gflow), ws, static_cast<const int *>(nullptr),
-                               C, H, W, pad_mode);
+            CERB_PICK_CG(C, hipLaunchKernelGGL(
+                (warp_bwd_kernel<float, true, CG>), grid, dim3(kPix * CG), 0, s,
+                static_cast<const float *>(image), static_cast<const float *>(flow),
+                static_cast<const float *>(gout), static_cast<float *>(nullptr),
+                static_cast<float *>(gflow), ws, static_cast<const int *>(nullptr), C, H, W,
+                pad_mode))
         } else {
-            hipLaunchKernelGGL((warp_bwd_kernel<float, false>), grid, dim3(kPix * kCg), 0, s,
-                               static_cast<const float *>(image), static_cast<const float *>(flow),
-                               static_cast<const float *>(gout), static_cast<float *>(nullptr),
-                               static_cast<float *>(gflow), ws, static_cast<const int *>(nullptr),
-                               C, H, W, pad_mode);
+            CERB_PICK_CG(C, hipLaunchKernelGGL(
+                (warp_bwd_kernel<float, false, CG>), grid, dim3(kPix * CG), 0, s,
+                static_cast<const float *>(image), static_cast<const float *>(flow),
+                static_cast<const float *>(gout), static_cast<float *>(nullptr),
+                static_cast<float *>(gflow), ws, static_cast<const int *>(nullptr), C, H, W,
+                pad_mode))
         }
         int rc = launch_status();
         if (rc) return rc;
@@ -499,7 +507,7 @@ int warp_backward(const void *image, const void *flow, const void *gout, void *g
         rc = launch_status();
         if (rc) return rc;
         // 3. scatter fallback, gated on the device: returns at once unless the extent was too large
-        hipLaunchKernelGGL((warp_bwd_kernel<float, false>), grid, dim3(kPix * kCg), 0, s,
+        hipLaunchKernelGGL((warp_bwd_kernel<float, false, 4>), grid, dim3(kPix * 4), 0, s,
                            static_cast<const float *>(image), static_cast<const float *>(flow),
                            static_cast<const float *>(gout), static_cast<float *>(gimage),
                            static_cast<float *>(nullptr), static_cast<int *>(nullptr), ws, C, H, W,
@@ -510,7 +518,7 @@ int warp_backward(const void *image, const void *flow, const void *gout, void *g
         hipError_t e = hipMemsetAsync(gimage, 0, static_cast<size_t>(B) * C * plane * esz, s);
         if (e != hipSuccess) return static_cast<int>(e);
     }
-    CERB_DISPATCH(dtype, hipLaunchKernelGGL((warp_bwd_kernel<T, false>), grid, dim3(kPix * kCg), 0, s,
+    CERB_DISPATCH(dtype, hipLaunchKernelGGL((warp_bwd_kernel<T, false, 4>), grid, dim3(kPix * 4), 0, s,
                                             static_cast<const T *>(image),
                                             static_cast<const T *>(flow),
                                             static_cast<const T *>(gout), static_cast<T *>(gimage),
