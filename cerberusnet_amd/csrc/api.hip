@@ -13,7 +13,8 @@ Option g_options[] = {{"corr_force_generic", {0}},   // 1: always use the generi
                       {"corr_fwd_variant", {0}},     // 0: auto, 1..6: force a tuned forward variant
                       {"corr_bwd_cslice", {0}},      // 0: auto, else channels per backward workgroup
                       {"corr_debug_ablate", {0}},    // timing ablation mask (WRONG results when != 0)
-                      {"warp_pair_taps", {0}}};      // 0: default, 1: pairs everywhere, 2: none
+                      {"warp_pair_taps", {0}},       // 0: default, 1: pairs everywhere, 2: none
+                      {"corr_bwd_variant", {0}}};    // 0: auto, 1: all-81 per lane, 2/3: 3 dy groups
 thread_local const char *t_last_kernel[2] = {"none", "none"};
 
 Option *find_option(const char *key) {

@@ -641,6 +641,213 @@ __global__ __launch_bounds__(K::THREADS, 2) void corr_bwd_d4_kernel(
     }
 }
 
+// ============================================================================
+// backward, displacement-group variant
+// ============================================================================
+// Same arithmetic as corr_bwd_d4_kernel, different ownership: a workgroup is 3 vertical
+// displacement groups (dy in {-4..-2}, {-1..1}, {2..4}) x NSW spatial wavefronts.  A lane
+// keeps only the 27 gradOutput values of its group (54 registers instead of 162), so the
+// kernel fits ~100 VGPRs instead of ~250: 2-3x the wavefronts in flight, a 3x shorter
+// gather per lane, and the three partial sums of a pixel meet in LDS once per channel chunk.
+template <int TSXP_, int CC_, int RS_, int NSW_>
+struct BwdG3Cfg {
+    static constexpr int TSXP = TSXP_, CC = CC_, RS = RS_, NSW = NSW_;
+    static constexpr int TW = 2 * TSXP;
+    static constexpr int RPW = 64 / TSXP;
+    static constexpr int TH = NSW * RPW;
+    static constexpr int HR = TH + 2 * kD;
+    static constexpr int HW4 = (TW + 2 * kD) / 4;
+    static constexpr int PS = HR * RS;
+    static constexpr int THREADS = 3 * NSW * 64;
+    static constexpr int N = CC * HR * HW4;
+    static constexpr int NSLOT = (N + THREADS - 1) / THREADS;
+    static constexpr int BUF = CC * PS;                    // floats per window buffer
+    static constexpr int PART = CC * 3 * NSW * 64 * 2;     // floats per partial-sum buffer
+    static constexpr size_t LDS_BYTES = sizeof(float) * (2 * BUF + 2 * PART);
+};
+
+template <typename K, typename T, bool VEC>
+__global__ __launch_bounds__(K::THREADS, 3) void corr_bwd_d4_g3_kernel(
+    const T *__restrict__ x1, const T *__restrict__ x2, const T *__restrict__ gout,
+    T *__restrict__ gin1, T *__restrict__ gin2, int C, int H, int W, int tiles_x,
+    int tiles_y, int cslice, int nslice) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int CC = K::CC, NSW = K::NSW;
+    float *part_base = smem + 2 * K::BUF;
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int grp = wave / NSW;          // displacement group: dyi in [3*grp, 3*grp+2]
+    const int sw = wave % NSW;           // spatial wavefront
+    const int r = sw * K::RPW + lane / K::TSXP;
+    const int sxp = lane % K::TSXP;
+    const int slot_lane = sw * 64 + lane;  // index of this lane's pixel pair inside the tile
+
+    int bid = xcd_swizzle(blockIdx.x, gridDim.x);
+    const int side = bid & 1; bid >>= 1;
+    const int slice = bid % nslice; bid /= nslice;
+    const int tx = bid % tiles_x; bid /= tiles_x;
+    const int ty = bid % tiles_y;
+    const int b = bid / tiles_y;
+    const int x0 = tx * K::TW, y0 = ty * K::TH;
+    const int c_begin = slice * cslice;
+    const int c_end = min(C, c_begin + cslice);
+    const int plane = H * W;
+
+    const T *src = (side == 0 ? x2 : x1) + static_cast<int64_t>(b) * C * plane;
+    T *dstb = (side == 0 ? gin1 : gin2) + static_cast<int64_t>(b) * C * plane;
+    const T *gob = gout + static_cast<int64_t>(b) * (kND * kND) * plane;
+
+    const int y = y0 + r, x = x0 + 2 * sxp;
+    const bool live = y < H && x < W;
+
+    // ---- staging descriptors (whole workgroup stages the window) ----
+    int goff[K::NSLOT], loff[K::NSLOT], gx0[K::NSLOT], chi[K::NSLOT];
+#pragma unroll
+    for (int j = 0; j < K::NSLOT; ++j) {
+        const int id = tid + j * K::THREADS;
+        goff[j] = -1; loff[j] = -1; gx0[j] = 0; chi[j] = 0;
+        if (id < K::N) {
+            const int pl = id / (K::HR * K::HW4);
+            const int rem = id % (K::HR * K::HW4);
+            const int row = rem / K::HW4, c4 = rem % K::HW4;
+            const int gy = y0 - kD + row, gx = x0 - kD + 4 * c4;
+            loff[j] = pl * K::PS + row * K::RS + 4 * c4;
+            gx0[j] = gx; chi[j] = pl;
+            const bool in = gy >= 0 && gy < H && (VEC ? (gx >= 0 && gx < W) : (gx > -4 && gx < W));
+            if (in) goff[j] = pl * plane + gy * W + gx + 4;
+        }
+    }
+    float4 stage[K::NSLOT];
+    auto prefetch = [&](int c_first) {
+#pragma unroll
+        for (int j = 0; j < K::NSLOT; ++j) {
+            const bool on = goff[j] >= 0 && c_first + chi[j] < c_end;
+            if (VEC) {
+                const T *p = on ? src + static_cast<int64_t>(c_first) * plane + (goff[j] - 4)
+                                : reinterpret_cast<const T *>(g_zero16);
+                stage[j] = Gmem<T>::load4(p);
+            } else {
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (on) {
+                    const T *p = src + static_cast<int64_t>(c_first) * plane + (goff[j] - 4);
+                    const int gx = gx0[j];
+                    if (gx >= 0 && gx < W) v.x = Gmem<T>::load1(p);
+                    if (gx + 1 >= 0 && gx + 1 < W) v.y = Gmem<T>::load1(p + 1);
+                    if (gx + 2 >= 0 && gx + 2 < W) v.z = Gmem<T>::load1(p + 2);
+                    if (gx + 3 >= 0 && gx + 3 < W) v.w = Gmem<T>::load1(p + 3);
+                }
+                stage[j] = v;
+            }
+        }
+    };
+    auto commit = [&](float *buf) {
+#pragma unroll
+        for (int j = 0; j < K::NSLOT; ++j)
+            if (loff[j] >= 0) st4(buf + loff[j], stage[j]);
+    };
+
+    prefetch(c_begin);
+
+    // ---- this group's 27 gradOutput values per pixel (branch-free, see corr_bwd_d4_kernel) ----
+    float2v g0p[3][4], g1p[3][4];
+    float g0s[3], g1s[3];
+    {
+        const int lane_off = live ? y * W + x : 0;
+        unsigned ymask = 0, xmask0 = 0, xmask1 = 0;
+#pragma unroll
+        for (int k = 0; k < kND; ++k) {
+            const int yy = y + k - kD, xx = x + k - kD;
+            if (yy >= 0 && yy < H) ymask |= 1u << k;
+            if (xx >= 0 && xx < W) xmask0 |= 1u << k;
+            if (xx + 1 >= 0 && xx + 1 < W) xmask1 |= 1u << k;
+        }
+        if (!live) ymask = 0;
+        const bool pair_ok = live && (VEC || x + 1 < W);
+        const T *zero = reinterpret_cast<const T *>(g_zero16);
+#pragma unroll
+        for (int dl = 0; dl < 3; ++dl) {
+            const int dyi = 3 * grp + dl;  // wave-uniform
+#pragma unroll
+            for (int dxi = 0; dxi < kND; ++dxi) {
+                const int d = dyi * kND + dxi;
+                float v0, v1;
+                if (side == 0) {
+                    const T *pd = gob + static_cast<int64_t>(d) * plane;
+                    if (VEC) {
+                        const float2 t = Gmem<T>::load2(pd + lane_off);
+                        v0 = t.x; v1 = t.y;
+                    } else {
+                        v0 = Gmem<T>::load1(pd + lane_off);
+                        v1 = Gmem<T>::load1(pd + (pair_ok ? lane_off + 1 : lane_off));
+                    }
+                } else {
+                    const int uni = (kND * kND - 1 - d) * plane + (dyi - kD) * W + (dxi - kD);
+                    const bool oky = (ymask >> dyi) & 1u;
+                    const bool ok0 = oky && ((xmask0 >> dxi) & 1u);
+                    const bool ok1 = oky && ((xmask1 >> dxi) & 1u);
+                    v0 = Gmem<T>::load1(ok0 ? gob + (uni + lane_off) : zero);
+                    v1 = Gmem<T>::load1(ok1 ? gob + (uni + lane_off + 1) : zero);
+                }
+                if (dxi == 8) g0s[dl] = v0; else if (dxi & 1) g0p[dl][dxi / 2].y = v0; else g0p[dl][dxi / 2].x = v0;
+                if (dxi == 0) g1s[dl] = v1; else if (dxi & 1) g1p[dl][(dxi - 1) / 2].x = v1; else g1p[dl][(dxi - 1) / 2].y = v1;
+            }
+        }
+    }
+
+    const float inv_nelems = 1.0f / static_cast<float>(C);
+    int it = 0;
+    for (int c0 = c_begin; c0 < c_end; c0 += CC, ++it) {
+        float *buf = smem + (it & 1) * K::BUF;
+        float *part = part_base + (it & 1) * K::PART;
+        commit(buf);
+        __syncthreads();
+        prefetch(c0 + CC);
+        const float *wbase = buf + (r + 3 * grp) * K::RS + 2 * sxp;
+#pragma unroll
+        for (int i = 0; i < CC; ++i) {
+            const float *wp = wbase + i * K::PS;
+            float2v a0 = float2v{0.f, 0.f}, a1 = float2v{0.f, 0.f};
+            float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+            for (int dl = 0; dl < 3; ++dl) {
+                float2v w[5];
+#pragma unroll
+                for (int q = 0; q < 5; ++q) w[q] = ld2v_nomerge(wp + dl * K::RS + 2 * q);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    a0 = pkfma(g0p[dl][j], w[j], a0);
+                    a1 = pkfma(g1p[dl][j], w[j + 1], a1);
+                }
+                s0 = fmaf(g0s[dl], w[4].x, s0);
+                s1 = fmaf(g1s[dl], w[0].y, s1);
+            }
+            // partial sums of this displacement group -> LDS
+            *reinterpret_cast<float2v *>(part + ((i * 3 + grp) * (NSW * 64) + slot_lane) * 2) =
+                float2v{a0.x + a0.y + s0, a1.x + a1.y + s1};
+        }
+        __syncthreads();
+        // group g finishes channels g, g+3, ... of the chunk: add the three partials, store
+#pragma unroll
+        for (int i = 0; i < CC; ++i) {
+            if (i % 3 != grp) continue;   // wave-uniform
+            const float *pp = part + (i * 3 * (NSW * 64) + slot_lane) * 2;
+            const float2v p0 = *reinterpret_cast<const float2v *>(pp);
+            const float2v p1 = *reinterpret_cast<const float2v *>(pp + NSW * 64 * 2);
+            const float2v p2 = *reinterpret_cast<const float2v *>(pp + 2 * NSW * 64 * 2);
+            const float r0 = (p0.x + p1.x + p2.x) * inv_nelems, r1 = (p0.y + p1.y + p2.y) * inv_nelems;
+            if (live && c0 + i < c_end) {
+                T *dst = dstb + static_cast<int64_t>(c0 + i) * plane + y * W + x;
+                if (VEC) {
+                    Gmem<T>::store2(dst, r0, r1);
+                } else {
+                    Gmem<T>::store1(dst, r0);
+                    if (x + 1 < W) Gmem<T>::store1(dst + 1, r1);
+                }
+            }
+        }
+    }
+}
+
 // ---- host side -------------------------------------------------------------
 // LDS above 64 KiB needs an explicit opt-in, once per kernel (flag owned by the call site)
 template <typename Kern>
@@ -739,6 +946,43 @@ int launch_bwd(const char *name, const void *in1, const void *in2, const void *g
     return launch_status();
 }
 
+template <typename K, typename T>
+int launch_bwd_g3(const char *name, const void *in1, const void *in2, const void *goutp, void *g1p,
+                  void *g2p, const CorrGeom &g, bool vec, hipStream_t s) {
+    const T *x1 = static_cast<const T *>(in1), *x2 = static_cast<const T *>(in2);
+    const T *gout = static_cast<const T *>(goutp);
+    T *gin1 = static_cast<T *>(g1p), *gin2 = static_cast<T *>(g2p);
+    const int tiles_x = (g.W + K::TW - 1) / K::TW, tiles_y = (g.H + K::TH - 1) / K::TH;
+    const int64_t tiles = static_cast<int64_t>(g.B) * tiles_x * tiles_y;
+    int cslice = g.C;
+    while (cslice > 16 && tiles * 2 * ((g.C + cslice - 1) / cslice) < 256) cslice /= 2;
+    if (const int forced = option_value("corr_bwd_cslice")) cslice = forced;
+    cslice = ((cslice + K::CC - 1) / K::CC) * K::CC;
+    const int nslice = (g.C + cslice - 1) / cslice;
+    if (tiles * nslice * 2 > 0x7fffffff) return CERB_ETOOLARGE;
+    const dim3 grid(static_cast<unsigned>(tiles * nslice * 2));
+    int rc;
+    static bool lds_v = false, lds_s = false;
+    if (vec) {
+        note_kernel(1, name);
+        if ((rc = ensure_lds(corr_bwd_d4_g3_kernel<K, T, true>, K::LDS_BYTES, &lds_v))) return rc;
+        hipLaunchKernelGGL((corr_bwd_d4_g3_kernel<K, T, true>), grid, dim3(K::THREADS),
+                           K::LDS_BYTES, s, x1, x2, gout, gin1, gin2, g.C, g.H, g.W, tiles_x,
+                           tiles_y, cslice, nslice);
+    } else if constexpr (sizeof(T) == 4) {
+        note_kernel(1, name);
+        if ((rc = ensure_lds(corr_bwd_d4_g3_kernel<K, T, false>, K::LDS_BYTES, &lds_s))) return rc;
+        hipLaunchKernelGGL((corr_bwd_d4_g3_kernel<K, T, false>), grid, dim3(K::THREADS),
+                           K::LDS_BYTES, s, x1, x2, gout, gin1, gin2, g.C, g.H, g.W, tiles_x,
+                           tiles_y, cslice, nslice);
+    } else {
+        return CERB_EUNSUPPORTED;
+    }
+    return launch_status();
+}
+
+using BwdG3Wide = BwdG3Cfg<32, 4, 72, 2>;    // 4x64 tile, 6 wavefronts
+using BwdG3Wide4 = BwdG3Cfg<32, 2, 72, 4>;   // 8x64 tile, 12 wavefronts
 using BwdWide = BwdCfg<32, 2, 72>;    // 8x64 tile
 // Tried and rejected on MI355X (level 3 / level 2, 4 pairs): 16x64 tiles with 8 wavefronts
 // (55.8 / 39.0 us vs 45.6 / 29.2: fewer workgroups in flight outweighs the smaller halo) and
@@ -790,6 +1034,17 @@ int bwd_dispatch(const void *x1, const void *x2, const void *go, void *g1, void 
                  const CorrGeom &g, bool vec, hipStream_t s) {
     if (g.W <= 32)
         return launch_bwd<BwdNarrow, T>("corr_bwd_d4_16x32", x1, x2, go, g1, g2, g, vec, s);
+    switch (option_value("corr_bwd_variant")) {
+        case 1: return launch_bwd<BwdWide, T>("corr_bwd_d4_8x64", x1, x2, go, g1, g2, g, vec, s);
+        case 2: return launch_bwd_g3<BwdG3Wide, T>("corr_bwd_d4_g3_4x64", x1, x2, go, g1, g2, g, vec, s);
+        case 3: return launch_bwd_g3<BwdG3Wide4, T>("corr_bwd_d4_g3_8x64", x1, x2, go, g1, g2, g, vec, s);
+        default: break;
+    }
+    // few tiles (coarse level): the displacement-group kernel puts 3x the wavefronts on the
+    // problem (measured 18 vs 21 us on the 128x32x64 level); larger maps prefer all-81
+    const int64_t tiles = static_cast<int64_t>(g.B) * ((g.W + 63) / 64) * ((g.H + 7) / 8);
+    if (tiles <= 32 && g.C >= 16)
+        return launch_bwd_g3<BwdG3Wide4, T>("corr_bwd_d4_g3_8x64", x1, x2, go, g1, g2, g, vec, s);
     return launch_bwd<BwdWide, T>("corr_bwd_d4_8x64", x1, x2, go, g1, g2, g, vec, s);
 }
 

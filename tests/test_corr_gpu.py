@@ -308,20 +308,23 @@ def test_every_tuned_forward_variant(variant, shape):
     assert rel_err(out, ref) < TOL
 
 
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
 @pytest.mark.parametrize("cslice", [0, 2, 4, 8, 1000])
 @pytest.mark.parametrize("shape", [(2, 12, 13, 72), (1, 10, 20, 32), (1, 7, 18, 33),
                                    (1, 16, 40, 28), (2, 5, 9, 130)])
-def test_tuned_backward_tiles_and_channel_slices(cslice, shape):
+def test_tuned_backward_tiles_and_channel_slices(variant, cslice, shape):
     B, C, H, W = shape
     x1, x2 = hash_uniform(shape, 43), hash_uniform(shape, 44)
     go = hash_uniform((B, 81, H, W), 45)
     r1, r2 = oracle.corr_backward_ref(x1, x2, go, 4, 1, 4, 1, 1)
     _lib.set_option("corr_bwd_cslice", cslice)
+    _lib.set_option("corr_bwd_variant", variant)
     try:
         g1, g2 = run_bwd(x1, x2, go, (4, 1, 4, 1, 1))
         name = _lib.last_kernel(1)
     finally:
         _lib.set_option("corr_bwd_cslice", 0)
+        _lib.set_option("corr_bwd_variant", 0)
     assert name.startswith("corr_bwd_d4"), name
     assert rel_err(g1, r1) < TOL
     assert rel_err(g2, r2) < TOL
