@@ -110,8 +110,14 @@ template <> struct Gmem<float> {
     static __device__ __forceinline__ void store1(float *p, float v) { *p = v; }
     static __device__ __forceinline__ void store2(float *p, float a, float b) { *reinterpret_cast<float2 *>(p) = make_float2(a, b); }
     static __device__ __forceinline__ void store4(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
+    // streaming store (written once, not re-read by the kernel): leaves L2 to the halo lines
+    static __device__ __forceinline__ void stream2(float *p, float a, float b) {
+        typedef float f2v __attribute__((ext_vector_type(2)));
+        __builtin_nontemporal_store(f2v{a, b}, reinterpret_cast<f2v *>(p));
+    }
 };
 template <> struct Gmem<__half> {
+    static __device__ __forceinline__ void stream2(__half *p, float a, float b) { store2(p, a, b); }
     static __device__ __forceinline__ float load1(const __half *p) { return __half2float(*p); }
     static __device__ __forceinline__ float2 load2(const __half *p) { return __half22float2(*reinterpret_cast<const __half2 *>(p)); }
     static __device__ __forceinline__ float4 load4(const __half *p) {
@@ -130,6 +136,7 @@ template <> struct Gmem<__half> {
     }
 };
 template <> struct Gmem<hip_bfloat16> {
+    static __device__ __forceinline__ void stream2(hip_bfloat16 *p, float a, float b) { store2(p, a, b); }
     static __device__ __forceinline__ float widen(unsigned short b) { return __uint_as_float(static_cast<unsigned int>(b) << 16); }
     static __device__ __forceinline__ unsigned short narrow(float v) {
         const hip_bfloat16 h(v);  // round to nearest even, NaN stays NaN
@@ -395,7 +402,15 @@ __global__ __launch_bounds__(K::THREADS, K::WPS) void corr_fwd_d4_kernel(
             }
             T *dst = ob + static_cast<int64_t>(d) * plane + y * W + x;
             if (VEC) {
-                Gmem<T>::store4(dst, make_float4(v[0], v[1], v[2], v[3]));
+                if constexpr (sizeof(T) == 4) {
+                    // streamed once, never re-read by this kernel: keep it out of the way of
+                    // the x2 halo lines that neighbouring tiles want to find in L2
+                    typedef float f4v __attribute__((ext_vector_type(4)));
+                    __builtin_nontemporal_store(f4v{v[0], v[1], v[2], v[3]},
+                                                reinterpret_cast<f4v *>(dst));
+                } else {
+                    Gmem<T>::store4(dst, make_float4(v[0], v[1], v[2], v[3]));
+                }
             } else {
 #pragma unroll
                 for (int p = 0; p < kP; ++p)
@@ -631,7 +646,7 @@ __global__ __launch_bounds__(K::THREADS, 2) void corr_bwd_d4_kernel(
             if (live && c0 + i < c_end && !((dbg & 1) && (c0 + i) != c_begin)) {
                 T *dst = dstb + static_cast<int64_t>(c0 + i) * plane + y * W + x;
                 if (VEC) {
-                    Gmem<T>::store2(dst, res[i][0], res[i][1]);
+                    Gmem<T>::stream2(dst, res[i][0], res[i][1]);
                 } else {
                     Gmem<T>::store1(dst, res[i][0]);
                     if (x + 1 < W) Gmem<T>::store1(dst + 1, res[i][1]);
@@ -838,7 +853,7 @@ __global__ __launch_bounds__(K::THREADS, 3) void corr_bwd_d4_g3_kernel(
             if (live && c0 + i < c_end) {
                 T *dst = dstb + static_cast<int64_t>(c0 + i) * plane + y * W + x;
                 if (VEC) {
-                    Gmem<T>::store2(dst, r0, r1);
+                    Gmem<T>::stream2(dst, r0, r1);
                 } else {
                     Gmem<T>::store1(dst, r0);
                     if (x + 1 < W) Gmem<T>::store1(dst + 1, r1);
