@@ -25,9 +25,9 @@
 namespace cerb {
 namespace {
 
-constexpr int kCgMax = 16;       // channel groups (waves) per workgroup: 4, or 16 for >= 128 channels
 constexpr int kPix = 64;         // pixels per workgroup = one wavefront
-constexpr int kMaxExtent = 16;   // largest tap distance the tiled grad_image kernel scans for
+constexpr int kMaxExtent = 32;   // largest tap distance the tiled grad_image kernel scans for
+                                 // (16 -> 32: the scatter fallback is 5-8x slower on diverging flows)
 
 template <typename A> struct Coord {
     A pos;   // source index after unnormalise + padding
@@ -42,8 +42,12 @@ __device__ __forceinline__ Coord<A> source_coord(int pix, A flow, int size, int 
     const A t = A(2.0) * v;
     const A u = t / static_cast<A>(size - 1);
     const A g = u - A(1.0);
-    // ATen grid_sampler_unnormalize, align_corners = false
-    A p = ((g + A(1.0)) * static_cast<A>(size) - A(1.0)) / A(2.0);
+    // ATen grid_sampler_unnormalize, align_corners = false: ((g + 1) * size - 1) / 2.  Both
+    // builds of the reference runtime FUSE the multiply-subtract (nvcc fmad on the GPU, gcc
+    // -ffp-contract on the vectorised CPU kernel: verified against torch CPU, 1-ulp
+    // coordinate differences otherwise), so this one product is an explicit fma while
+    // everything around it stays uncontracted.
+    A p = fma(g + A(1.0), static_cast<A>(size), A(-1.0)) / A(2.0);
     // d(p)/d(flow) = (size/2) * (1/(size-1)) * 2, in autograd's order
     A m = static_cast<A>(size) / A(2.0);
     if (pad_mode == CERB_PAD_BORDER) {

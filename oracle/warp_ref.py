@@ -78,7 +78,10 @@ def _reflect(x, twice_low, twice_high, T):
 
 def _source_index(coord, size, pad, T):
     """unnormalise + padding; returns (index, d(index)/d(coord))."""
-    idx = ((coord + T(1)) * T(size) - T(1)) / T(2)
+    # torch's CPU (gcc -ffp-contract) and CUDA (nvcc fmad) kernels both fuse (g+1)*size-1 into
+    # one rounding; emulate the fma through float64 (exact for a 24-bit x small-integer product)
+    a = (coord + T(1)).astype(T)
+    idx = ((a.astype(np.float64) * float(size) - 1.0).astype(T) / T(2)).astype(T)
     mult = np.full(coord.shape, T(size) / T(2), dtype=T)
     if pad == "border":
         clipped = (idx <= 0) | (idx >= T(size - 1))

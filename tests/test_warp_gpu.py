@@ -125,15 +125,15 @@ def test_errors():
         ca.flow_warp(img, torch.zeros(1, 2, 8, 8, device=DEV), mode="bicubic")
 
 
-@pytest.mark.parametrize("amp", [3.0, 15.9, 40.0])
+@pytest.mark.parametrize("amp", [3.0, 15.9, 31.0, 60.0])
 @pytest.mark.parametrize("pad", ["border", "zeros"])
 def test_grad_image_tiled_and_scatter_paths(amp, pad):
-    """The owner-computes grad_image kernel covers tap extents up to 16 px; larger
+    """The owner-computes grad_image kernel covers tap extents up to 32 px; larger
     flows must fall through (on the device) to the scatter kernel.  Both against
     the torch-CPU oracle."""
-    shape = (2, 12, 40, 72)
+    shape = (2, 12, 80, 136)
     img = hash_uniform(shape, 21)
-    flo = hash_uniform((2, 2, 40, 72), 22, -amp, amp)
+    flo = hash_uniform((2, 2, 80, 136), 22, -amp, amp)
     go = hash_uniform(shape, 23)
     ref, rgi, rgf = oracle.flow_warp_grads_ref(torch.from_numpy(img), torch.from_numpy(flo),
                                                torch.from_numpy(go), pad)
