@@ -262,9 +262,11 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("CERB_FORCE_DIST") == "1":  # the latter: 1-rank RCCL self-test
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=device)  # RCCL
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)  # RCCL
 
     wl = Workload(args.pairs, args.width, args.height, device, args.flow, args.fuse_directions)
 
