@@ -10,11 +10,11 @@ namespace cerb {
 namespace {
 struct Option { const char *key; std::atomic<int> value; };
 Option g_options[] = {{"corr_force_generic", {0}},   // 1: always use the generic kernels
-                      {"corr_fwd_variant", {0}},     // 0: auto, 1..6: force a tuned forward variant
+                      {"corr_fwd_variant", {0}},     // 0: auto, 1..8: force a register-staged variant, 9: LDS-DMA
                       {"corr_bwd_cslice", {0}},      // 0: auto, else channels per backward workgroup
                       {"corr_debug_ablate", {0}},    // timing ablation mask (WRONG results when != 0)
                       {"warp_pair_taps", {0}},       // 0: default, 1: pairs everywhere, 2: none
-                      {"corr_bwd_variant", {0}}};    // 0: auto, 1: all-81 per lane, 2/3: 3 dy groups
+                      {"corr_bwd_variant", {0}}};    // 0: auto, 1: all-81 per lane, 2/3: 3 dy groups, 4: LDS-DMA
 thread_local const char *t_last_kernel[2] = {"none", "none"};
 
 Option *find_option(const char *key) {

@@ -421,6 +421,205 @@ __global__ __launch_bounds__(K::THREADS, K::WPS) void corr_fwd_d4_kernel(
 }
 
 // ============================================================================
+// forward, LDS-DMA variant (fp32, 4x64 tile, vector path only)
+// ============================================================================
+// Same tile, lane mapping and FMA loop as corr_fwd_d4_kernel<S=1,TSX=16,RB=1>, different
+// data movement: a TENTH wavefront is a dedicated loader.  It streams channel chunks into a
+// ring of NB LDS buffers with global_load_lds (LDS-DMA: no VGPR round trip, no ds_write),
+// NB-1 chunks ahead, and only ever executes {address arithmetic, DMA issue, s_waitcnt vmcnt,
+// s_barrier}; the nine compute wavefronts only execute {s_barrier, ds_read, FMA}.  hipcc
+// places a conservative vmcnt(0) before every ds_read that follows an LDS-DMA in the SAME
+// wave (see tools/ubench/glds_test.hip) -- with the roles split across waves that wait is
+// free: the compute waves have no vector-memory operation in flight.
+// LDS image of a chunk (linear in DMA slot order, 16 B per slot):
+//   x2 window: CC planes x 12 rows x 18 slots (row stride 72 floats, conflict-free with ROT=2)
+//   x1 tile  : CC planes x  4 rows x 16 slots; slot j of row r holds strip (j - 2r) mod 16, so
+//              the lane that owns that strip reads position (lane % 16): the rotation is
+//              applied to the DMA *source* address, the LDS side stays linear.
+template <int CC_, int NB_>
+struct FwdDmaCfg {
+    static constexpr int CC = CC_, NB = NB_;
+    static constexpr int TSX = 16, TH = 4, TW = 64, HR = TH + 2 * kD, HW4 = TSX + 2;
+    static constexpr int PS = HR * HW4 * 4;        // 864 floats
+    static constexpr int PS1 = TH * TSX * 4;       // 256 floats
+    static constexpr int NINST = CC * (HR / 3 + 1);       // DMA wave-instructions per chunk
+    static constexpr int BUF = CC * (PS + PS1);           // floats per ring buffer
+    static constexpr int THREADS = 64 * (kND + 1);
+    static constexpr size_t LDS_BYTES = sizeof(float) * NB * BUF;
+    static_assert(NINST * (NB - 2) <= 63, "vmcnt is 6 bits");
+    static_assert(HR % 3 == 0, "x2 window is issued as three-row groups");
+};
+
+typedef __attribute__((address_space(3))) void *lds_void_ptr;
+typedef const __attribute__((address_space(1))) void *gbl_void_ptr;
+
+#if defined(__HIP_DEVICE_COMPILE__)
+// Buffer resource over [p, p+bytes) with the pointer pinned to SGPRs (64-bit address
+// arithmetic runs on the VALU; a resource left in VGPRs costs a waterfall loop per use).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const void *p, int bytes) {
+    const uint64_t a = reinterpret_cast<uint64_t>(p);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(a));
+    const uint32_t hi = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(a >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<void *>((static_cast<uint64_t>(hi) << 32) | lo), 0,
+        __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+}
+#endif
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <typename K>
+__global__ __launch_bounds__(K::THREADS, 5) void corr_fwd_d4_dma_kernel(
+    const float *__restrict__ x1, const float *__restrict__ x2, float *__restrict__ out, int C,
+    int H, int W, int tiles_x, int tiles_y, float slope, int64_t out_bstride) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int CC = K::CC, NB = K::NB, NINST = K::NINST;
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+
+    int bid = xcd_swizzle(blockIdx.x, gridDim.x);
+    const int tx = __builtin_amdgcn_readfirstlane(bid % tiles_x); bid /= tiles_x;
+    const int ty = __builtin_amdgcn_readfirstlane(bid % tiles_y);
+    const int b = __builtin_amdgcn_readfirstlane(bid / tiles_y);
+    const int x0 = tx * K::TW, y0 = ty * K::TH;
+    const int plane = H * W;
+    const int nchunks = (C + CC - 1) / CC;
+
+#if defined(__HIP_DEVICE_COMPILE__)  // buffer-resource builtins exist in the device pass only
+    if (wave == kND) {
+        // ------------------------------ loader wavefront ------------------------------
+        // Buffer-resource DMA: an offset at or beyond num_records reads zeros, so padding and
+        // the channel tail need no branch and no zero block; the plane / chunk advance goes
+        // into the scalar offset, which leaves FIVE per-lane byte offsets for the whole
+        // kernel (4 three-row groups of the x2 window, 1 for the x1 tile).
+        constexpr int kDead = static_cast<int>(0x80000000u);
+        const int item_bytes = C * plane * 4;
+        const __amdgpu_buffer_rsrc_t r1 = uniform_rsrc(x1 + static_cast<int64_t>(b) * C * plane, item_bytes);
+        const __amdgpu_buffer_rsrc_t r2 = uniform_rsrc(x2 + static_cast<int64_t>(b) * C * plane, item_bytes);
+        const bool x2lane = lane < 3 * K::HW4;               // 3 rows x 18 slots per DMA
+        const int lrow = lane / K::HW4, c4 = lane % K::HW4;
+        const int gx2 = x0 - kD + 4 * c4;
+        const bool xok = gx2 >= 0 && gx2 < W;
+        int v2[K::HR / 3];
+#pragma unroll
+        for (int rg = 0; rg < K::HR / 3; ++rg) {
+            const int gy = y0 - kD + 3 * rg + lrow;
+            v2[rg] = (xok && gy >= 0 && gy < H) ? (gy * W + gx2) * 4 : kDead;
+        }
+        const int row1 = lane / K::TSX, pos1 = lane % K::TSX;
+        const int strip1 = (pos1 + K::TSX - (2 * row1) % K::TSX) % K::TSX;  // ROT = 2
+        const int gy1 = y0 + row1, gx1 = x0 + 4 * strip1;
+        const int v1 = (gy1 < H && gx1 < W) ? (gy1 * W + gx1) * 4 : kDead;
+        auto issue = [&](int k) {
+            float *buf = smem + (k % NB) * K::BUF;
+            // scalar byte offsets of the chunk's planes, fixed before the (divergent) lane
+            // mask below so that they stay in SGPRs
+            int soff[CC];
+            bool chok[CC];
+#pragma unroll
+            for (int pl = 0; pl < CC; ++pl) {
+                soff[pl] = __builtin_amdgcn_readfirstlane((k * CC + pl) * plane * 4);
+                chok[pl] = k * CC + pl < C;
+            }
+            if (x2lane) {
+#pragma unroll
+                for (int pl = 0; pl < CC; ++pl)
+#pragma unroll
+                    for (int rg = 0; rg < K::HR / 3; ++rg)
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                            r2, (lds_void_ptr)(buf + pl * K::PS + rg * (3 * K::HW4 * 4)), 16,
+                            chok[pl] ? v2[rg] : kDead, soff[pl], 0, 0);
+            }
+#pragma unroll
+            for (int pl = 0; pl < CC; ++pl)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                    r1, (lds_void_ptr)(buf + CC * K::PS + pl * K::PS1), 16, chok[pl] ? v1 : kDead,
+                    soff[pl], 0, 0);
+        };
+#pragma unroll
+        for (int k = 0; k < NB - 1; ++k)
+            if (k < nchunks) issue(k);
+        for (int k = 0; k < nchunks; ++k) {
+            // this wave's DMAs for chunk k have landed once at most the younger chunks remain
+            const int younger = min(NB - 2, nchunks - 1 - k);
+            if (younger >= 2 && NB >= 4) wait_vmcnt<2 * NINST>();
+            else if (younger == 1) wait_vmcnt<NINST>();
+            else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();  // chunk k visible to the compute waves; k-1 consumed
+            if (k + NB - 1 < nchunks) issue(k + NB - 1);  // into the buffer chunk k-1 used
+        }
+        return;
+    }
+#endif
+
+    // -------------------------------- compute wavefronts --------------------------------
+    const int si = lane;                      // S = 1: 64 strips = 4 rows x 16
+    const int r = si / K::TSX;
+    const int pos = si % K::TSX;
+    const int sx = (pos + K::TSX - (2 * r) % K::TSX) % K::TSX;  // strip owned (ROT = 2)
+
+    float2v accp[kP][4];
+    float accs[kP];
+#pragma unroll
+    for (int p = 0; p < kP; ++p) {
+        accs[p] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) accp[p][j] = float2v{0.f, 0.f};
+    }
+    for (int k = 0; k < nchunks; ++k) {
+        __builtin_amdgcn_s_barrier();
+        const float *buf = smem + (k % NB) * K::BUF;
+        const float *X2 = buf + (r + wave) * (K::HW4 * 4) + 4 * sx;
+        const float *X1 = buf + CC * K::PS + r * (K::TSX * 4) + 4 * pos;
+#pragma unroll
+        for (int i = 0; i < CC; ++i) {
+            const float4 a = ld4(X1 + i * K::PS1);
+            const float *bp = X2 + i * K::PS;
+            const float4 b0 = ld4(bp), b1 = ld4(bp + 4), b2 = ld4(bp + 8);
+            const float av[4] = {a.x, a.y, a.z, a.w};
+            const float2v bw[6] = {float2v{b0.x, b0.y}, float2v{b0.z, b0.w}, float2v{b1.x, b1.y},
+                                   float2v{b1.z, b1.w}, float2v{b2.x, b2.y}, float2v{b2.z, b2.w}};
+#pragma unroll
+            for (int p = 0; p < kP; ++p) {
+                const int off = p & 1;
+                const float2v aa = float2v{av[p], av[p]};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) accp[p][j] = pkfma(aa, bw[(p + off) / 2 + j], accp[p][j]);
+                const float bs = off ? bw[(p - 1) / 2].y : bw[(p + 8) / 2].x;
+                accs[p] = fmaf(av[p], bs, accs[p]);
+            }
+        }
+        // all LDS reads of this chunk have returned before the next barrier releases the loader
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+
+    const float inv_nelems = 1.0f / static_cast<float>(C);
+    const int64_t obs = out_bstride ? out_bstride : static_cast<int64_t>(kND * kND) * plane;
+    float *ob = out + b * obs + static_cast<int64_t>(wave * kND) * plane;
+    const int y = y0 + r, x = x0 + 4 * sx;
+    if (y >= H || x >= W) return;
+#pragma unroll
+    for (int d = 0; d < kND; ++d) {
+        float v[4];
+#pragma unroll
+        for (int p = 0; p < kP; ++p) {
+            const int off = p & 1;
+            float q;
+            if (d == (off ? 0 : 8)) q = accs[p];
+            else { const int j = (d - off) / 2; q = ((d - off) & 1) ? accp[p][j].y : accp[p][j].x; }
+            q *= inv_nelems;
+            v[p] = q > 0.f ? q : q * slope;
+        }
+        typedef float f4v __attribute__((ext_vector_type(4)));
+        __builtin_nontemporal_store(f4v{v[0], v[1], v[2], v[3]},
+                                    reinterpret_cast<f4v *>(ob + static_cast<int64_t>(d) * plane + y * W + x));
+    }
+}
+
+// ============================================================================
 // backward
 // ============================================================================
 // TSXP pixel pairs per tile row (tile width 2*TSXP); a wavefront covers
@@ -654,6 +853,219 @@ __global__ __launch_bounds__(K::THREADS, 2) void corr_bwd_d4_kernel(
             }
         }
     }
+}
+
+// ============================================================================
+// backward, LDS-DMA variant (fp32, vector path)
+// ============================================================================
+// Same ownership and arithmetic as corr_bwd_d4_kernel (lane = 2 pixels x 81 gradOutput
+// registers).  The channel window no longer passes through VGPRs: every wavefront issues
+// buffer_load ... lds for chunk k+NB-1 into a ring of NB LDS buffers, then computes chunk
+// k.  Two things make that legal AND fast from plain HIP:
+//  * the chunk step is an inlined function whose read / write buffers are __restrict__:
+//    the alias scopes let hipcc's waitcnt pass see that the ds_reads cannot touch the
+//    buffer a DMA is filling (without them it drains vmcnt(0) before every ds_read);
+//  * every vector-memory operation of the loop is unconditional (buffer resources: dead
+//    lanes and channels past the slice use an out-of-range offset, which reads zeros /
+//    drops the store), so "chunk k has landed" is a fixed s_waitcnt vmcnt(N).  N counts
+//    only the younger DMA loads, which is correct whether or not stores retire in order
+//    with loads.
+template <int CC_, int NB_>
+struct BwdDmaCfg {
+    static constexpr int CC = CC_, NB = NB_;
+    static constexpr int TSXP = 32, TW = 64, RPW = 2, NW = 4, TH = NW * RPW;
+    static constexpr int HR = TH + 2 * kD, HW4 = (TW + 2 * kD) / 4, RS = HW4 * 4, PS = HR * RS;
+    static constexpr int THREADS = 64 * NW;
+    static constexpr int LPI = 48;                        // active lanes per DMA instruction
+    static constexpr int SLOTS = CC * HR * HW4;           // 16-byte slots per chunk
+    static constexpr int DW = SLOTS / (NW * LPI);         // DMA instructions per wave per chunk
+    static constexpr int BUF = CC * PS;
+    static constexpr size_t LDS_BYTES = sizeof(float) * NB * BUF;
+    static constexpr int WAITN = (NB - 2) * DW;
+    static_assert(DW * NW * LPI == SLOTS && (HR * HW4) % LPI == 0, "DMA partition");
+    static_assert(WAITN <= 63, "vmcnt is 6 bits");
+};
+
+#if defined(__HIP_DEVICE_COMPILE__)
+template <typename K>
+__device__ __forceinline__ void bwd_dma_issue(float *__restrict__ wr, __amdgpu_buffer_rsrc_t rsrc,
+                                              const int (&voff)[K::DW], int wave, int lane,
+                                              int c_first, int c_end, int plane) {
+    constexpr int kDead = static_cast<int>(0x80000000u);
+    const int soff = __builtin_amdgcn_readfirstlane(c_first * plane * 4);
+    bool chok[K::DW];
+#pragma unroll
+    for (int q = 0; q < K::DW; ++q)
+        chok[q] = c_first + (wave + K::NW * q) / (K::HR * K::HW4 / K::LPI) < c_end;
+    if (lane < K::LPI) {
+#pragma unroll
+        for (int q = 0; q < K::DW; ++q)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                rsrc, (lds_void_ptr)(wr + (wave + K::NW * q) * (K::LPI * 4)), 16,
+                chok[q] ? voff[q] : kDead, soff, 0, 0);
+    }
+}
+
+// one chunk: start the DMA of a later chunk into `wr`, consume the chunk in `rd`
+template <typename K>
+__device__ __forceinline__ void bwd_dma_step(
+    const float *__restrict__ rd, float *__restrict__ wr, __amdgpu_buffer_rsrc_t rsrc_src,
+    __amdgpu_buffer_rsrc_t rsrc_dst, const int (&voff)[K::DW], int wave, int lane, int c0,
+    int c_next, int c_end, int plane, const float2v (&g0p)[kND][4], const float2v (&g1p)[kND][4],
+    const float (&g0s)[kND], const float (&g1s)[kND], int woff, int dst_voff, float inv_nelems,
+    int dbg) {
+    constexpr int kDead = static_cast<int>(0x80000000u);
+    constexpr int CC = K::CC;
+    if (!(dbg & 2)) bwd_dma_issue<K>(wr, rsrc_src, voff, wave, lane, c_next, c_end, plane);
+    const float *wbase = rd + woff;
+    float res[CC][2] = {};
+#pragma unroll 1
+    for (int i = 0; i < CC; ++i) {
+        if (dbg & 4) break;
+        const float *wp = wbase + i * K::PS;
+        float2v a0[3] = {float2v{0.f, 0.f}, float2v{0.f, 0.f}, float2v{0.f, 0.f}};
+        float2v a1[3] = {float2v{0.f, 0.f}, float2v{0.f, 0.f}, float2v{0.f, 0.f}};
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int dyi = 0; dyi < kND; ++dyi) {
+            float2v w[5];
+#pragma unroll
+            for (int q = 0; q < 5; ++q)
+                w[q] = (dbg & 8) ? float2v{inv_nelems, inv_nelems} : ld2v_nomerge(wp + dyi * K::RS + 2 * q);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                a0[dyi % 3] = pkfma(g0p[dyi][j], w[j], a0[dyi % 3]);
+                a1[dyi % 3] = pkfma(g1p[dyi][j], w[j + 1], a1[dyi % 3]);
+            }
+            s0 = fmaf(g0s[dyi], w[4].x, s0);
+            s1 = fmaf(g1s[dyi], w[0].y, s1);
+        }
+        const float2v t0 = a0[0] + a0[1] + a0[2], t1 = a1[0] + a1[1] + a1[2];
+        const float r0 = (t0.x + t0.y + s0) * inv_nelems, r1 = (t1.x + t1.y + s1) * inv_nelems;
+#pragma unroll
+        for (int q = 0; q < CC; ++q)
+            if (q == i) { res[q][0] = r0; res[q][1] = r1; }
+    }
+    typedef unsigned uint2v __attribute__((ext_vector_type(2)));
+    if (dbg & 1) return;
+#pragma unroll
+    for (int i = 0; i < CC; ++i)
+        __builtin_amdgcn_raw_buffer_store_b64(
+            __builtin_bit_cast(uint2v, float2v{res[i][0], res[i][1]}), rsrc_dst,
+            c0 + i < c_end ? dst_voff : kDead,
+            __builtin_amdgcn_readfirstlane((c0 + i) * plane * 4), 2 /* nt */);
+}
+#endif
+
+template <typename K>
+__global__ __launch_bounds__(K::THREADS, 2) void corr_bwd_d4_dma_kernel(
+    const float *__restrict__ x1, const float *__restrict__ x2, const float *__restrict__ gout,
+    float *__restrict__ gin1, float *__restrict__ gin2, int C, int H, int W, int tiles_x,
+    int tiles_y, int cslice, int nslice, int dbg) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#ifndef CERB_ABLATE
+    dbg = 0;
+#endif
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int CC = K::CC, NB = K::NB;
+    constexpr int kDead = static_cast<int>(0x80000000u);
+    if (dbg & 64) return;
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int r = wave * K::RPW + lane / K::TSXP;
+    const int sxp = lane % K::TSXP;
+
+    // runtime divisions run on the VALU: pin the (uniform) results to SGPRs, a buffer
+    // resource held in VGPRs costs a waterfall loop around every DMA
+    int bid = xcd_swizzle(blockIdx.x, gridDim.x);
+    const int side = __builtin_amdgcn_readfirstlane(bid & 1); bid >>= 1;  // 0: gradInput1
+    const int slice = __builtin_amdgcn_readfirstlane(bid % nslice); bid /= nslice;
+    const int tx = __builtin_amdgcn_readfirstlane(bid % tiles_x); bid /= tiles_x;
+    const int ty = __builtin_amdgcn_readfirstlane(bid % tiles_y);
+    const int b = __builtin_amdgcn_readfirstlane(bid / tiles_y);
+    const int x0 = tx * K::TW, y0 = ty * K::TH;
+    const int c_begin = slice * cslice;
+    const int c_end = min(C, c_begin + cslice);
+    const int plane = H * W;
+    const int nchunks = (c_end - c_begin + CC - 1) / CC;
+
+    const float *src = (side == 0 ? x2 : x1) + static_cast<int64_t>(b) * C * plane;
+    float *dstb = (side == 0 ? gin1 : gin2) + static_cast<int64_t>(b) * C * plane;
+    const float *gob = gout + static_cast<int64_t>(b) * (kND * kND) * plane;
+    const __amdgpu_buffer_rsrc_t rsrc_src = uniform_rsrc(src, C * plane * 4);
+    const __amdgpu_buffer_rsrc_t rsrc_dst = uniform_rsrc(dstb, C * plane * 4);
+
+    const int y = y0 + r, x = x0 + 2 * sxp;
+    const bool live = y < H && x < W;
+    const int dst_voff = live ? (y * W + x) * 4 : kDead;
+
+    // per-lane byte offsets of this wave's DMA slots (channel 0 of a chunk)
+    int voff[K::DW];
+#pragma unroll
+    for (int q = 0; q < K::DW; ++q) {
+        const int id = (wave + K::NW * q) * K::LPI + lane;
+        const int pl = id / (K::HR * K::HW4), rem = id % (K::HR * K::HW4);
+        const int row = rem / K::HW4, c4 = rem % K::HW4;
+        const int gy = y0 - kD + row, gx = x0 - kD + 4 * c4;
+        voff[q] = (lane < K::LPI && gy >= 0 && gy < H && gx >= 0 && gx < W)
+                      ? (pl * plane + gy * W + gx) * 4 : kDead;
+    }
+#pragma unroll
+    for (int k = 0; k < NB - 1; ++k)   // in flight while the gradOutput registers are gathered
+        bwd_dma_issue<K>(smem + k * K::BUF, rsrc_src, voff, wave, lane, c_begin + k * CC, c_end, plane);
+
+    float2v g0p[kND][4], g1p[kND][4];
+    float g0s[kND], g1s[kND];
+    {
+        // branch-free gather, see corr_bwd_d4_kernel
+        const int lane_off = live ? y * W + x : 0;
+        unsigned ymask = 0, xmask0 = 0, xmask1 = 0;
+#pragma unroll
+        for (int k = 0; k < kND; ++k) {
+            const int yy = y + k - kD, xx = x + k - kD;
+            if (yy >= 0 && yy < H) ymask |= 1u << k;
+            if (xx >= 0 && xx < W) xmask0 |= 1u << k;
+            if (xx + 1 >= 0 && xx + 1 < W) xmask1 |= 1u << k;
+        }
+        if (!live) ymask = 0;
+#pragma unroll
+        for (int d = 0; d < kND * kND; ++d) {
+            const int dyi = d / kND, dxi = d % kND;
+            float v0, v1;
+            if (side == 0) {  // wave-uniform
+                const float2 t = Gmem<float>::load2(gob + static_cast<int64_t>(d) * plane + lane_off);
+                v0 = t.x; v1 = t.y;
+            } else {
+                const int uni = (kND * kND - 1 - d) * plane + (dyi - kD) * W + (dxi - kD);
+                const bool oky = (ymask >> dyi) & 1u;
+                const bool ok0 = oky && ((xmask0 >> dxi) & 1u);
+                const bool ok1 = oky && ((xmask1 >> dxi) & 1u);
+                v0 = Gmem<float>::load1(ok0 ? gob + (uni + lane_off) : g_zero16);
+                v1 = Gmem<float>::load1(ok1 ? gob + (uni + lane_off + 1) : g_zero16);
+            }
+            if (dxi == 8) g0s[dyi] = v0; else if (dxi & 1) g0p[dyi][dxi / 2].y = v0; else g0p[dyi][dxi / 2].x = v0;
+            if (dxi == 0) g1s[dyi] = v1; else if (dxi & 1) g1p[dyi][(dxi - 1) / 2].x = v1; else g1p[dyi][(dxi - 1) / 2].y = v1;
+        }
+    }
+
+    if (dbg & 32) {  // ablation: prologue + gather only
+        if (live) gin1[y * W + x] = g0s[0] + g1s[8] + g0p[4][2].x;
+        return;
+    }
+    const float inv_nelems = 1.0f / static_cast<float>(C);
+    const int woff = r * K::RS + 2 * sxp;
+    for (int k = 0; k < nchunks; ++k) {
+        // own DMAs of chunk k have landed: at most the NB-2 younger chunks' loads may be pending
+        wait_vmcnt<K::WAITN>();
+        __builtin_amdgcn_s_barrier();   // chunk k complete in LDS; everyone is done with chunk k-1
+        const int c0 = c_begin + k * CC;
+        bwd_dma_step<K>(smem + (k % NB) * K::BUF, smem + ((k + NB - 1) % NB) * K::BUF, rsrc_src,
+                        rsrc_dst, voff, wave, lane, c0, c0 + (NB - 1) * CC, c_end, plane, g0p, g1p,
+                        g0s, g1s, woff, dst_voff, inv_nelems, dbg);
+        // LDS reads of chunk k have returned (the FMAs consumed them) before the next barrier
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+#endif
 }
 
 // ============================================================================
@@ -916,6 +1328,25 @@ using FwdE1 = FwdCfg<16, 4, 1, 2, 0, 24, 16, 16, 3, 2>;  // 1x16 tile, 16 channe
 using FwdA1b = FwdCfg<1, 16, 1, 4, 2, 72, 72, 0, 3, 1>;  // 4x64 tile, small chunks, 3 WGs/CU
 using FwdA1c = FwdCfg<1, 16, 1, 4, 2, 72, 72, 0, 3, 2>;  // 4x64 tile, 2 chunks in flight
 
+using FwdDma4 = FwdDmaCfg<4, 4>;   // 4-channel chunks, ring of 4 (3 chunks in flight)
+
+template <typename K>
+int launch_fwd_dma(const char *name, const void *in1, const void *in2, void *outp,
+                   const CorrGeom &g, float slope, int64_t obs, hipStream_t s) {
+    const int tiles_x = (g.W + K::TW - 1) / K::TW, tiles_y = (g.H + K::TH - 1) / K::TH;
+    const int64_t blocks = static_cast<int64_t>(g.B) * tiles_x * tiles_y;
+    if (blocks > 0x7fffffff) return CERB_ETOOLARGE;
+    static bool lds_done = false;
+    int rc;
+    if ((rc = ensure_lds(corr_fwd_d4_dma_kernel<K>, K::LDS_BYTES, &lds_done))) return rc;
+    note_kernel(0, name);
+    hipLaunchKernelGGL((corr_fwd_d4_dma_kernel<K>), dim3(static_cast<unsigned>(blocks)),
+                       dim3(K::THREADS), K::LDS_BYTES, s, static_cast<const float *>(in1),
+                       static_cast<const float *>(in2), static_cast<float *>(outp), g.C, g.H, g.W,
+                       tiles_x, tiles_y, slope, obs);
+    return launch_status();
+}
+
 template <typename K>
 int64_t fwd_tiles(const CorrGeom &g) {
     return static_cast<int64_t>(g.B) * ((g.W + K::TW - 1) / K::TW) * ((g.H + K::TH - 1) / K::TH);
@@ -961,6 +1392,32 @@ int launch_bwd(const char *name, const void *in1, const void *in2, const void *g
     return launch_status();
 }
 
+template <typename K>
+int launch_bwd_dma(const char *name, const void *in1, const void *in2, const void *goutp, void *g1p,
+                   void *g2p, const CorrGeom &g, hipStream_t s) {
+    const int tiles_x = (g.W + K::TW - 1) / K::TW, tiles_y = (g.H + K::TH - 1) / K::TH;
+    const int64_t tiles = static_cast<int64_t>(g.B) * tiles_x * tiles_y;
+    int cslice = option_value("corr_bwd_cslice");
+    if (cslice <= 0) {
+        cslice = g.C;
+        while (cslice > 8 && 2 * tiles * ((g.C + cslice - 1) / cslice) < 512) cslice = (cslice + 1) / 2;
+    }
+    cslice = std::max(K::CC, (cslice + K::CC - 1) / K::CC * K::CC);
+    const int nslice = (g.C + cslice - 1) / cslice;
+    const int64_t blocks = tiles * nslice * 2;
+    if (blocks > 0x7fffffff) return CERB_ETOOLARGE;
+    static bool lds_done = false;
+    int rc;
+    if ((rc = ensure_lds(corr_bwd_d4_dma_kernel<K>, K::LDS_BYTES, &lds_done))) return rc;
+    note_kernel(1, name);
+    hipLaunchKernelGGL((corr_bwd_d4_dma_kernel<K>), dim3(static_cast<unsigned>(blocks)),
+                       dim3(K::THREADS), K::LDS_BYTES, s, static_cast<const float *>(in1),
+                       static_cast<const float *>(in2), static_cast<const float *>(goutp),
+                       static_cast<float *>(g1p), static_cast<float *>(g2p), g.C, g.H, g.W, tiles_x,
+                       tiles_y, cslice, nslice, option_value("corr_debug_ablate"));
+    return launch_status();
+}
+
 template <typename K, typename T>
 int launch_bwd_g3(const char *name, const void *in1, const void *in2, const void *goutp, void *g1p,
                   void *g2p, const CorrGeom &g, bool vec, hipStream_t s) {
@@ -998,6 +1455,7 @@ int launch_bwd_g3(const char *name, const void *in1, const void *in2, const void
 
 using BwdG3Wide = BwdG3Cfg<32, 4, 72, 2>;    // 4x64 tile, 6 wavefronts
 using BwdG3Wide4 = BwdG3Cfg<32, 2, 72, 4>;   // 8x64 tile, 12 wavefronts
+using BwdDma2x5 = BwdDmaCfg<2, 5>;   // 8x64 tile, 2-channel chunks, ring of 5
 using BwdWide = BwdCfg<32, 2, 72>;    // 8x64 tile
 // Tried and rejected on MI355X (level 3 / level 2, 4 pairs): 16x64 tiles with 8 wavefronts
 // (55.8 / 39.0 us vs 45.6 / 29.2: fewer workgroups in flight outweighs the smaller halo) and
@@ -1028,13 +1486,25 @@ int fwd_dispatch(const void *x1, const void *x2, void *o, const CorrGeom &g, flo
         case 6: if (g.C % 16 == 0) return launch_fwd<FwdE1, T>("corr_fwd_d4_1x16_s16", x1, x2, o, g, slope, obs, vec, s); break;
         case 7: return launch_fwd<FwdA1b, T>("corr_fwd_d4_4x64_cc4", x1, x2, o, g, slope, obs, vec, s);
         case 8: return launch_fwd<FwdA1c, T>("corr_fwd_d4_4x64_cc4x2", x1, x2, o, g, slope, obs, vec, s);
+        case 9:
+            if constexpr (sizeof(T) == 4) {
+                if (vec) return launch_fwd_dma<FwdDma4>("corr_fwd_d4_dma_4x64", x1, x2, o, g, slope, obs, s);
+            }
+            break;
         default: break;
     }
     // Smallest channel split that still yields >= 256 workgroups (one per CU); the tile
     // sweep on MI355X (tools/tune_corr.py, profiles/) picked exactly this order.
     const int64_t want = 256;
-    if (fwd_tiles<FwdA1b>(g) >= want || g.C % 2 != 0)
+    if (fwd_tiles<FwdA1b>(g) >= want || g.C % 2 != 0) {
+        // fp32 vector path: LDS-DMA ring with a loader wavefront (21.3 vs 22.2 us at level 3,
+        // 15 vs 20 us at 64 channels); same tile, same summation order, identical bits
+        if constexpr (sizeof(T) == 4) {
+            if (vec)
+                return launch_fwd_dma<FwdDma4>("corr_fwd_d4_dma_4x64", x1, x2, o, g, slope, obs, s);
+        }
         return launch_fwd<FwdA1b, T>("corr_fwd_d4_4x64_cc4", x1, x2, o, g, slope, obs, vec, s);
+    }
     if (fwd_tiles<FwdB1>(g) >= want || g.C % 4 != 0)
         return launch_fwd<FwdB1, T>("corr_fwd_d4_2x64_s2", x1, x2, o, g, slope, obs, vec, s);
     if (fwd_tiles<FwdC1>(g) >= want || g.C % 8 != 0)
@@ -1053,6 +1523,11 @@ int bwd_dispatch(const void *x1, const void *x2, const void *go, void *g1, void 
         case 1: return launch_bwd<BwdWide, T>("corr_bwd_d4_8x64", x1, x2, go, g1, g2, g, vec, s);
         case 2: return launch_bwd_g3<BwdG3Wide, T>("corr_bwd_d4_g3_4x64", x1, x2, go, g1, g2, g, vec, s);
         case 3: return launch_bwd_g3<BwdG3Wide4, T>("corr_bwd_d4_g3_8x64", x1, x2, go, g1, g2, g, vec, s);
+        case 4:
+            if constexpr (sizeof(T) == 4) {
+                if (vec) return launch_bwd_dma<BwdDma2x5>("corr_bwd_d4_dma_8x64", x1, x2, go, g1, g2, g, s);
+            }
+            break;
         default: break;
     }
     // few tiles (coarse level): the displacement-group kernel puts 3x the wavefronts on the
@@ -1060,6 +1535,10 @@ int bwd_dispatch(const void *x1, const void *x2, const void *go, void *g1, void 
     const int64_t tiles = static_cast<int64_t>(g.B) * ((g.W + 63) / 64) * ((g.H + 7) / 8);
     if (tiles <= 32 && g.C >= 16)
         return launch_bwd_g3<BwdG3Wide4, T>("corr_bwd_d4_g3_8x64", x1, x2, go, g1, g2, g, vec, s);
+    // fp32 vector path: same kernel with the channel window streamed by LDS-DMA (identical bits)
+    if constexpr (sizeof(T) == 4) {
+        if (vec) return launch_bwd_dma<BwdDma2x5>("corr_bwd_d4_dma_8x64", x1, x2, go, g1, g2, g, s);
+    }
     return launch_bwd<BwdWide, T>("corr_bwd_d4_8x64", x1, x2, go, g1, g2, g, vec, s);
 }
 

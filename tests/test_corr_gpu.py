@@ -289,9 +289,9 @@ def test_native_library_is_loaded():
     assert "libcerberus_hip.so" in maps
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 8])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 8, 9])
 @pytest.mark.parametrize("shape", [(2, 32, 13, 72), (1, 16, 9, 64), (1, 48, 20, 33),
-                                   (2, 64, 5, 16), (1, 16, 3, 130)])
+                                   (2, 64, 5, 16), (1, 16, 3, 130), (2, 7, 11, 132)])
 def test_every_tuned_forward_variant(variant, shape):
     """Force each tile / channel-split variant of the tuned forward (vector and
     scalar staging paths, ragged tiles) against the C oracle."""
@@ -308,10 +308,10 @@ def test_every_tuned_forward_variant(variant, shape):
     assert rel_err(out, ref) < TOL
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4])
 @pytest.mark.parametrize("cslice", [0, 2, 4, 8, 1000])
 @pytest.mark.parametrize("shape", [(2, 12, 13, 72), (1, 10, 20, 32), (1, 7, 18, 33),
-                                   (1, 16, 40, 28), (2, 5, 9, 130)])
+                                   (1, 16, 40, 28), (2, 5, 9, 130), (2, 9, 21, 136)])
 def test_tuned_backward_tiles_and_channel_slices(variant, cslice, shape):
     B, C, H, W = shape
     x1, x2 = hash_uniform(shape, 43), hash_uniform(shape, 44)
@@ -328,6 +328,33 @@ def test_tuned_backward_tiles_and_channel_slices(variant, cslice, shape):
     assert name.startswith("corr_bwd_d4"), name
     assert rel_err(g1, r1) < TOL
     assert rel_err(g2, r2) < TOL
+
+
+@pytest.mark.parametrize("shape", [(2, 32, 24, 128), (1, 6, 8, 64), (3, 17, 37, 196)])
+def test_dma_kernels_are_bit_identical_to_the_register_staged_ones(shape):
+    """The LDS-DMA kernels change the data movement only (same tile, same lane mapping, same
+    summation order): their results must equal the register-staged kernels bit for bit."""
+    B, C, H, W = shape
+    x1 = torch.from_numpy(hash_uniform(shape, 46)).to(DEV)
+    x2 = torch.from_numpy(hash_uniform(shape, 47)).to(DEV)
+    go = torch.from_numpy(hash_uniform((B, 81, H, W), 48)).to(DEV)
+    res = {}
+    for tag, fv, bv in (("staged", 7, 1), ("dma", 9, 4)):
+        _lib.set_option("corr_fwd_variant", fv)
+        _lib.set_option("corr_bwd_variant", bv)
+        try:
+            out = torch.ops.cerberus.correlation(x1, x2, 4, 1, 4, 1, 1, 1)
+            fname = _lib.last_kernel(0)
+            g1, g2 = torch.ops.cerberus.correlation_backward(x1, x2, go, 4, 1, 4, 1, 1, 1)
+            bname = _lib.last_kernel(1)
+        finally:
+            _lib.set_option("corr_fwd_variant", 0)
+            _lib.set_option("corr_bwd_variant", 0)
+        res[tag] = (out, g1, g2, fname, bname)
+    assert "dma" in res["dma"][3] and "dma" in res["dma"][4], res["dma"][3:]
+    assert "dma" not in res["staged"][3] and "dma" not in res["staged"][4], res["staged"][3:]
+    for a, b in zip(res["staged"][:3], res["dma"][:3]):
+        assert torch.equal(a, b)
 
 
 def test_headline_shapes_use_the_tuned_kernels():
