@@ -111,7 +111,12 @@ class Workload:
         ops = torch.ops.cerberus
         # forward, coarse to fine
         for l, t in enumerate(lv):
-            t["warped"] = ops.flow_warp(t["f2"], t["flow"], 1, 0) if l > 0 else t["f2"]
+            # training forward: the warp also saves its backward context (sample positions),
+            # as autograd's save_for_backward does for grid_sample in the reference
+            if l > 0:
+                t["warped"], t["ctx"] = ops.flow_warp_ctx(t["f2"], t["flow"], 1, 0)
+            else:
+                t["warped"] = t["f2"]
             t["out"] = ops.correlation(t["f1"], t["warped"], *CORR_P)
         # backward, fine to coarse
         for l in reversed(range(len(lv))):
@@ -119,7 +124,8 @@ class Workload:
             g1, g2 = ops.correlation_backward(t["f1"], t["warped"], t["gout"], *CORR_P)
             keep.append(g1)
             if l > 0:
-                keep += ops.flow_warp_backward(t["f2"], t["flow"], g2, 1, 0, True, True)
+                keep += ops.flow_warp_backward_ctx(t["f2"], t["flow"], t["ctx"], g2, 1, 0,
+                                                   True, True)
             else:
                 keep.append(g2)
 
@@ -155,9 +161,9 @@ def per_kernel_times(wl, reps):
         calls["corr_bwd_L%d" % l] = (lambda t=t: ops.correlation_backward(
             t["f1"], t["warped"], t["gout"], *CORR_P))
         if l > 0:
-            calls["warp_fwd_L%d" % l] = (lambda t=t: ops.flow_warp(t["f2"], t["flow"], 1, 0))
-            calls["warp_bwd_L%d" % l] = (lambda t=t: ops.flow_warp_backward(
-                t["f2"], t["flow"], t["f1"], 1, 0, True, True))
+            calls["warp_fwd_L%d" % l] = (lambda t=t: ops.flow_warp_ctx(t["f2"], t["flow"], 1, 0))
+            calls["warp_bwd_L%d" % l] = (lambda t=t: ops.flow_warp_backward_ctx(
+                t["f2"], t["flow"], t["ctx"], t["f1"], 1, 0, True, True))
     out = {}
     for label, fn in calls.items():
         fn()

@@ -139,27 +139,43 @@ static int warp_args_ok(int B, int C, int H, int W, int pad_mode, int interp_mod
 
 int cerberus_flow_warp_forward(const void *image, const void *flow, void *out, int B, int C, int H,
                                int W, int pad_mode, int interp_mode, int dtype, void *stream) {
+    return cerberus_flow_warp_forward_ctx(image, flow, out, nullptr, 0, B, C, H, W, pad_mode,
+                                          interp_mode, dtype, stream);
+}
+
+int64_t cerberus_flow_warp_context_bytes(int B, int H, int W) {
+    if (B < 0 || H < 0 || W < 0) return 0;
+    return warp_context_bytes(B, H, W);
+}
+
+int cerberus_flow_warp_forward_ctx(const void *image, const void *flow, void *out, void *context,
+                                   int64_t context_bytes, int B, int C, int H, int W,
+                                   int pad_mode, int interp_mode, int dtype, void *stream) {
     const int rc = warp_args_ok(B, C, H, W, pad_mode, interp_mode, dtype);
     if (rc) return rc;
     if (B == 0) return CERB_OK;
     if (!image || !flow || !out) return CERB_EINVAL;
-    return warp_forward(image, flow, out, B, C, H, W, pad_mode, interp_mode, dtype,
-                        static_cast<hipStream_t>(stream));
+    return warp_forward(image, flow, out, context, context_bytes, B, C, H, W, pad_mode,
+                        interp_mode, dtype, static_cast<hipStream_t>(stream));
 }
 
-int64_t cerberus_flow_warp_backward_workspace_bytes(void) { return 4 * sizeof(int); }
+int64_t cerberus_flow_warp_backward_workspace_bytes(int B, int C, int H, int W) {
+    if (B < 0 || C < 0 || H < 0 || W < 0) return 0;
+    return warp_backward_workspace_bytes(B, C, H, W);
+}
 
 int cerberus_flow_warp_backward(const void *image, const void *flow, const void *grad_out,
-                                void *grad_image, void *grad_flow, void *workspace,
-                                int64_t workspace_bytes, int B, int C, int H, int W,
-                                int pad_mode, int interp_mode, int dtype, void *stream) {
+                                void *grad_image, void *grad_flow, const void *context,
+                                int64_t context_bytes, void *workspace, int64_t workspace_bytes,
+                                int B, int C, int H, int W, int pad_mode, int interp_mode,
+                                int dtype, void *stream) {
     const int rc = warp_args_ok(B, C, H, W, pad_mode, interp_mode, dtype);
     if (rc) return rc;
     if (B == 0) return CERB_OK;
     if (!image || !flow || !grad_out) return CERB_EINVAL;
     if (!grad_image && !grad_flow) return CERB_OK;
-    return warp_backward(image, flow, grad_out, grad_image, grad_flow, workspace, workspace_bytes,
-                         B, C, H, W, pad_mode, interp_mode, dtype,
+    return warp_backward(image, flow, grad_out, grad_image, grad_flow, context, context_bytes,
+                         workspace, workspace_bytes, B, C, H, W, pad_mode, interp_mode, dtype,
                          static_cast<hipStream_t>(stream));
 }
 

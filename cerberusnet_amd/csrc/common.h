@@ -81,11 +81,14 @@ int corr_d4_forward(const void *in1, const void *in2, void *out, const CorrGeom 
 int corr_d4_backward(const void *in1, const void *in2, const void *gout, void *gin1, void *gin2,
                      const CorrGeom &g, int dtype, hipStream_t s);
 
-int warp_forward(const void *image, const void *flow, void *out, int B, int C, int H, int W,
-                 int pad_mode, int interp, int dtype, hipStream_t s);
+int64_t warp_context_bytes(int B, int H, int W);
+int64_t warp_backward_workspace_bytes(int B, int C, int H, int W);
+int warp_forward(const void *image, const void *flow, void *out, void *ctx, int64_t ctx_size,
+                 int B, int C, int H, int W, int pad_mode, int interp, int dtype, hipStream_t s);
 int warp_backward(const void *image, const void *flow, const void *gout, void *gimage,
-                  void *gflow, void *workspace, int64_t workspace_bytes, int B, int C, int H,
-                  int W, int pad_mode, int interp, int dtype, hipStream_t s);
+                  void *gflow, const void *ctx, int64_t ctx_size, void *workspace,
+                  int64_t workspace_bytes, int B, int C, int H, int W, int pad_mode, int interp,
+                  int dtype, hipStream_t s);
 
 static inline int launch_status() {
     hipError_t e = hipGetLastError();

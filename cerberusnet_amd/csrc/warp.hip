@@ -20,6 +20,8 @@
 // channels: each wave reduces its own channels in registers, the kCg partials
 // meet in LDS, wave 0 stores -- deterministic, no atomics.  The image gradient
 // is a data-dependent scatter: fp32/fp64 hardware atomics, as ATen does.
+#include <algorithm>
+
 #include "common.h"
 
 namespace cerb {
@@ -96,62 +98,151 @@ __device__ __forceinline__ void load_taps(const T *q, bool ok0, bool ok1, A &v0,
     }
 }
 
+// ---- backward context ----------------------------------------------------------
+// What the forward already knows and the backward needs again: every pixel's sample
+// position (after unnormalise + padding) and how far a tap can land from its own pixel.
+// Saved by the forward (cerberus_flow_warp_forward_ctx) the backward is two launches with no
+// pre-pass; without it the backward first runs warp_context_kernel over the flow.
+//   int   ext[kCtxPartials][2]   per-workgroup max tap extent (x, y); the first
+//                                min(B*ceil(HW/64), kCtxPartials) slots are written and read
+//   float pos[B][2][H][W]        sample positions (x plane, y plane)
+constexpr int kCtxPartials = 2048;
+__host__ __device__ inline int64_t ctx_bytes(int B, int H, int W) {
+    return static_cast<int64_t>(kCtxPartials) * 2 * sizeof(int) +
+           static_cast<int64_t>(B) * 2 * H * W * sizeof(float);
+}
+__host__ __device__ __forceinline__ float *ctx_pos(void *ctx) {
+    return reinterpret_cast<float *>(static_cast<int *>(ctx) + 2 * kCtxPartials);
+}
+__host__ __device__ __forceinline__ const float *ctx_pos(const void *ctx) {
+    return reinterpret_cast<const float *>(static_cast<const int *>(ctx) + 2 * kCtxPartials);
+}
+
+// Wave-level max of two non-negative ints.
+__device__ __forceinline__ void wave_max2(int &a, int &b) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        a = max(a, __shfl_xor(a, m, 64));
+        b = max(b, __shfl_xor(b, m, 64));
+    }
+}
+
+// Grid: 1-D over the B * ceil(HW/64) pixel strips (grid-stride when a context caps the
+// number of workgroups at kCtxPartials).
 template <typename T, bool PAIR, int kCg>
 __global__ __launch_bounds__(kPix * kCg) void warp_fwd_kernel(
-    const T *__restrict__ image, const T *__restrict__ flow, T *__restrict__ out, int C, int H,
-    int W, int pad_mode, int interp) {
+    const T *__restrict__ image, const T *__restrict__ flow, T *__restrict__ out,
+    void *__restrict__ ctx, int B, int C, int H, int W, int pad_mode, int interp) {
     using A = typename Acc<T>::type;
     const int64_t plane = static_cast<int64_t>(H) * W;
     const int lane = threadIdx.x & (kPix - 1);
     const int cg = threadIdx.x / kPix;
-    const int64_t p = static_cast<int64_t>(blockIdx.x) * kPix + lane;
-    const int b = blockIdx.y;
-    if (p >= plane) return;
-    const int y = static_cast<int>(p / W), x = static_cast<int>(p % W);
-    const T *fl = flow + static_cast<int64_t>(b) * 2 * plane + p;
-    const Coord<A> cx = source_coord<A>(x, ld(fl), W, pad_mode);
-    const Coord<A> cy = source_coord<A>(y, ld(fl + plane), H, pad_mode);
-    const T *img = image + static_cast<int64_t>(b) * C * plane;
-    T *dst = out + static_cast<int64_t>(b) * C * plane + p;
-    if (interp == CERB_INTERP_NEAREST) {
-        const A xn = nearbyint(cx.pos), yn = nearbyint(cy.pos);
-        const bool ok = xn >= A(0) && xn < static_cast<A>(W) && yn >= A(0) && yn < static_cast<A>(H);
-        const int64_t off = ok ? static_cast<int64_t>(yn) * W + static_cast<int64_t>(xn) : 0;
-        for (int c = cg; c < C; c += kCg)
-            st(dst + c * plane, ok ? ld(img + c * plane + off) : A(0));
-        return;
+    const int spp = static_cast<int>((plane + kPix - 1) / kPix);   // strips per plane
+    const int64_t nstrips = static_cast<int64_t>(B) * spp;
+    int ext_x = 0, ext_y = 0;
+    for (int64_t strip = blockIdx.x; strip < nstrips; strip += gridDim.x) {
+        const int b = static_cast<int>(strip / spp);
+        const int64_t p = (strip % spp) * kPix + lane;
+        if (p >= plane) continue;
+        const int y = static_cast<int>(p / W), x = static_cast<int>(p % W);
+        const T *fl = flow + static_cast<int64_t>(b) * 2 * plane + p;
+        const Coord<A> cx = source_coord<A>(x, ld(fl), W, pad_mode);
+        const Coord<A> cy = source_coord<A>(y, ld(fl + plane), H, pad_mode);
+        const T *img = image + static_cast<int64_t>(b) * C * plane;
+        T *dst = out + static_cast<int64_t>(b) * C * plane + p;
+        if (interp == CERB_INTERP_NEAREST) {
+            const A xn = nearbyint(cx.pos), yn = nearbyint(cy.pos);
+            const bool ok = xn >= A(0) && xn < static_cast<A>(W) && yn >= A(0) && yn < static_cast<A>(H);
+            const int64_t off = ok ? static_cast<int64_t>(yn) * W + static_cast<int64_t>(xn) : 0;
+            for (int c = cg; c < C; c += kCg)
+                st(dst + c * plane, ok ? ld(img + c * plane + off) : A(0));
+            continue;
+        }
+        const A x0f = floor(cx.pos), y0f = floor(cy.pos);
+        const A x1f = x0f + A(1), y1f = y0f + A(1);
+        const A wnw = (x1f - cx.pos) * (y1f - cy.pos);
+        const A wne = (cx.pos - x0f) * (y1f - cy.pos);
+        const A wsw = (x1f - cx.pos) * (cy.pos - y0f);
+        const A wse = (cx.pos - x0f) * (cy.pos - y0f);
+        const int x0 = static_cast<int>(x0f), y0 = static_cast<int>(y0f);
+        const bool okx0 = x0 >= 0 && x0 < W, okx1 = x0 + 1 >= 0 && x0 + 1 < W;
+        const bool oky0 = y0 >= 0 && y0 < H, oky1 = y0 + 1 >= 0 && y0 + 1 < H;
+        const int64_t o00 = static_cast<int64_t>(y0) * W + x0;
+        if (ctx && cg == 0) {
+            float *pos = ctx_pos(ctx) + static_cast<int64_t>(b) * 2 * plane + p;
+            pos[0] = static_cast<float>(cx.pos);
+            pos[plane] = static_cast<float>(cy.pos);
+            if ((okx0 || okx1) && (oky0 || oky1)) {
+                ext_x = max(ext_x, max(abs(x0 - x), abs(x0 + 1 - x)));
+                ext_y = max(ext_y, max(abs(y0 - y), abs(y0 + 1 - y)));
+            }
+        }
+        constexpr int kU = 4;  // channels per trip: 16 independent taps in flight per lane
+        for (int c = cg; c < C; c += kU * kCg) {
+            A v[kU][4];
+#pragma unroll
+            for (int u = 0; u < kU; ++u) {
+                const int cc = min(c + u * kCg, C - 1);
+                const T *q = img + cc * plane + o00;
+                load_taps<PAIR, T, A>(q, oky0 && okx0, oky0 && okx1, v[u][0], v[u][1]);
+                load_taps<PAIR, T, A>(q + W, oky1 && okx0, oky1 && okx1, v[u][2], v[u][3]);
+            }
+#pragma unroll
+            for (int u = 0; u < kU; ++u) {
+                const int cc = c + u * kCg;
+                if (cc >= C) break;
+                // same summation order as before; absent taps contribute exact zeros
+                A acc = v[u][0] * wnw;
+                acc += v[u][1] * wne;
+                acc += v[u][2] * wsw;
+                acc += v[u][3] * wse;
+                st(dst + cc * plane, acc);
+            }
+        }
     }
-    const A x0f = floor(cx.pos), y0f = floor(cy.pos);
-    const A x1f = x0f + A(1), y1f = y0f + A(1);
-    const A wnw = (x1f - cx.pos) * (y1f - cy.pos);
-    const A wne = (cx.pos - x0f) * (y1f - cy.pos);
-    const A wsw = (x1f - cx.pos) * (cy.pos - y0f);
-    const A wse = (cx.pos - x0f) * (cy.pos - y0f);
-    const int x0 = static_cast<int>(x0f), y0 = static_cast<int>(y0f);
-    const bool okx0 = x0 >= 0 && x0 < W, okx1 = x0 + 1 >= 0 && x0 + 1 < W;
-    const bool oky0 = y0 >= 0 && y0 < H, oky1 = y0 + 1 >= 0 && y0 + 1 < H;
-    const int64_t o00 = static_cast<int64_t>(y0) * W + x0;
-    constexpr int kU = 4;  // channels per trip: 16 independent taps in flight per lane
-    for (int c = cg; c < C; c += kU * kCg) {
-        A v[kU][4];
-#pragma unroll
-        for (int u = 0; u < kU; ++u) {
-            const int cc = min(c + u * kCg, C - 1);
-            const T *q = img + cc * plane + o00;
-            load_taps<PAIR, T, A>(q, oky0 && okx0, oky0 && okx1, v[u][0], v[u][1]);
-            load_taps<PAIR, T, A>(q + W, oky1 && okx0, oky1 && okx1, v[u][2], v[u][3]);
+    if (ctx && cg == 0) {   // one wave per workgroup publishes; every slot < gridDim.x is written
+        wave_max2(ext_x, ext_y);
+        if (lane == 0) {
+            int *e = static_cast<int *>(ctx) + 2 * blockIdx.x;
+            e[0] = ext_x; e[1] = ext_y;
         }
-#pragma unroll
-        for (int u = 0; u < kU; ++u) {
-            const int cc = c + u * kCg;
-            if (cc >= C) break;
-            // same summation order as before; absent taps contribute exact zeros
-            A acc = v[u][0] * wnw;
-            acc += v[u][1] * wne;
-            acc += v[u][2] * wsw;
-            acc += v[u][3] * wse;
-            st(dst + cc * plane, acc);
+    }
+}
+
+// Context from the flow alone (backward called without a forward context).
+__global__ __launch_bounds__(256) void warp_context_kernel(const float *__restrict__ flow,
+                                                            void *__restrict__ ctx, int B, int H,
+                                                            int W, int pad_mode) {
+    __shared__ int red[4][2];
+    const int64_t plane = static_cast<int64_t>(H) * W;
+    const int64_t total = static_cast<int64_t>(B) * plane;
+    int ext_x = 0, ext_y = 0;
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; i < total;
+         i += static_cast<int64_t>(gridDim.x) * 256) {
+        const int b = static_cast<int>(i / plane);
+        const int64_t p = i % plane;
+        const int y = static_cast<int>(p / W), x = static_cast<int>(p % W);
+        const float *fl = flow + static_cast<int64_t>(b) * 2 * plane + p;
+        const Coord<float> cx = source_coord<float>(x, fl[0], W, pad_mode);
+        const Coord<float> cy = source_coord<float>(y, fl[plane], H, pad_mode);
+        float *pos = ctx_pos(ctx) + static_cast<int64_t>(b) * 2 * plane + p;
+        pos[0] = cx.pos;
+        pos[plane] = cy.pos;
+        const int x0 = static_cast<int>(floorf(cx.pos)), y0 = static_cast<int>(floorf(cy.pos));
+        const bool okx = (x0 >= 0 && x0 < W) || (x0 + 1 >= 0 && x0 + 1 < W);
+        const bool oky = (y0 >= 0 && y0 < H) || (y0 + 1 >= 0 && y0 + 1 < H);
+        if (okx && oky) {
+            ext_x = max(ext_x, max(abs(x0 - x), abs(x0 + 1 - x)));
+            ext_y = max(ext_y, max(abs(y0 - y), abs(y0 + 1 - y)));
         }
+    }
+    wave_max2(ext_x, ext_y);
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0] = ext_x; red[threadIdx.x >> 6][1] = ext_y; }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        int *e = static_cast<int *>(ctx) + 2 * blockIdx.x;
+        e[threadIdx.x] = max(max(red[0][threadIdx.x], red[1][threadIdx.x]),
+                             max(red[2][threadIdx.x], red[3][threadIdx.x]));
     }
 }
 
@@ -182,48 +273,67 @@ template <typename H16> __device__ __forceinline__ void atomic_accumulate_16(H16
 __device__ __forceinline__ void atomic_accumulate(__half *p, float v) { atomic_accumulate_16(p, v); }
 __device__ __forceinline__ void atomic_accumulate(hip_bfloat16 *p, float v) { atomic_accumulate_16(p, v); }
 
-// ---- tap extent -------------------------------------------------------------
-// The owner-computes image-gradient kernel below needs to know how far a sample can
-// land from its own pixel.  Every backward call measures it on the device (max over
-// all pixels that have at least one in-image tap of the tap distance, per axis) into
-// a 2-int workspace; no host round trip, so the sequence stays graph-capturable.
-// Wave-level max of three non-negative ints (tap extent x/y, |gradOutput| bits).
-__device__ __forceinline__ void wave_max3(int &a, int &b, int &c) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
-        a = max(a, __shfl_xor(a, m, 64));
-        b = max(b, __shfl_xor(b, m, 64));
-        c = max(c, __shfl_xor(c, m, 64));
-    }
-}
-// One thread per workgroup publishes; the plain read first keeps thousands of
-// workgroups from serialising on the same three words (a stale read only costs a
-// redundant atomic, never a lost maximum).
-__device__ __forceinline__ void publish_max(int *ws, int v) {
-    if (v > *reinterpret_cast<volatile int *>(ws)) atomicMax(ws, v);
-}
+// ---- backward, per-pixel kernel ---------------------------------------------------
+// grad_flow by a deterministic gather (+ optionally grad_image by global float atomics, as
+// ATen does).  Three uses:
+//   * the whole backward when the tiled path does not apply (no workspace, not fp32);
+//   * grad_flow alone when grad_image is not wanted;
+//   * the LAST launch of the tiled path (`fin` set): normally it only sums the per-channel-
+//     split grad_flow partials the tile kernel left in the workspace; if that kernel
+//     flagged a tap extent beyond its window (fin.flag != 0) it ran nothing but a zero
+//     fill, and this launch does the full job by scatter on top of the zeros.
+struct WarpFinish {
+    const int *flag;          // workspace word: 0 = tiles did the work
+    const float *gflow_part;  // [nsplit][B][2][H][W]
+    const float *pos;         // context sample positions [B][2][H][W]
+    int nsplit;
+};
 
 template <typename T, bool PAIR, int kCg>
 __global__ __launch_bounds__(kPix * kCg) void warp_bwd_kernel(
     const T *__restrict__ image, const T *__restrict__ flow, const T *__restrict__ gout,
-    T *__restrict__ gimage, T *__restrict__ gflow, int *__restrict__ extent_ws,
-    const int *__restrict__ gate_ws, int C, int H, int W, int pad_mode) {
+    T *__restrict__ gimage, T *__restrict__ gflow, WarpFinish fin, int B, int C, int H, int W,
+    int pad_mode) {
     using A = typename Acc<T>::type;
-    // gate: when the tiled kernel handled grad_image (extent within its window) this
-    // launch is only the scatter fallback and has nothing to do
-    if (gate_ws && gate_ws[0] <= kMaxExtent && gate_ws[1] <= kMaxExtent) return;  // tiles did it
     __shared__ A part[kCg][2][kPix];
-    __shared__ int wmax[kCg][3];
     const int64_t plane = static_cast<int64_t>(H) * W;
     const int lane = threadIdx.x & (kPix - 1);
     const int cg = threadIdx.x / kPix;
     const int64_t p = static_cast<int64_t>(blockIdx.x) * kPix + lane;
     const int b = blockIdx.y;
     const bool live = p < plane;
+    if (fin.flag && *fin.flag == 0) {
+        if constexpr (sizeof(T) == 4) {
+            if (!gflow) return;
+            // wave cg sums the splits k = cg, cg + kCg, ... of BOTH components (independent
+            // loads, all in flight), the kCg partial sums meet in LDS in a fixed order
+            float sx = 0.f, sy = 0.f;
+            const int64_t comp = static_cast<int64_t>(b) * 2 * plane + (live ? p : 0);
+            for (int k = cg; k < fin.nsplit; k += kCg) {
+                const float *gp = fin.gflow_part + static_cast<int64_t>(k) * B * 2 * plane + comp;
+                sx += gp[0];
+                sy += gp[plane];
+            }
+            part[cg][0][lane] = sx;
+            part[cg][1][lane] = sy;
+            __syncthreads();
+            if (live && cg < 2) {   // cg 0: x component, cg 1: y component
+                float sum = 0.f;
+#pragma unroll
+                for (int k = 0; k < kCg; ++k) sum += part[k][cg][lane];
+                const int size = cg == 0 ? W : H;
+                const float pos = fin.pos[comp + cg * plane];
+                float mult = static_cast<float>(size) / 2.0f;
+                if (pad_mode == CERB_PAD_BORDER && (pos <= 0.f || pos >= static_cast<float>(size - 1)))
+                    mult = 0.f;   // clip_coordinates_set_grad, from the clamped position
+                // autograd order: grad_grid = mult * sum ; through norm_grid: / (size-1) then * 2.0
+                st(gflow + comp + cg * plane, mult * sum / static_cast<float>(size - 1) * 2.0f);
+            }
+        }
+        return;
+    }
     A gix = 0, giy = 0;
     Coord<A> cx{0, 0}, cy{0, 0};
-    int ex = 0, ey = 0;
-    float gmax = 0.f;
     if (live) {
         const int y = static_cast<int>(p / W), x = static_cast<int>(p % W);
         const T *fl = flow + static_cast<int64_t>(b) * 2 * plane + p;
@@ -240,10 +350,6 @@ __global__ __launch_bounds__(kPix * kCg) void warp_bwd_kernel(
         const bool oky0 = y0 >= 0 && y0 < H, oky1 = y0 + 1 >= 0 && y0 + 1 < H;
         const int64_t o00 = static_cast<int64_t>(y0) * W + x0;
         const int64_t base = static_cast<int64_t>(b) * C * plane;
-        if ((okx0 || okx1) && (oky0 || oky1)) {
-            ex = max(abs(x0 - x), abs(x0 + 1 - x));
-            ey = max(abs(y0 - y), abs(y0 + 1 - y));
-        }
         // kU channels per trip: all loads of a trip are issued before any is consumed
         constexpr int kU = 4;
         for (int c = cg; c < C; c += kU * kCg) {
@@ -264,7 +370,6 @@ __global__ __launch_bounds__(kPix * kCg) void warp_bwd_kernel(
             for (int u = 0; u < kU; ++u) {
                 const int cc = c + u * kCg;
                 if (cc >= C) break;
-                gmax = fmaxf(gmax, fabsf(static_cast<float>(g[u])));
                 if (gimage) {
                     const int64_t q = base + cc * plane + o00;
                     if (oky0 && okx0) atomic_accumulate(gimage + q, wnw * g[u]);
@@ -281,21 +386,10 @@ __global__ __launch_bounds__(kPix * kCg) void warp_bwd_kernel(
             }
         }
     }
-    if (extent_ws) {  // whole waves participate
-        int gb = __float_as_int(gmax);
-        wave_max3(ex, ey, gb);
-        if (lane == 0) { wmax[cg][0] = ex; wmax[cg][1] = ey; wmax[cg][2] = gb; }
-    }
+    if (!gflow) return;
     part[cg][0][lane] = gix;
     part[cg][1][lane] = giy;
     __syncthreads();
-    if (extent_ws && threadIdx.x < 3) {
-        int v = 0;
-#pragma unroll
-        for (int k = 0; k < kCg; ++k) v = max(v, wmax[k][threadIdx.x]);
-        publish_max(extent_ws + threadIdx.x, v);
-    }
-    if (!gflow) return;
     if (cg == 0 && live) {
         A sx = 0, sy = 0;
 #pragma unroll
@@ -307,109 +401,268 @@ __global__ __launch_bounds__(kPix * kCg) void warp_bwd_kernel(
     }
 }
 
-// ---- grad_image, owner-computes ---------------------------------------------
-// ATen's (and our fallback's) image gradient is a global float-atomic scatter: 4
-// atomics per (pixel, channel), ~0.1 TB/s when neighbouring lanes hit different rows
-// (measured: 555 us at the 32x128x256 level).  Here a workgroup OWNS a TH x TW tile of
-// grad_image for CW channels: it scans every source pixel whose taps can reach the tile
-// (tile grown by the measured tap extent), accumulates the taps that fall inside in LDS
-// and writes the tile once with plain coalesced stores.  No global atomics, no memset,
-// every output element written exactly once.
+// ---- backward, owner-computes tiles ------------------------------------------------
+// ATen's (and our fallback's) image gradient is a global float-atomic scatter: 4 atomics
+// per (pixel, channel), ~0.1 TB/s when neighbouring lanes hit different rows (measured:
+// 555 us at the 32x128x256 level).  Here a workgroup OWNS a TH x TW tile of grad_image for
+// CW channels: it scans every source pixel whose taps can reach the tile (tile grown by the
+// tap extent from the context), accumulates the taps that fall inside in LDS and writes the
+// tile once with plain coalesced stores: no global atomics, no memset, every output element
+// written exactly once.  The same workgroup also produces the grad_flow contribution of its
+// CW channels for the tile's own pixels (the finish launch sums the channel splits).
 // The LDS accumulators are 64-bit FIXED POINT: ds_add_f32 runs at 0.3 lanes/clk/CU on
 // gfx950 (tools/ubench/lds_atomic.hip) against 6.7 for ds_add_u64.  The scale is
-// 2^(30 - exponent(max|gradOutput|)), measured on the device by the grad_flow pass:
-// every product w*g <= max|g| is an int32 with a resolution of 2^-30 of the largest
-// gradient (fp32 itself resolves 2^-24), and 2^33 of them can meet in one pixel.  Integer addition commutes, so
-// the result is bit-reproducible (ATen's and our scatter fallback's are not).
+// 2^(30 - exponent(m)), m = max|gradOutput| over the sources this workgroup adds (a block
+// reduction, pass A): every product w*g <= m is an int32 with a resolution of 2^-30 of the
+// largest gradient in the tile (fp32 itself resolves 2^-24), and 2^33 of them can meet in
+// one pixel.  Integer addition commutes, so the result is bit-reproducible (ATen's and our
+// scatter fallback's are not).
 __device__ __forceinline__ unsigned long long fixed64(float scaled) {
     return static_cast<unsigned long long>(static_cast<long long>(__float2int_rn(scaled)));
 }
 
-template <int TH, int TW, int CW>
-__global__ __launch_bounds__(256) void warp_gimage_tile_kernel(
-    const float *__restrict__ flow, const float *__restrict__ gout, float *__restrict__ gimage,
-    const int *__restrict__ ws, int C, int H, int W, int pad_mode, int tiles_x, int tiles_y,
-    int nchunk) {
-    __shared__ long long acc[CW * TH * TW + 64];  // + one dummy word per lane
-    const int tid = threadIdx.x;
+template <int TH, int TW, int CW, int NS>
+__global__ __launch_bounds__(256) void warp_bwd_tile_kernel(
+    const float *__restrict__ image, const float *__restrict__ gout, const void *__restrict__ ctx,
+    int npart, float *__restrict__ gimage, float *__restrict__ gflow_part, int *__restrict__ flag,
+    int B, int C, int H, int W, int tiles_x, int tiles_y, int nsplit, int dbg) {
+#ifndef CERB_ABLATE
+    dbg = 0;
+#endif
+    // per channel: the tile + one dummy word per lane (taps that miss the tile add 0 there)
+    constexpr int PS = TH * TW + 64;
+    __shared__ long long acc[CW * PS];
+    __shared__ int red[4][2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int bid = blockIdx.x;
-    const int chunk = bid % nchunk; bid /= nchunk;
+    const int split = bid % nsplit; bid /= nsplit;
     const int tx = bid % tiles_x; bid /= tiles_x;
     const int ty = bid % tiles_y;
     const int b = bid / tiles_y;
-    const int tx0 = tx * TW, ty0 = ty * TH, c0 = chunk * CW;
+    const int tx0 = tx * TW, ty0 = ty * TH, c0 = split * CW;
     const int cw = min(CW, C - c0);
-    const int64_t plane = static_cast<int64_t>(H) * W;
-    const int rx = ws[0], ry = ws[1];
-    const bool fallback = rx > kMaxExtent || ry > kMaxExtent;  // scatter kernel takes over
-    const float gabs = __int_as_float(ws[2]);
-    int gexp = 0;
-    frexpf(gabs, &gexp);                         // gabs < 2^gexp
-    // products land below 2^30: one v_cvt_i32_f32 per contribution (a 64-bit float->int
-    // conversion is a 12-instruction sequence), sign-extended into the 64-bit accumulator,
-    // which leaves 2^33 of headroom for taps piling up on one pixel
-    const float scale = ldexpf(1.0f, 30 - gexp);
-    const float unscale = ldexpf(1.0f, gexp - 30);
+    const int plane = H * W;
+    const float *pos = ctx_pos(ctx) + static_cast<int64_t>(b) * 2 * plane;
+    const float *go = gout + (static_cast<int64_t>(b) * C + c0) * plane;
 
-    for (int i = tid; i < CW * TH * TW; i += 256) acc[i] = 0;
-    __syncthreads();
+    // tap extent: max over the context's per-workgroup partials (first loads in flight)
+    int rx = 0, ry = 0;
+    {
+        const int2 *ext = static_cast<const int2 *>(ctx);
+        for (int i = tid; i < npart; i += 256) {
+            const int2 e = ext[i];
+            rx = max(rx, e.x); ry = max(ry, e.y);
+        }
+    }
 
-    if (!fallback) {
-        const int ys = max(0, ty0 - ry), ye = min(H, ty0 + TH + ry);
-        const int xs = max(0, tx0 - rx), xe = min(W, tx0 + TW + rx);
-        const int rw = xe - xs, n = (ye - ys) * rw;
-        const float *fl = flow + static_cast<int64_t>(b) * 2 * plane;
-        const float *go = gout + (static_cast<int64_t>(b) * C + c0) * plane;
-        for (int idx = tid; idx < n; idx += 256) {
-            const int sy = ys + idx / rw, sx = xs + idx % rw;
-            const int64_t p = static_cast<int64_t>(sy) * W + sx;
-            const Coord<float> cx = source_coord<float>(sx, fl[p], W, pad_mode);
-            const Coord<float> cy = source_coord<float>(sy, fl[plane + p], H, pad_mode);
-            const float x0f = floorf(cx.pos), y0f = floorf(cy.pos);
+    // ---- grad_flow partial of this channel split for the tile's own pixels ----
+    // Independent of the extent, so it goes first: its two round trips (positions, then
+    // gradOutput + image taps) overlap the partials read above and the LDS zeroing below.
+    // (If the extent turns out too large the finish launch recomputes grad_flow; the
+    // partials written here are then simply ignored.)
+    if (gflow_part && !(dbg & 1)) {
+        const float *im = image + (static_cast<int64_t>(b) * C + c0) * plane;
+        float *gp = gflow_part + (static_cast<int64_t>(split) * B + b) * 2 * plane;
+        constexpr int NP = TH * TW / 256;   // own pixels per thread
+        static_assert(TW == 64 && TH % 4 == 0, "lane = column, wave + 4k = row");
+        float ixp[NP], iyp[NP];
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            const int y = min(ty0 + wave + 4 * k, H - 1), x = min(tx0 + lane, W - 1);
+            ixp[k] = pos[y * W + x];
+            iyp[k] = pos[plane + y * W + x];
+        }
+#pragma unroll 2
+        for (int k = 0; k < NP; ++k) {
+            const int y = ty0 + wave + 4 * k, x = tx0 + lane;
+            const bool live = y < H && x < W;
+            const int p = min(y, H - 1) * W + min(x, W - 1);
+            const float x0f = floorf(ixp[k]), y0f = floorf(iyp[k]);
             const float x1f = x0f + 1.f, y1f = y0f + 1.f;
             const int x0 = static_cast<int>(x0f), y0 = static_cast<int>(y0f);
-            // tap (j,i) -> tile-local coordinates; keep only taps inside BOTH image and tile
-            const int lx0 = x0 - tx0, ly0 = y0 - ty0;
-            const bool ox0 = x0 >= 0 && x0 < W && lx0 >= 0 && lx0 < TW;
-            const bool ox1 = x0 + 1 >= 0 && x0 + 1 < W && lx0 + 1 >= 0 && lx0 + 1 < TW;
-            const bool oy0 = y0 >= 0 && y0 < H && ly0 >= 0 && ly0 < TH;
-            const bool oy1 = y0 + 1 >= 0 && y0 + 1 < H && ly0 + 1 >= 0 && ly0 + 1 < TH;
-            if (!((ox0 || ox1) && (oy0 || oy1))) continue;
-            const float wnw = (x1f - cx.pos) * (y1f - cy.pos);
-            const float wne = (cx.pos - x0f) * (y1f - cy.pos);
-            const float wsw = (x1f - cx.pos) * (cy.pos - y0f);
-            const float wse = (cx.pos - x0f) * (cy.pos - y0f);
-            // all CW gradOutput values first (independent loads in flight together), then
-            // branch-free LDS atomics: a tap outside the tile adds 0 to a per-lane dummy word
-            float g[CW];
+            const bool okx0 = x0 >= 0 && x0 < W, okx1 = x0 + 1 >= 0 && x0 + 1 < W;
+            const bool oky0 = y0 >= 0 && y0 < H, oky1 = y0 + 1 >= 0 && y0 + 1 < H;
+            const int o00 = y0 * W + x0;
+            float g[CW], vnw[CW], vne[CW], vsw[CW], vse[CW];
 #pragma unroll
-            for (int c = 0; c < CW; ++c) g[c] = go[min(c, cw - 1) * plane + p];
-            const int o = ly0 * TW + lx0;
-            unsigned long long *dummy =
-                reinterpret_cast<unsigned long long *>(acc) + CW * TH * TW + (tid & 63);
-            const bool v00 = oy0 && ox0, v01 = oy0 && ox1, v10 = oy1 && ox0, v11 = oy1 && ox1;
-            const float w00 = v00 ? wnw * scale : 0.f, w01 = v01 ? wne * scale : 0.f;
-            const float w10 = v10 ? wsw * scale : 0.f, w11 = v11 ? wse * scale : 0.f;
+            for (int c = 0; c < CW; ++c) {
+                const int cc = min(c, cw - 1);
+                g[c] = go[cc * plane + p];
+                const float *q = im + cc * plane + o00;
+                load_taps<false, float, float>(q, oky0 && okx0, oky0 && okx1, vnw[c], vne[c]);
+                load_taps<false, float, float>(q + W, oky1 && okx0, oky1 && okx1, vsw[c], vse[c]);
+            }
+            float gix = 0.f, giy = 0.f;
 #pragma unroll
             for (int c = 0; c < CW; ++c) {
                 if (c >= cw) break;
-                unsigned long long *a =
-                    reinterpret_cast<unsigned long long *>(acc) + c * (TH * TW) + o;
-                // two's-complement add: negative contributions wrap correctly
-                atomicAdd(v00 ? a : dummy, fixed64(w00 * g[c]));
-                atomicAdd(v01 ? a + 1 : dummy, fixed64(w01 * g[c]));
-                atomicAdd(v10 ? a + TW : dummy, fixed64(w10 * g[c]));
-                atomicAdd(v11 ? a + TW + 1 : dummy, fixed64(w11 * g[c]));
+                gix += (-vnw[c] * (y1f - iyp[k]) + vne[c] * (y1f - iyp[k]) -
+                        vsw[c] * (iyp[k] - y0f) + vse[c] * (iyp[k] - y0f)) * g[c];
+                giy += (-vnw[c] * (x1f - ixp[k]) - vne[c] * (ixp[k] - x0f) +
+                        vsw[c] * (x1f - ixp[k]) + vse[c] * (ixp[k] - x0f)) * g[c];
             }
+            if (live) { gp[p] = gix; gp[plane + p] = giy; }
         }
-        __syncthreads();
     }
+
+    wave_max2(rx, ry);
+    if (lane == 0) { red[wave][0] = rx; red[wave][1] = ry; }
+    for (int i = tid; i < CW * PS; i += 256) acc[i] = 0;
+    __syncthreads();
+    rx = max(max(red[0][0], red[1][0]), max(red[2][0], red[3][0]));
+    ry = max(max(red[0][1], red[1][1]), max(red[2][1], red[3][1]));
+    const bool fallback = rx > kMaxExtent || ry > kMaxExtent;  // the finish launch scatters
+    if (blockIdx.x == 0 && tid == 0) *flag = fallback ? 1 : 0;
+
     float *dst = gimage + (static_cast<int64_t>(b) * C + c0) * plane;
+    if (fallback) {
+        for (int i = tid; i < cw * TH * TW; i += 256) {
+            const int c = i / (TH * TW), rem = i % (TH * TW);
+            const int yy = ty0 + rem / TW, xx = tx0 + rem % TW;
+            if (yy < H && xx < W) dst[static_cast<int64_t>(c) * plane + yy * W + xx] = 0.f;
+        }
+        return;
+    }
+
+    const int ys = max(0, ty0 - ry), ye = min(H, ty0 + TH + ry);
+    const int xs = max(0, tx0 - rx), xe = min(W, tx0 + TW + rx);
+    const int rw = xe - xs, n = (ye - ys) * rw;
+    unsigned long long *acc64 = reinterpret_cast<unsigned long long *>(acc);
+    unsigned long long *dummy = acc64 + TH * TW + lane;
+
+    // One batch = up to NS sources per thread with every load in flight together (the first
+    // version walked its sources one by one -- position load -> test -> gradOutput loads ->
+    // atomics, two dependent round trips per source: pure memory latency).
+    // valid bits 0..3: nw, ne, sw, se tap lands inside image AND tile.
+    auto classify = [&](bool on, float ixj, float iyj, int &o) -> unsigned {
+        const int x0 = static_cast<int>(floorf(ixj)), y0 = static_cast<int>(floorf(iyj));
+        const int lx0 = x0 - tx0, ly0 = y0 - ty0;
+        const bool ox0 = on && x0 >= 0 && x0 < W && lx0 >= 0 && lx0 < TW;
+        const bool ox1 = on && x0 + 1 >= 0 && x0 + 1 < W && lx0 + 1 >= 0 && lx0 + 1 < TW;
+        const bool oy0 = y0 >= 0 && y0 < H && ly0 >= 0 && ly0 < TH;
+        const bool oy1 = y0 + 1 >= 0 && y0 + 1 < H && ly0 + 1 >= 0 && ly0 + 1 < TH;
+        o = ly0 * TW + lx0;
+        return (oy0 && ox0 ? 1u : 0u) | (oy0 && ox1 ? 2u : 0u) | (oy1 && ox0 ? 4u : 0u) |
+               (oy1 && ox1 ? 8u : 0u);
+    };
+    // block max of |g| -> fixed-point scale.  Products land below 2^30: one v_cvt_i32_f32 per
+    // contribution (a 64-bit float->int conversion is a 12-instruction sequence),
+    // sign-extended into the 64-bit accumulator.
+    auto block_scale = [&](float gmax, float &scale, float &unscale) {
+        int gb = __float_as_int(gmax), unused = 0;   // non-negative floats order as ints
+        wave_max2(gb, unused);
+        __syncthreads();                              // earlier red[] reads are done
+        if (lane == 0) red[wave][0] = gb;
+        __syncthreads();
+        gmax = __int_as_float(max(max(red[0][0], red[1][0]), max(red[2][0], red[3][0])));
+        int gexp = 0;
+        frexpf(gmax, &gexp);                          // gmax < 2^gexp
+        gexp = max(gexp, -90);                        // keep 2^(30-gexp) finite for denormal maxima
+        scale = ldexpf(1.0f, 30 - gexp);
+        unscale = ldexpf(1.0f, gexp - 30);
+    };
+    auto add_taps = [&](unsigned valid, int o, float ixj, float iyj, const float (&g)[CW],
+                        float scale) {
+        const float x0f = floorf(ixj), y0f = floorf(iyj);
+        const float x1f = x0f + 1.f, y1f = y0f + 1.f;
+        const float w00 = (valid & 1u) ? (x1f - ixj) * (y1f - iyj) * scale : 0.f;
+        const float w01 = (valid & 2u) ? (ixj - x0f) * (y1f - iyj) * scale : 0.f;
+        const float w10 = (valid & 4u) ? (x1f - ixj) * (iyj - y0f) * scale : 0.f;
+        const float w11 = (valid & 8u) ? (ixj - x0f) * (iyj - y0f) * scale : 0.f;
+        unsigned long long *a = acc64 + o;
+        unsigned long long *a00 = (valid & 1u) ? a : dummy;
+        unsigned long long *a01 = (valid & 2u) ? a + 1 : dummy;
+        unsigned long long *a10 = (valid & 4u) ? a + TW : dummy;
+        unsigned long long *a11 = (valid & 8u) ? a + TW + 1 : dummy;
+#pragma unroll
+        for (int c = 0; c < CW; ++c) {
+            if (c >= cw) break;
+            // two's-complement add: negative contributions wrap correctly
+            atomicAdd(a00 + c * PS, fixed64(w00 * g[c]));
+            atomicAdd(a01 + c * PS, fixed64(w01 * g[c]));
+            atomicAdd(a10 + c * PS, fixed64(w10 * g[c]));
+            atomicAdd(a11 + c * PS, fixed64(w11 * g[c]));
+        }
+    };
+
+    float scale = 1.f, unscale = 1.f;
+    if (dbg & 4) {
+    } else if (n <= 256 * NS) {
+        // ---- the whole scan fits one batch: sources stay in registers between the max
+        // reduction and the accumulation (tap extents up to ~8 px on interior tiles) ----
+        int pv[NS], o[NS];
+        float ix[NS], iy[NS], g[NS][CW];
+        unsigned valid[NS];
+#pragma unroll
+        for (int j = 0; j < NS; ++j) {
+            const int idx = min(j * 256 + tid, n - 1);  // clamped: always a valid address
+            pv[j] = (ys + idx / rw) * W + xs + idx % rw;
+            ix[j] = pos[pv[j]];
+            iy[j] = pos[plane + pv[j]];
+        }
+        float gmax = 0.f;
+#pragma unroll
+        for (int j = 0; j < NS; ++j) {
+            valid[j] = classify(j * 256 + tid < n, ix[j], iy[j], o[j]);
+#pragma unroll
+            for (int c = 0; c < CW; ++c)
+                g[j][c] = *tap_ptr(go + min(c, cw - 1) * plane + pv[j], valid[j] != 0);
+        }
+#pragma unroll
+        for (int j = 0; j < NS; ++j)
+#pragma unroll
+            for (int c = 0; c < CW; ++c) gmax = fmaxf(gmax, fabsf(g[j][c]));
+        block_scale(gmax, scale, unscale);
+        if (!(dbg & 2)) {
+#pragma unroll
+        for (int j = 0; j < NS; ++j)
+            if (valid[j]) add_taps(valid[j], o[j], ix[j], iy[j], g[j], scale);
+        }
+    } else {
+        // ---- larger extents: pass A finds the maximum, pass B reloads (L1/L2) and adds ----
+        constexpr int NB = 4;
+        float gmax = 0.f;
+        for (int pass = 0; pass < 2; ++pass) {
+            for (int base = 0; base < n; base += 256 * NB) {
+                int pv[NB], o[NB];
+                float ix[NB], iy[NB], g[NB][CW];
+                unsigned valid[NB];
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    const int idx = min(base + j * 256 + tid, n - 1);
+                    pv[j] = (ys + idx / rw) * W + xs + idx % rw;
+                    ix[j] = pos[pv[j]];
+                    iy[j] = pos[plane + pv[j]];
+                }
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    valid[j] = classify(base + j * 256 + tid < n, ix[j], iy[j], o[j]);
+#pragma unroll
+                    for (int c = 0; c < CW; ++c)
+                        g[j][c] = *tap_ptr(go + min(c, cw - 1) * plane + pv[j], valid[j] != 0);
+                }
+                if (pass == 0) {
+#pragma unroll
+                    for (int j = 0; j < NB; ++j)
+#pragma unroll
+                        for (int c = 0; c < CW; ++c) gmax = fmaxf(gmax, fabsf(g[j][c]));
+                } else {
+#pragma unroll
+                    for (int j = 0; j < NB; ++j)
+                        if (valid[j]) add_taps(valid[j], o[j], ix[j], iy[j], g[j], scale);
+                }
+            }
+            if (pass == 0) block_scale(gmax, scale, unscale);
+        }
+    }
+
+    __syncthreads();
     for (int i = tid; i < cw * TH * TW; i += 256) {
         const int c = i / (TH * TW), rem = i % (TH * TW);
         const int yy = ty0 + rem / TW, xx = tx0 + rem % TW;
         if (yy < H && xx < W)
-            dst[c * plane + static_cast<int64_t>(yy) * W + xx] = static_cast<float>(acc[i]) * unscale;
+            dst[static_cast<int64_t>(c) * plane + yy * W + xx] =
+                static_cast<float>(acc[c * PS + rem]) * unscale;
     }
 }
 
@@ -439,28 +692,52 @@ size_t dtype_size(int dtype) {
     if ((C) >= 128) { constexpr int CG = 16; __VA_ARGS__; }    \
     else { constexpr int CG = 4; __VA_ARGS__; }
 
-int warp_forward(const void *image, const void *flow, void *out, int B, int C, int H, int W,
-                 int pad_mode, int interp, int dtype, hipStream_t s) {
+int64_t warp_context_bytes(int B, int H, int W) { return ctx_bytes(B, H, W); }
+
+// number of extent partials a context of this shape holds (= workgroups of its producer)
+static int ctx_partials(int B, int H, int W) {
+    const int64_t nstrips = B * ((static_cast<int64_t>(H) * W + kPix - 1) / kPix);
+    return static_cast<int>(std::min<int64_t>(nstrips, kCtxPartials));
+}
+
+// workspace of the tiled backward: int[4] {fallback flag, pad...}, the grad_flow partials
+// float[nsplit][B][2][H][W] (nsplit = ceil(C/4) channel splits), and room for a context in
+// case the caller has none from the forward
+constexpr int kTileCW = 4;
+int64_t warp_backward_workspace_bytes(int B, int C, int H, int W) {
+    const int64_t nsplit = (C + kTileCW - 1) / kTileCW;
+    return 16 + nsplit * B * 2 * H * W * static_cast<int64_t>(sizeof(float)) + ctx_bytes(B, H, W);
+}
+
+int warp_forward(const void *image, const void *flow, void *out, void *ctx, int64_t ctx_size,
+                 int B, int C, int H, int W, int pad_mode, int interp, int dtype, hipStream_t s) {
     const int64_t plane = static_cast<int64_t>(H) * W;
     if (B == 0) return CERB_OK;
-    const dim3 grid(static_cast<unsigned>((plane + kPix - 1) / kPix), B);
+    if (ctx && (ctx_size < ctx_bytes(B, H, W) || (reinterpret_cast<uintptr_t>(ctx) & 7)))
+        return CERB_EINVAL;
+    const int64_t nstrips = B * ((plane + kPix - 1) / kPix);
+    if (nstrips > 0x7fffffff) return CERB_ETOOLARGE;
+    // with a context the grid is capped: one extent partial per workgroup (ctx_partials of them)
+    const unsigned blocks = static_cast<unsigned>(ctx ? ctx_partials(B, H, W) : nstrips);
+    const dim3 grid(blocks);
     if (option_value("warp_pair_taps") != 2) {  // default: paired taps in the forward gather
         CERB_PICK_CG(C, CERB_DISPATCH(dtype, hipLaunchKernelGGL(
             (warp_fwd_kernel<T, true, CG>), grid, dim3(kPix * CG), 0, s,
-            static_cast<const T *>(image), static_cast<const T *>(flow), static_cast<T *>(out), C, H,
-            W, pad_mode, interp)))
+            static_cast<const T *>(image), static_cast<const T *>(flow), static_cast<T *>(out), ctx,
+            B, C, H, W, pad_mode, interp)))
     } else {
         CERB_PICK_CG(C, CERB_DISPATCH(dtype, hipLaunchKernelGGL(
             (warp_fwd_kernel<T, false, CG>), grid, dim3(kPix * CG), 0, s,
-            static_cast<const T *>(image), static_cast<const T *>(flow), static_cast<T *>(out), C, H,
-            W, pad_mode, interp)))
+            static_cast<const T *>(image), static_cast<const T *>(flow), static_cast<T *>(out), ctx,
+            B, C, H, W, pad_mode, interp)))
     }
     return launch_status();
 }
 
 int warp_backward(const void *image, const void *flow, const void *gout, void *gimage,
-                  void *gflow, void *workspace, int64_t workspace_bytes, int B, int C, int H,
-                  int W, int pad_mode, int interp, int dtype, hipStream_t s) {
+                  void *gflow, const void *ctx, int64_t ctx_size, void *workspace,
+                  int64_t workspace_bytes, int B, int C, int H, int W, int pad_mode, int interp,
+                  int dtype, hipStream_t s) {
     const int64_t plane = static_cast<int64_t>(H) * W;
     if (B == 0) return CERB_OK;
     const size_t esz = dtype_size(dtype);
@@ -470,64 +747,65 @@ int warp_backward(const void *image, const void *flow, const void *gout, void *g
         // no reference caller differentiates through either.
         return CERB_EUNSUPPORTED;
     }
+    if (ctx && (ctx_size < ctx_bytes(B, H, W) || (reinterpret_cast<uintptr_t>(ctx) & 7)))
+        return CERB_EINVAL;
     const dim3 grid(static_cast<unsigned>((plane + kPix - 1) / kPix), B);
-    // tiled (owner-computes) grad_image: fp32, caller gave the 16-byte workspace
-    // (ws[0..1] tap extent x/y, ws[2] max|gradOutput| bits)
+    // tiled (owner-computes) path: fp32, grad_image wanted, caller gave the workspace
     const bool tiled = gimage && dtype == CERB_F32 && workspace &&
-                       workspace_bytes >= static_cast<int64_t>(4 * sizeof(int)) &&
-                       (reinterpret_cast<uintptr_t>(workspace) & 3) == 0;
+                       workspace_bytes >= warp_backward_workspace_bytes(B, C, H, W) &&
+                       (reinterpret_cast<uintptr_t>(workspace) & 7) == 0 &&
+                       static_cast<int64_t>(C) * plane < 0x7fffffff;
     if (tiled) {
-        int *ws = static_cast<int *>(workspace);
-        hipError_t e = hipMemsetAsync(ws, 0, 4 * sizeof(int), s);
-        if (e != hipSuccess) return static_cast<int>(e);
-        // 1. grad_flow (deterministic gather) + tap-extent reduction
-        if (option_value("warp_pair_taps") == 1) {
-            CERB_PICK_CG(C, hipLaunchKernelGGL(
-                (warp_bwd_kernel<float, true, CG>), grid, dim3(kPix * CG), 0, s,
-                static_cast<const float *>(image), static_cast<const float *>(flow),
-                static_cast<const float *>(gout), static_cast<float *>(nullptr),
-                static_cast<float *>(gflow), ws, static_cast<const int *>(nullptr), C, H, W,
-                pad_mode))
-        } else {
-            CERB_PICK_CG(C, hipLaunchKernelGGL(
-                (warp_bwd_kernel<float, false, CG>), grid, dim3(kPix * CG), 0, s,
-                static_cast<const float *>(image), static_cast<const float *>(flow),
-                static_cast<const float *>(gout), static_cast<float *>(nullptr),
-                static_cast<float *>(gflow), ws, static_cast<const int *>(nullptr), C, H, W,
-                pad_mode))
+        constexpr int TH = 16, TW = 64, CW = kTileCW;  // 34 KiB of int64 accumulators
+        int *flag = static_cast<int *>(workspace);
+        float *gflow_part = reinterpret_cast<float *>(flag + 4);
+        const int nsplit = (C + CW - 1) / CW;
+        int rc;
+        if (!ctx) {
+            // no forward context: positions + tap extents from the flow (one extra launch)
+            void *own = gflow_part + static_cast<int64_t>(nsplit) * B * 2 * plane;
+            hipLaunchKernelGGL(warp_context_kernel, dim3(ctx_partials(B, H, W)), dim3(256), 0, s,
+                               static_cast<const float *>(flow), own, B, H, W, pad_mode);
+            if ((rc = launch_status())) return rc;
+            ctx = own;
         }
-        int rc = launch_status();
-        if (rc) return rc;
-        // 2. grad_image tiles (zero-fills instead when the extent exceeds its window)
-        constexpr int TH = 16, TW = 64, CW = 4;  // 32 KiB of int64 accumulators
         const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
-        const int nchunk = (C + CW - 1) / CW;
-        const int64_t blocks = static_cast<int64_t>(B) * tiles_x * tiles_y * nchunk;
+        const int64_t blocks = static_cast<int64_t>(B) * tiles_x * tiles_y * nsplit;
+        const int npart = ctx_partials(B, H, W);
         if (blocks > 0x7fffffff) return CERB_ETOOLARGE;
-        hipLaunchKernelGGL((warp_gimage_tile_kernel<TH, TW, CW>), dim3(static_cast<unsigned>(blocks)),
-                           dim3(256), 0, s, static_cast<const float *>(flow),
-                           static_cast<const float *>(gout), static_cast<float *>(gimage), ws, C,
-                           H, W, pad_mode, tiles_x, tiles_y, nchunk);
-        rc = launch_status();
-        if (rc) return rc;
-        // 3. scatter fallback, gated on the device: returns at once unless the extent was too large
+        // 1. tiles: grad_image + grad_flow partials (zero fill + flag when the extent is too large)
+        hipLaunchKernelGGL((warp_bwd_tile_kernel<TH, TW, CW, 10>), dim3(static_cast<unsigned>(blocks)),
+                           dim3(256), 0, s, static_cast<const float *>(image),
+                           static_cast<const float *>(gout), ctx, npart,
+                           static_cast<float *>(gimage), gflow ? gflow_part : nullptr, flag, B, C,
+                           H, W, tiles_x, tiles_y, nsplit, option_value("corr_debug_ablate"));
+        if ((rc = launch_status())) return rc;
+        // 2. finish: sums the grad_flow partials; on the flag, the whole job by scatter instead
+        const WarpFinish fin{flag, gflow_part, ctx_pos(ctx), nsplit};
         hipLaunchKernelGGL((warp_bwd_kernel<float, false, 4>), grid, dim3(kPix * 4), 0, s,
                            static_cast<const float *>(image), static_cast<const float *>(flow),
                            static_cast<const float *>(gout), static_cast<float *>(gimage),
-                           static_cast<float *>(nullptr), static_cast<int *>(nullptr), ws, C, H, W,
-                           pad_mode);
+                           static_cast<float *>(gflow), fin, B, C, H, W, pad_mode);
         return launch_status();
     }
     if (gimage) {
         hipError_t e = hipMemsetAsync(gimage, 0, static_cast<size_t>(B) * C * plane * esz, s);
         if (e != hipSuccess) return static_cast<int>(e);
     }
-    CERB_DISPATCH(dtype, hipLaunchKernelGGL((warp_bwd_kernel<T, false, 4>), grid, dim3(kPix * 4), 0, s,
-                                            static_cast<const T *>(image),
-                                            static_cast<const T *>(flow),
-                                            static_cast<const T *>(gout), static_cast<T *>(gimage),
-                                            static_cast<T *>(gflow), static_cast<int *>(nullptr),
-                                            static_cast<const int *>(nullptr), C, H, W, pad_mode));
+    const WarpFinish none{nullptr, nullptr, nullptr, 0};
+    if (option_value("warp_pair_taps") == 1) {
+        CERB_PICK_CG(C, CERB_DISPATCH(dtype, hipLaunchKernelGGL(
+            (warp_bwd_kernel<T, true, CG>), grid, dim3(kPix * CG), 0, s,
+            static_cast<const T *>(image), static_cast<const T *>(flow),
+            static_cast<const T *>(gout), static_cast<T *>(gimage), static_cast<T *>(gflow), none,
+            B, C, H, W, pad_mode)))
+    } else {
+        CERB_PICK_CG(C, CERB_DISPATCH(dtype, hipLaunchKernelGGL(
+            (warp_bwd_kernel<T, false, CG>), grid, dim3(kPix * CG), 0, s,
+            static_cast<const T *>(image), static_cast<const T *>(flow),
+            static_cast<const T *>(gout), static_cast<T *>(gimage), static_cast<T *>(gflow), none,
+            B, C, H, W, pad_mode)))
+    }
     return launch_status();
 }
 

@@ -42,5 +42,9 @@ def flow_warp(image, flow12, pad='border', mode='bilinear'):
                          "'border', or 'reflection', but got: '%s'" % pad)
     if mode not in _ops.INTERP_MODES:
         raise ValueError("flow_warp: mode must be 'bilinear' or 'nearest', got '%s'" % mode)
-    return torch.ops.cerberus.flow_warp(image, flow12, _ops.PAD_MODES[pad],
-                                        _ops.INTERP_MODES[mode])
+    modes = (_ops.PAD_MODES[pad], _ops.INTERP_MODES[mode])
+    if torch.is_grad_enabled() and (image.requires_grad or flow12.requires_grad):
+        # training: the forward also saves the sample positions for the backward (what
+        # autograd's save_for_backward is to grid_sample in the reference)
+        return torch.ops.cerberus.flow_warp_ctx(image, flow12, *modes)[0]
+    return torch.ops.cerberus.flow_warp(image, flow12, *modes)

@@ -42,6 +42,10 @@ _def.define("correlation_backward(Tensor input1, Tensor input2, Tensor gradOutpu
 _def.define("correlation_leaky(Tensor input1, Tensor input2, %s, float negative_slope) "
             "-> Tensor" % _CORR_ARGS)
 _def.define("flow_warp(Tensor image, Tensor flow, int pad_mode, int interp_mode) -> Tensor")
+_def.define("flow_warp_ctx(Tensor image, Tensor flow, int pad_mode, int interp_mode) -> "
+            "(Tensor, Tensor)")
+_def.define("flow_warp_backward_ctx(Tensor image, Tensor flow, Tensor context, Tensor grad_out, "
+            "int pad_mode, int interp_mode, bool need_image, bool need_flow) -> Tensor[]")
 _def.define("flow_warp_backward(Tensor image, Tensor flow, Tensor grad_out, int pad_mode, "
             "int interp_mode, bool need_image, bool need_flow) -> Tensor[]")
 
@@ -184,27 +188,46 @@ def _warp_check(image, flow, what):
         raise RuntimeError("%s: image and flow on different devices" % what)
 
 
-def _flow_warp_cuda(image, flow, pad_mode, interp_mode):
-    what = "cerberus::flow_warp"
+def _flow_warp_run(image, flow, pad_mode, interp_mode, want_ctx, what):
     _warp_check(image, flow, what)
     code = _dtype_code(image, what)
     img = image.contiguous()
     flo = flow.to(dtype=img.dtype).contiguous()
     out = torch.empty_like(img)
-    if out.numel() == 0:
-        return out
     B, C, H, W = img.shape
+    lib = _lib.get()
+    ctx_bytes = lib.cerberus_flow_warp_context_bytes(B, H, W) if want_ctx else 0
+    # int64 elements: 8-byte aligned whatever the allocator's sub-block offset
+    ctx = torch.empty((ctx_bytes + 7) // 8, dtype=torch.int64, device=img.device) if want_ctx else None
+    if out.numel() == 0:
+        return out, ctx
     with torch.cuda.device(img.device):
-        rc = _lib.get().cerberus_flow_warp_forward(img.data_ptr(), flo.data_ptr(),
-                                                   out.data_ptr(), B, C, H, W, pad_mode,
-                                                   interp_mode, code, _stream_ptr(img))
+        rc = lib.cerberus_flow_warp_forward_ctx(
+            img.data_ptr(), flo.data_ptr(), out.data_ptr(),
+            ctx.data_ptr() if want_ctx else None, ctx_bytes, B, C, H, W, pad_mode, interp_mode,
+            code, _stream_ptr(img))
     _lib.check(rc, what)
-    return out
+    return out, ctx
 
 
-def _flow_warp_backward_cuda(image, flow, grad_out, pad_mode, interp_mode, need_image,
-                             need_flow) -> List[torch.Tensor]:
-    what = "cerberus::flow_warp_backward"
+def _flow_warp_cuda(image, flow, pad_mode, interp_mode):
+    return _flow_warp_run(image, flow, pad_mode, interp_mode, False, "cerberus::flow_warp")[0]
+
+
+def _flow_warp_ctx_cuda(image, flow, pad_mode, interp_mode):
+    """Forward that also returns the backward context (sample positions + tap extents):
+    the analogue of what autograd saves for grid_sample in the reference."""
+    return _flow_warp_run(image, flow, pad_mode, interp_mode, True, "cerberus::flow_warp_ctx")
+
+
+def _flow_warp_ctx_meta(image, flow, pad_mode, interp_mode):
+    B, _, H, W = image.shape
+    n = (2048 * 8 + B * 2 * H * W * 4 + 7) // 8
+    return torch.empty_like(image), image.new_empty((n,), dtype=torch.int64)
+
+
+def _flow_warp_backward_run(image, flow, context, grad_out, pad_mode, interp_mode, need_image,
+                            need_flow, what) -> List[torch.Tensor]:
     _warp_check(image, flow, what)
     code = _dtype_code(image, what)
     img = image.contiguous()
@@ -219,18 +242,38 @@ def _flow_warp_backward_cuda(image, flow, grad_out, pad_mode, interp_mode, need_
         return [gi, gf]
     B, C, H, W = img.shape
     lib = _lib.get()
-    # 16-byte device scratch (tap extent + max|grad_out|) (caching allocator: no sync,
-    # graph-capturable; stream-ordered reuse keeps it private to this call)
-    ws_bytes = lib.cerberus_flow_warp_backward_workspace_bytes()
-    ws = torch.empty(ws_bytes // 4, dtype=torch.int32, device=img.device) if need_image else None
+    ctx_ptr, ctx_bytes = None, 0
+    if context is not None:
+        ctx_bytes = lib.cerberus_flow_warp_context_bytes(B, H, W)
+        if (context.device != img.device or not context.is_contiguous()
+                or context.numel() * context.element_size() < ctx_bytes):
+            raise RuntimeError("%s: context does not belong to this image/flow shape" % what)
+        ctx_ptr = context.data_ptr()
+    # device scratch for the tiled grad_image (caching allocator: no sync, graph-capturable;
+    # stream-ordered reuse keeps it private to this call)
+    ws_bytes = lib.cerberus_flow_warp_backward_workspace_bytes(B, C, H, W)
+    ws = torch.empty((ws_bytes + 7) // 8, dtype=torch.int64, device=img.device) if need_image else None
     with torch.cuda.device(img.device):
         rc = lib.cerberus_flow_warp_backward(
             img.data_ptr(), flo.data_ptr(), go.data_ptr(),
             gi.data_ptr() if need_image else None, gf.data_ptr() if need_flow else None,
+            ctx_ptr, ctx_bytes,
             ws.data_ptr() if ws is not None else None, ws_bytes if ws is not None else 0,
             B, C, H, W, pad_mode, interp_mode, code, _stream_ptr(img))
     _lib.check(rc, what)
     return [gi, gf]
+
+
+def _flow_warp_backward_cuda(image, flow, grad_out, pad_mode, interp_mode, need_image,
+                             need_flow) -> List[torch.Tensor]:
+    return _flow_warp_backward_run(image, flow, None, grad_out, pad_mode, interp_mode,
+                                   need_image, need_flow, "cerberus::flow_warp_backward")
+
+
+def _flow_warp_backward_ctx_cuda(image, flow, context, grad_out, pad_mode, interp_mode,
+                                 need_image, need_flow) -> List[torch.Tensor]:
+    return _flow_warp_backward_run(image, flow, context, grad_out, pad_mode, interp_mode,
+                                   need_image, need_flow, "cerberus::flow_warp_backward_ctx")
 
 
 def _no_cpu(name):
@@ -257,6 +300,14 @@ _def.impl("flow_warp_backward",
           lambda image, flow, go, p, m, ni, nf: [torch.empty_like(image), torch.empty_like(flow)],
           "Meta")
 _def.impl("flow_warp_backward", _no_cpu("flow_warp_backward"), "CPU")
+_def.impl("flow_warp_ctx", _flow_warp_ctx_cuda, "CUDA")
+_def.impl("flow_warp_ctx", _flow_warp_ctx_meta, "Meta")
+_def.impl("flow_warp_ctx", _no_cpu("flow_warp_ctx"), "CPU")
+_def.impl("flow_warp_backward_ctx", _flow_warp_backward_ctx_cuda, "CUDA")
+_def.impl("flow_warp_backward_ctx",
+          lambda image, flow, ctx, go, p, m, ni, nf: [torch.empty_like(image),
+                                                      torch.empty_like(flow)], "Meta")
+_def.impl("flow_warp_backward_ctx", _no_cpu("flow_warp_backward_ctx"), "CPU")
 
 
 # ----------------------------------------------------------------------------
@@ -310,5 +361,28 @@ torch.library.register_autograd("cerberus::correlation", _corr_backward,
                                 setup_context=_corr_setup)
 torch.library.register_autograd("cerberus::correlation_leaky", _corr_leaky_backward,
                                 setup_context=_corr_leaky_setup)
+def _warp_ctx_setup(ctx, inputs, output):
+    image, flow, pad_mode, interp_mode = inputs
+    ctx.save_for_backward(image, flow, output[1])
+    ctx.modes = (pad_mode, interp_mode)
+    ctx.mark_non_differentiable(output[1])
+
+
+def _warp_ctx_backward(ctx, grad, _grad_context):
+    image, flow, context = ctx.saved_tensors
+    need_image, need_flow = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+    if ctx.modes[1] != INTERP_MODES["bilinear"] or ctx.modes[0] == PAD_MODES["reflection"]:
+        context = None   # unsupported combinations raise in the raw op, as before
+        gi, gf = torch.ops.cerberus.flow_warp_backward(image, flow, grad, ctx.modes[0],
+                                                       ctx.modes[1], need_image, need_flow)
+    else:
+        gi, gf = torch.ops.cerberus.flow_warp_backward_ctx(image, flow, context, grad,
+                                                           ctx.modes[0], ctx.modes[1],
+                                                           need_image, need_flow)
+    return (gi if need_image else None, gf.to(flow.dtype) if need_flow else None, None, None)
+
+
 torch.library.register_autograd("cerberus::flow_warp", _warp_backward,
                                 setup_context=_warp_setup)
+torch.library.register_autograd("cerberus::flow_warp_ctx", _warp_ctx_backward,
+                                setup_context=_warp_ctx_setup)

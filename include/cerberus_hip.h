@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define CERBERUS_HIP_ABI_VERSION 1
+#define CERBERUS_HIP_ABI_VERSION 2
 
 /* element types (AT_DISPATCH_FLOATING_TYPES_AND_HALF in the reference,
  * correlation_cuda_kernel.cu:269,303; bf16 is an extension) */
@@ -116,20 +116,35 @@ int cerberus_flow_warp_forward(const void *image, const void *flow, void *out,
                                int B, int C, int H, int W, int pad_mode,
                                int interp_mode, int dtype, void *stream);
 
+/* The same forward, additionally saving what the backward needs again (what autograd's
+ * save_for_backward is to the reference's grid_sample): every pixel's sample position and
+ * the largest distance a tap lands from its own pixel.
+ *   context : caller-owned device buffer of cerberus_flow_warp_context_bytes(B,H,W) bytes
+ *             (8-byte aligned, contents irrelevant, fully written); NULL = plain forward. */
+int64_t cerberus_flow_warp_context_bytes(int B, int H, int W);
+int cerberus_flow_warp_forward_ctx(const void *image, const void *flow, void *out,
+                                   void *context, int64_t context_bytes, int B, int C,
+                                   int H, int W, int pad_mode, int interp_mode,
+                                   int dtype, void *stream);
+
 /* flow_warp backward (autograd of the above w.r.t. image and flow).
- *   grad_image : (B,C,H,W) -- fully overwritten.  Summation order of the taps that
- *                meet in one pixel is not deterministic (float atomics, as ATen's).
+ *   grad_image : (B,C,H,W) -- fully overwritten.  With a workspace (fp32): built tile by
+ *                tile in LDS in 64-bit fixed point, no global atomics, bit-reproducible.
+ *                Without: global float atomics as ATen's (summation order not fixed).
  *   grad_flow  : (B,2,H,W) -- fully overwritten, deterministic
- *   workspace  : caller-owned device scratch of
- *                cerberus_flow_warp_backward_workspace_bytes() bytes (4-byte aligned,
- *                contents irrelevant), private to this call until it completes.  With
- *                it (fp32) grad_image is built tile by tile in LDS with no global
- *                atomics; NULL selects the global-atomic scatter (ATen's method).
+ *   context    : the buffer a cerberus_flow_warp_forward_ctx call with the SAME flow,
+ *                shape and pad_mode filled, or NULL (the backward then derives it from the
+ *                flow with one extra launch).
+ *   workspace  : caller-owned device scratch of at least
+ *                cerberus_flow_warp_backward_workspace_bytes(B,C,H,W) bytes (8-byte
+ *                aligned, contents irrelevant), private to this call until it completes.
+ *                NULL or too small selects the global-atomic scatter (ATen's method).
  * Either grad pointer may be NULL to skip that gradient. */
-int64_t cerberus_flow_warp_backward_workspace_bytes(void);
+int64_t cerberus_flow_warp_backward_workspace_bytes(int B, int C, int H, int W);
 int cerberus_flow_warp_backward(const void *image, const void *flow,
                                 const void *grad_out, void *grad_image,
-                                void *grad_flow, void *workspace,
+                                void *grad_flow, const void *context,
+                                int64_t context_bytes, void *workspace,
                                 int64_t workspace_bytes, int B, int C, int H, int W,
                                 int pad_mode, int interp_mode, int dtype,
                                 void *stream);

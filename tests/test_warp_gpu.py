@@ -154,21 +154,69 @@ def test_backward_without_workspace_uses_scatter_and_matches():
     gf = torch.full_like(flo, 7.0)
     rc = _lib.get().cerberus_flow_warp_backward(
         img.data_ptr(), flo.data_ptr(), go.data_ptr(), gi.data_ptr(), gf.data_ptr(), None, 0,
-        1, 6, 20, 36, 1, 0, 0, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        None, 0, 1, 6, 20, 36, 1, 0, 0,
+        ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
     assert rc == 0
     torch.cuda.synchronize()
     _, rgi, rgf = oracle.flow_warp_grads_ref(img.cpu(), flo.cpu(), go.cpu(), "border")
     assert rel_err(gi.cpu().numpy(), rgi.numpy()) < TOL
     assert rel_err(gf.cpu().numpy(), rgf.numpy()) < TOL
     # and only one of the two gradients
+    # a workspace that is too small is not an error either: same scatter path
     gi2 = torch.full_like(img, 7.0)
-    ws = torch.empty(4, dtype=torch.int32, device=DEV)
+    ws = torch.empty(2, dtype=torch.int64, device=DEV)
     rc = _lib.get().cerberus_flow_warp_backward(
-        img.data_ptr(), flo.data_ptr(), go.data_ptr(), gi2.data_ptr(), None, ws.data_ptr(), 16,
-        1, 6, 20, 36, 1, 0, 0, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        img.data_ptr(), flo.data_ptr(), go.data_ptr(), gi2.data_ptr(), None, None, 0,
+        ws.data_ptr(), 16, 1, 6, 20, 36, 1, 0, 0,
+        ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
     assert rc == 0
     torch.cuda.synchronize()
     assert rel_err(gi2.cpu().numpy(), rgi.numpy()) < TOL
+    # full workspace, no context: tiled path with the context derived from the flow
+    need = _lib.get().cerberus_flow_warp_backward_workspace_bytes(1, 6, 20, 36)
+    ws = torch.empty((need + 7) // 8, dtype=torch.int64, device=DEV)
+    gi3, gf3 = torch.full_like(img, 7.0), torch.full_like(flo, 7.0)
+    rc = _lib.get().cerberus_flow_warp_backward(
+        img.data_ptr(), flo.data_ptr(), go.data_ptr(), gi3.data_ptr(), gf3.data_ptr(), None, 0,
+        ws.data_ptr(), need, 1, 6, 20, 36, 1, 0, 0,
+        ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert rel_err(gi3.cpu().numpy(), rgi.numpy()) < TOL
+    assert rel_err(gf3.cpu().numpy(), rgf.numpy()) < TOL
+    # a context of the wrong size is rejected
+    rc = _lib.get().cerberus_flow_warp_backward(
+        img.data_ptr(), flo.data_ptr(), go.data_ptr(), gi3.data_ptr(), gf3.data_ptr(),
+        ws.data_ptr(), 64, ws.data_ptr(), need, 1, 6, 20, 36, 1, 0, 0,
+        ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == -1
+
+
+@pytest.mark.parametrize("amp", [0.4, 6.0, 40.0])
+@pytest.mark.parametrize("shape", [(2, 12, 80, 136), (1, 5, 17, 70), (3, 32, 32, 64)])
+def test_forward_context_path_equals_the_contextless_path(amp, shape):
+    """Training saves the sample positions in the forward (flow_warp_ctx) and the backward
+    reuses them; the raw backward derives them from the flow.  Same kernels, same numbers:
+    outputs and both gradients must agree bit for bit, in the tiled regime and in the
+    scatter fallback's grad_flow (large flows; its grad_image is atomic-ordered)."""
+    B, C, H, W = shape
+    img, go = dev(hash_uniform(shape, 51)), dev(hash_uniform(shape, 53))
+    flo = dev(hash_uniform((B, 2, H, W), 52, -amp, amp))
+    out0 = torch.ops.cerberus.flow_warp(img, flo, 1, 0)
+    out1, ctx = torch.ops.cerberus.flow_warp_ctx(img, flo, 1, 0)
+    assert torch.equal(out0, out1)
+    gi0, gf0 = torch.ops.cerberus.flow_warp_backward(img, flo, go, 1, 0, True, True)
+    gi1, gf1 = torch.ops.cerberus.flow_warp_backward_ctx(img, flo, ctx, go, 1, 0, True, True)
+    assert torch.equal(gf0, gf1)
+    if amp < 30:
+        assert torch.equal(gi0, gi1)
+    else:
+        assert rel_err(gi0.cpu().numpy(), gi1.cpu().numpy()) < TOL
+    _, rgi, rgf = oracle.flow_warp_grads_ref(img.cpu(), flo.cpu(), go.cpu(), "border")
+    assert rel_err(gi1.cpu().numpy(), rgi.numpy()) < TOL
+    assert rel_err(gf1.cpu().numpy(), rgf.numpy()) < TOL
+    with pytest.raises(RuntimeError, match="context"):
+        torch.ops.cerberus.flow_warp_backward_ctx(img, flo, ctx[:8], go, 1, 0, True, True)
 
 
 @pytest.mark.parametrize("mag", [1e-20, 1.0, 3e18, 0.0])
