@@ -69,13 +69,18 @@ class Workload:
         up = up + torch.from_numpy(hash_uniform((pairs, 2, H, W), seed + 100, -0.25, 0.25))
         return up.contiguous().to(device)
 
-    def __init__(self, pairs, width, height, device, flow_kind="smooth", fuse=False):
+    def __init__(self, pairs, width, height, device, flow_kind="smooth", fuse=False, chains=1):
         from cerberusnet_amd.synth import hash_uniform, pyramid_shapes
         import cerberusnet_amd  # noqa: F401  registers torch.ops.cerberus.*
         self.levels = pyramid_shapes(width, height, 32)
         self.pairs = pairs
         self.dirs = []
-        for direction in range(2):
+        if pairs % chains:
+            raise SystemExit("--chains must divide --pairs")
+        pairs = pairs // chains
+        # `chains` > 1: every direction's batch is split into that many independent
+        # sub-batches (the op is stateless and batch items never interact)
+        for direction in range(2 * chains):
             lv = []
             for l, (C, H, W) in enumerate(self.levels):
                 seed = 16 * direction + 4 * l
@@ -140,12 +145,13 @@ class Workload:
                 self._direction(lv, keep)
             return keep
         main = torch.cuda.current_stream()
-        side = streams[0]
-        side.wait_stream(main)
-        with torch.cuda.stream(side):
-            self._direction(self.dirs[1], keep)
+        for side, lv in zip(streams, self.dirs[1:]):
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                self._direction(lv, keep)
         self._direction(self.dirs[0], keep)
-        main.wait_stream(side)
+        for side in streams[:len(self.dirs) - 1]:
+            main.wait_stream(side)
         return keep
 
 
@@ -250,6 +256,9 @@ def main():
                     help="stack both flow directions into one batched call per op")
     ap.add_argument("--serial-directions", action="store_true",
                     help="issue both flow directions on one stream (default: two streams)")
+    ap.add_argument("--chains", type=int, default=1,
+                    help="split each direction's batch into this many independent sub-batches, "
+                         "one HIP stream each")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--probe-steps", type=int, default=20)
     ap.add_argument("--flow", choices=["smooth", "noise"], default="smooth",
@@ -274,10 +283,12 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)  # RCCL
 
-    wl = Workload(args.pairs, args.width, args.height, device, args.flow, args.fuse_directions)
+    wl = Workload(args.pairs, args.width, args.height, device, args.flow, args.fuse_directions,
+                  args.chains)
 
     # ---- warm-up (eager), then capture the step into a hipGraph ----
-    streams = None if args.serial_directions else [torch.cuda.Stream()]
+    streams = None if args.serial_directions else [torch.cuda.Stream()
+                                                   for _ in range(max(1, len(wl.dirs) - 1))]
     for _ in range(max(1, args.warmup if args.no_graph else 3)):
         wl.step(streams)
     torch.cuda.synchronize()
@@ -332,7 +343,9 @@ def main():
                 "flow_field": args.flow,
                 "launch": ("hipGraph replay" if graph is not None else "eager") +
                           (", directions fused into one batched call" if args.fuse_directions else
-                           ", 2 streams (one per flow direction)" if streams else ", 1 stream"),
+                           ", %d streams (one per flow direction%s)" % (
+                               len(streams) + 1, " and sub-batch" if args.chains > 1 else "")
+                           if streams else ", 1 stream"),
                 "sharding": "image pairs sharded over ranks, no data-path collective",
                 "algorithmic_bytes_per_step": step_bytes,
                 "step_algorithmic_GBps_per_gpu": round(step_bytes * args.steps / elapsed / 1e9, 1),

@@ -22,7 +22,7 @@ def label(name):
         return "corr_bwd_L3"
     if "warp_fwd" in name:
         return "warp_fwd_L3"
-    if "warp_gimage_tile" in name or "warp_bwd" in name or "fillBuffer" in name:
+    if "warp_bwd" in name:   # tile kernel + finish kernel
         return "warp_bwd_L3"
     return None
 
@@ -46,7 +46,7 @@ with open("%s/%s_pmc_counters.csv" % (out_dir, tag), "w") as f:
 
 REPS = 5  # tools/prof_kernels.py --reps
 traffic = {"_note": "bytes per op call at 4 pairs, level 3 (32x128x256); read = 2*FETCH_SIZE KiB "
-                    "(gfx950 correction), write = WRITE_SIZE KiB; warp_bwd sums its 3 kernels + memset"}
+                    "(gfx950 correction), write = WRITE_SIZE KiB; warp_bwd sums its tile + finish kernels"}
 for lab, ctr in per_dispatch.items():
     if "FETCH_SIZE" in ctr and "WRITE_SIZE" in ctr:
         rd = 2.0 * sum(ctr["FETCH_SIZE"]) / REPS * 1024.0

@@ -31,11 +31,12 @@ for lvl in [int(x) for x in args.levels.split(",")]:
     x1 = torch.from_numpy(hash_uniform((B, C, H, W), 1)).to(dev)
     x2 = torch.from_numpy(hash_uniform((B, C, H, W), 2)).to(dev)
     go = torch.from_numpy(hash_uniform((B, 81, H, W), 3)).to(dev)
-    fl = torch.from_numpy(hash_uniform((B, 2, H, W), 4, -6.0, 6.0)).to(dev)
+    from bench import Workload
+    fl = Workload._flow(B, H, W, 4, "smooth", dev)   # the bench's flow field
     for _ in range(args.reps):
         ops.correlation(x1, x2, *P)
         ops.correlation_backward(x1, x2, go, *P)
         if args.warp:
-            w = ops.flow_warp(x2, fl, 1, 0)
-            ops.flow_warp_backward(x2, fl, w, 1, 0, True, True)
+            w, ctx = ops.flow_warp_ctx(x2, fl, 1, 0)
+            ops.flow_warp_backward_ctx(x2, fl, ctx, w, 1, 0, True, True)
     torch.cuda.synchronize()
