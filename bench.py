@@ -197,6 +197,48 @@ def per_kernel_times(wl, reps):
     return out
 
 
+def torch_gpu_reference(wl, budget_s=4.0):
+    """the same step with the op swapped for stock PyTorch on the SAME
+    device -- CorrelationTorch (correlation.py:4-21, the reference's own fallback) + autograd, and
+    the reference's flow_warp composition (mesh + norm_grid + F.grid_sample) + autograd.  Context
+    only (what a user gets without the HIP kernels); not the product and not the oracle."""
+    import torch.nn.functional as F
+    from cerberusnet_amd.correlation_package.correlation import CorrelationTorch
+    from cerberusnet_amd.loss_functions.UnFlowLoss import mesh_grid, norm_grid
+    corr = CorrelationTorch(4)
+
+    def one_step():
+        for lv in wl.dirs:
+            for l, t in enumerate(lv):
+                f1 = t["f1"].detach().requires_grad_(True)
+                f2 = t["f2"].detach().requires_grad_(True)
+                ins = [f1, f2]
+                if l > 0:
+                    flow = t["flow"].detach().requires_grad_(True)
+                    b, _, h, w = f2.shape
+                    grid = norm_grid(mesh_grid(b, h, w).type_as(f2) + flow)
+                    warped = F.grid_sample(f2, grid, mode="bilinear", padding_mode="border",
+                                           align_corners=False)
+                    ins.append(flow)
+                else:
+                    warped = f2
+                torch.autograd.grad(corr(f1, warped), ins, t["gout"])
+
+    one_step()
+    torch.cuda.synchronize()
+    n, t0 = 0, time.perf_counter()
+    while True:
+        one_step()
+        torch.cuda.synchronize()
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt > budget_s or n >= 50:
+            break
+    return {"value": round(wl.pairs * n / dt, 2), "unit": "image-pairs/s",
+            "what": "same tensors and op sequence in stock PyTorch ops on this GPU (CorrelationTorch + "
+                    "F.grid_sample + autograd, eager), %d steps in %.1f s" % (n, dt)}
+
+
 def cpu_baseline(levels, budget_s=12.0):
     """Reference CPU path: CorrelationTorch semantics (oracle port) forward +
     autograd backward on the B=1 pyramid, both directions = one image pair."""
@@ -389,6 +431,10 @@ def main():
         except Exception:  # diagnostics only
             pass
         if not args.no_cpu_baseline and world == 1:
+            try:
+                result["torch_gpu_reference"] = torch_gpu_reference(wl)
+            except Exception as exc:  # context only: never fail the bench line on it
+                result["torch_gpu_reference"] = {"error": repr(exc)[:200]}
             result["cpu_baseline"] = cpu_baseline(wl.levels)
         elif not args.no_cpu_baseline:
             result["cpu_baseline"] = None

@@ -1017,32 +1017,37 @@ __global__ __launch_bounds__(K::THREADS, 2) void corr_bwd_d4_dma_kernel(
     float2v g0p[kND][4], g1p[kND][4];
     float g0s[kND], g1s[kND];
     {
-        // branch-free gather, see corr_bwd_d4_kernel
-        const int lane_off = live ? y * W + x : 0;
-        unsigned ymask = 0, xmask0 = 0, xmask1 = 0;
+        // branch-free gather as in corr_bwd_d4_kernel, through a buffer resource: the
+        // displacement's plane/shift is the SCALAR offset, the lane's pixel the vector offset,
+        // and a tap outside the image is an out-of-range vector offset (reads 0) -- one
+        // v_cndmask per value instead of a 64-bit pointer select (the gather is ~1300 VALU
+        // instructions per wave at 2 waves/SIMD otherwise)
+        const __amdgpu_buffer_rsrc_t rsrc_go = uniform_rsrc(gob, kND * kND * plane * 4);
+        const int lane_byte = live ? (y * W + x) * 4 : kDead;
+        // ONE load site per value for both sides (two sites writing the same registers made
+        // hipcc load into temporaries and shuffle them under shallow counted waits): side 0
+        // is the same gather with every shift 0 and every tap valid.
+        int vx0[kND], vx1[kND];   // per horizontal displacement: byte offset or "outside"
+        bool oky[kND];
 #pragma unroll
         for (int k = 0; k < kND; ++k) {
-            const int yy = y + k - kD, xx = x + k - kD;
-            if (yy >= 0 && yy < H) ymask |= 1u << k;
-            if (xx >= 0 && xx < W) xmask0 |= 1u << k;
-            if (xx + 1 >= 0 && xx + 1 < W) xmask1 |= 1u << k;
+            const int yy = side ? y + k - kD : y, xx = side ? x + k - kD : x;
+            oky[k] = live && yy >= 0 && yy < H;
+            vx0[k] = (xx >= 0 && xx < W) ? lane_byte : kDead;
+            vx1[k] = (xx + 1 >= 0 && xx + 1 < W) ? lane_byte + 4 : kDead;
         }
-        if (!live) ymask = 0;
 #pragma unroll
         for (int d = 0; d < kND * kND; ++d) {
             const int dyi = d / kND, dxi = d % kND;
-            float v0, v1;
-            if (side == 0) {  // wave-uniform
-                const float2 t = Gmem<float>::load2(gob + static_cast<int64_t>(d) * plane + lane_off);
-                v0 = t.x; v1 = t.y;
-            } else {
-                const int uni = (kND * kND - 1 - d) * plane + (dyi - kD) * W + (dxi - kD);
-                const bool oky = (ymask >> dyi) & 1u;
-                const bool ok0 = oky && ((xmask0 >> dxi) & 1u);
-                const bool ok1 = oky && ((xmask1 >> dxi) & 1u);
-                v0 = Gmem<float>::load1(ok0 ? gob + (uni + lane_off) : g_zero16);
-                v1 = Gmem<float>::load1(ok1 ? gob + (uni + lane_off + 1) : g_zero16);
-            }
+            // side 0: gO[d][y][x (+1)];  side 1: gO[80-d][y+dy][x+dx (+1)], whose scalar offset
+            // is never negative (80-d >= 9*(8-dyi))
+            // (arithmetic on the 0/1 side instead of a select: hipcc turns scalar selects into branches)
+            const int soff = ((d + side * (kND * kND - 1 - 2 * d)) * plane +
+                              side * ((dyi - kD) * W + (dxi - kD))) * 4;
+            const float v0 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                 rsrc_go, oky[dyi] ? vx0[dxi] : kDead, soff, 0));
+            const float v1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                 rsrc_go, oky[dyi] ? vx1[dxi] : kDead, soff, 0));
             if (dxi == 8) g0s[dyi] = v0; else if (dxi & 1) g0p[dyi][dxi / 2].y = v0; else g0p[dyi][dxi / 2].x = v0;
             if (dxi == 0) g1s[dyi] = v1; else if (dxi & 1) g1p[dyi][(dxi - 1) / 2].x = v1; else g1p[dyi][(dxi - 1) / 2].y = v1;
         }

@@ -395,3 +395,42 @@ def test_half_storage_takes_the_tuned_kernels(dtype, tol, lvl):
     assert _lib.last_kernel(0) == "corr_fwd_generic"
     refo = oracle.corr_forward_ref(xo1.double().cpu().numpy(), xo2.double().cpu().numpy(), *p)
     assert rel_err(outo.double().cpu().numpy(), refo) < tol
+
+
+CONFIG5_PYRAMID_2048x1024 = [(256, 32, 64), (128, 64, 128), (64, 128, 256), (32, 256, 512)]
+
+
+@pytest.mark.parametrize("lvl", [0, 1, 2, 3])
+def test_config5_fp16_level_shapes_at_full_size(lvl):
+    """BASELINE config 5 (AMP fp16, 2048x1024 -> W32 levels) at its full level sizes, B = 1.
+    The CPU oracle is too slow there, so: (i) the fp16 result must equal the fp32 kernels run
+    on the same fp16-rounded inputs up to the fp16 rounding of the output (both accumulate in
+    fp32), (ii) the adjoint identity <corr(x1,x2), gO> pairing with the gradients, and (iii) a
+    full-size window of the output against the C oracle."""
+    C, H, W = CONFIG5_PYRAMID_2048x1024[lvl]
+    shp = (1, C, H, W)
+    x1 = torch.from_numpy(hash_uniform(shp, 61)).half().to(DEV)
+    x2 = torch.from_numpy(hash_uniform(shp, 62)).half().to(DEV)
+    go = torch.from_numpy(hash_uniform((1, 81, H, W), 63)).half().to(DEV)
+    p = (4, 1, 4, 1, 1, 1)
+    out = torch.ops.cerberus.correlation(x1, x2, *p)
+    assert _lib.last_kernel(0).startswith("corr_fwd_d4"), _lib.last_kernel(0)
+    g1, g2 = torch.ops.cerberus.correlation_backward(x1, x2, go, *p)
+    assert _lib.last_kernel(1).startswith("corr_bwd_d4"), _lib.last_kernel(1)
+    o32 = torch.ops.cerberus.correlation(x1.float(), x2.float(), *p)
+    h1, h2 = torch.ops.cerberus.correlation_backward(x1.float(), x2.float(), go.float(), *p)
+    for a, b in ((out, o32), (g1, h1), (g2, h2)):
+        scale = float(b.abs().max())
+        assert float((a.float() - b).abs().max()) <= 1.5e-3 * scale   # fp16 output rounding
+    # (ii) <corr(x1,x2), gO> = <x1, g1> = <x2, g2> (bilinear form), in fp64 on the fp32 results
+    lhs = float((o32.double() * go.double()).sum())
+    r1 = float((x1.double() * h1.double()).sum())
+    r2 = float((x2.double() * h2.double()).sum())
+    mag = float((o32.double() * go.double()).abs().sum())
+    assert abs(lhs - r1) <= 1e-6 * mag and abs(lhs - r2) <= 1e-6 * mag
+    # (iii) a corner window (includes the zero padding) against the C oracle
+    hh, ww = min(H, 24), min(W, 40)
+    ref = oracle.corr_forward_ref(x1[..., :hh + 4, :ww + 4].double().cpu().numpy(),
+                                  x2[..., :hh + 4, :ww + 4].double().cpu().numpy(), 4, 1, 4, 1, 1)
+    got = o32[..., :hh, :ww].double().cpu().numpy()
+    assert rel_err(got, ref[..., :hh, :ww]) < TOL
