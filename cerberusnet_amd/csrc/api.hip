@@ -13,7 +13,9 @@ Option g_options[] = {{"corr_force_generic", {0}},   // 1: always use the generi
                       {"corr_fwd_variant", {0}},     // 0: auto, 1..8: force a register-staged variant, 9: LDS-DMA
                       {"corr_bwd_cslice", {0}},      // 0: auto, else channels per backward workgroup
                       {"corr_debug_ablate", {0}},    // timing ablation mask (WRONG results when != 0)
-                      {"warp_pair_taps", {0}},       // 0: default, 1: pairs everywhere, 2: none
+                      {"warp_pair_taps", {0}},
+                             // 0: default, 1: pairs everywhere, 2: none
+                      {"warp_tile_cw", {0}},         // 0: auto, 4 / 8: channels per warp-backward tile workgroup
                       {"corr_bwd_variant", {0}}};    // 0: auto, 1: all-81 per lane, 2/3: 3 dy groups, 4: LDS-DMA
 thread_local const char *t_last_kernel[2] = {"none", "none"};
 

@@ -930,8 +930,7 @@ __device__ __forceinline__ void bwd_dma_step(
         for (int dyi = 0; dyi < kND; ++dyi) {
             float2v w[5];
 #pragma unroll
-            for (int q = 0; q < 5; ++q)
-                w[q] = (dbg & 8) ? float2v{inv_nelems, inv_nelems} : ld2v_nomerge(wp + dyi * K::RS + 2 * q);
+            for (int q = 0; q < 5; ++q) w[q] = ld2v_nomerge(wp + dyi * K::RS + 2 * q);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 a0[dyi % 3] = pkfma(g0p[dyi][j], w[j], a0[dyi % 3]);

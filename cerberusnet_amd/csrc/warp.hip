@@ -28,8 +28,6 @@ namespace cerb {
 namespace {
 
 constexpr int kPix = 64;         // pixels per workgroup = one wavefront
-constexpr int kMaxExtent = 32;   // largest tap distance the tiled grad_image kernel scans for
-                                 // (16 -> 32: the scatter fallback is 5-8x slower on diverging flows)
 
 template <typename A> struct Coord {
     A pos;   // source index after unnormalise + padding
@@ -209,18 +207,20 @@ __global__ __launch_bounds__(kPix * kCg) void warp_fwd_kernel(
     }
 }
 
-// Context from the flow alone (backward called without a forward context).
-__global__ __launch_bounds__(256) void warp_context_kernel(const float *__restrict__ flow,
-                                                            void *__restrict__ ctx, int B, int H,
-                                                            int W, int pad_mode) {
-    __shared__ int red[4][2];
+// Context from the flow alone (backward called without a forward context): same strip ->
+// workgroup mapping as the forward, one wavefront per workgroup.
+__global__ __launch_bounds__(kPix) void warp_context_kernel(const float *__restrict__ flow,
+                                                             void *__restrict__ ctx, int B, int H,
+                                                             int W, int pad_mode) {
     const int64_t plane = static_cast<int64_t>(H) * W;
-    const int64_t total = static_cast<int64_t>(B) * plane;
+    const int lane = threadIdx.x;
+    const int spp = static_cast<int>((plane + kPix - 1) / kPix);
+    const int64_t nstrips = static_cast<int64_t>(B) * spp;
     int ext_x = 0, ext_y = 0;
-    for (int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; i < total;
-         i += static_cast<int64_t>(gridDim.x) * 256) {
-        const int b = static_cast<int>(i / plane);
-        const int64_t p = i % plane;
+    for (int64_t strip = blockIdx.x; strip < nstrips; strip += gridDim.x) {
+        const int b = static_cast<int>(strip / spp);
+        const int64_t p = (strip % spp) * kPix + lane;
+        if (p >= plane) continue;
         const int y = static_cast<int>(p / W), x = static_cast<int>(p % W);
         const float *fl = flow + static_cast<int64_t>(b) * 2 * plane + p;
         const Coord<float> cx = source_coord<float>(x, fl[0], W, pad_mode);
@@ -237,12 +237,9 @@ __global__ __launch_bounds__(256) void warp_context_kernel(const float *__restri
         }
     }
     wave_max2(ext_x, ext_y);
-    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0] = ext_x; red[threadIdx.x >> 6][1] = ext_y; }
-    __syncthreads();
-    if (threadIdx.x < 2) {
+    if (lane == 0) {
         int *e = static_cast<int *>(ctx) + 2 * blockIdx.x;
-        e[threadIdx.x] = max(max(red[0][threadIdx.x], red[1][threadIdx.x]),
-                             max(red[2][threadIdx.x], red[3][threadIdx.x]));
+        e[0] = ext_x; e[1] = ext_y;
     }
 }
 
@@ -275,25 +272,12 @@ __device__ __forceinline__ void atomic_accumulate(hip_bfloat16 *p, float v) { at
 
 // ---- backward, per-pixel kernel ---------------------------------------------------
 // grad_flow by a deterministic gather (+ optionally grad_image by global float atomics, as
-// ATen does).  Three uses:
-//   * the whole backward when the tiled path does not apply (no workspace, not fp32);
-//   * grad_flow alone when grad_image is not wanted;
-//   * the LAST launch of the tiled path (`fin` set): normally it only sums the per-channel-
-//     split grad_flow partials the tile kernel left in the workspace; if that kernel
-//     flagged a tap extent beyond its window (fin.flag != 0) it ran nothing but a zero
-//     fill, and this launch does the full job by scatter on top of the zeros.
-struct WarpFinish {
-    const int *flag;          // workspace word: 0 = tiles did the work
-    const float *gflow_part;  // [nsplit][B][2][H][W]
-    const float *pos;         // context sample positions [B][2][H][W]
-    int nsplit;
-};
-
+// ATen does).  Used when the tiled path does not apply (no workspace, not fp32) and for
+// grad_flow alone when grad_image is not wanted.
 template <typename T, bool PAIR, int kCg>
 __global__ __launch_bounds__(kPix * kCg) void warp_bwd_kernel(
     const T *__restrict__ image, const T *__restrict__ flow, const T *__restrict__ gout,
-    T *__restrict__ gimage, T *__restrict__ gflow, WarpFinish fin, int B, int C, int H, int W,
-    int pad_mode) {
+    T *__restrict__ gimage, T *__restrict__ gflow, int B, int C, int H, int W, int pad_mode) {
     using A = typename Acc<T>::type;
     __shared__ A part[kCg][2][kPix];
     const int64_t plane = static_cast<int64_t>(H) * W;
@@ -302,36 +286,6 @@ __global__ __launch_bounds__(kPix * kCg) void warp_bwd_kernel(
     const int64_t p = static_cast<int64_t>(blockIdx.x) * kPix + lane;
     const int b = blockIdx.y;
     const bool live = p < plane;
-    if (fin.flag && *fin.flag == 0) {
-        if constexpr (sizeof(T) == 4) {
-            if (!gflow) return;
-            // wave cg sums the splits k = cg, cg + kCg, ... of BOTH components (independent
-            // loads, all in flight), the kCg partial sums meet in LDS in a fixed order
-            float sx = 0.f, sy = 0.f;
-            const int64_t comp = static_cast<int64_t>(b) * 2 * plane + (live ? p : 0);
-            for (int k = cg; k < fin.nsplit; k += kCg) {
-                const float *gp = fin.gflow_part + static_cast<int64_t>(k) * B * 2 * plane + comp;
-                sx += gp[0];
-                sy += gp[plane];
-            }
-            part[cg][0][lane] = sx;
-            part[cg][1][lane] = sy;
-            __syncthreads();
-            if (live && cg < 2) {   // cg 0: x component, cg 1: y component
-                float sum = 0.f;
-#pragma unroll
-                for (int k = 0; k < kCg; ++k) sum += part[k][cg][lane];
-                const int size = cg == 0 ? W : H;
-                const float pos = fin.pos[comp + cg * plane];
-                float mult = static_cast<float>(size) / 2.0f;
-                if (pad_mode == CERB_PAD_BORDER && (pos <= 0.f || pos >= static_cast<float>(size - 1)))
-                    mult = 0.f;   // clip_coordinates_set_grad, from the clamped position
-                // autograd order: grad_grid = mult * sum ; through norm_grid: / (size-1) then * 2.0
-                st(gflow + comp + cg * plane, mult * sum / static_cast<float>(size - 1) * 2.0f);
-            }
-        }
-        return;
-    }
     A gix = 0, giy = 0;
     Coord<A> cx{0, 0}, cy{0, 0};
     if (live) {
@@ -402,37 +356,36 @@ __global__ __launch_bounds__(kPix * kCg) void warp_bwd_kernel(
 }
 
 // ---- backward, owner-computes tiles ------------------------------------------------
-// ATen's (and our fallback's) image gradient is a global float-atomic scatter: 4 atomics
-// per (pixel, channel), ~0.1 TB/s when neighbouring lanes hit different rows (measured:
-// 555 us at the 32x128x256 level).  Here a workgroup OWNS a TH x TW tile of grad_image for
-// CW channels: it scans every source pixel whose taps can reach the tile (tile grown by the
-// tap extent from the context), accumulates the taps that fall inside in LDS and writes the
-// tile once with plain coalesced stores: no global atomics, no memset, every output element
-// written exactly once.  The same workgroup also produces the grad_flow contribution of its
-// CW channels for the tile's own pixels (the finish launch sums the channel splits).
+// ATen's image gradient is a global float-atomic scatter: 4 atomics per (pixel, channel),
+// ~0.1 TB/s when neighbouring lanes hit different rows (measured: 555 us at the 32x128x256
+// level).  Here a workgroup OWNS a TH x TW tile of grad_image for CW channels: it scans every
+// source pixel whose taps can reach the tile (the strips of the context whose own tap extent
+// reaches it), accumulates the taps that fall inside in LDS and writes the tile once with
+// plain coalesced stores: no global atomics, no memset, every output element written exactly
+// once, ONE launch for grad_image and grad_flow.
 // The LDS accumulators are 64-bit FIXED POINT: ds_add_f32 runs at 0.3 lanes/clk/CU on
 // gfx950 (tools/ubench/lds_atomic.hip) against 6.7 for ds_add_u64.  The scale is
 // 2^(30 - exponent(m)), m = max|gradOutput| over the sources this workgroup adds (a block
-// reduction, pass A): every product w*g <= m is an int32 with a resolution of 2^-30 of the
-// largest gradient in the tile (fp32 itself resolves 2^-24), and 2^33 of them can meet in
-// one pixel.  Integer addition commutes, so the result is bit-reproducible (ATen's and our
-// scatter fallback's are not).
+// reduction): every product w*g <= m is an int32 with a resolution of 2^-30 of the largest
+// gradient in the tile (fp32 itself resolves 2^-24), and 2^33 of them can meet in one pixel.
+// Integer addition commutes, so the result is bit-reproducible (ATen's is not).
 __device__ __forceinline__ unsigned long long fixed64(float scaled) {
     return static_cast<unsigned long long>(static_cast<long long>(__float2int_rn(scaled)));
 }
 
 template <int TH, int TW, int CW, int NS>
-__global__ __launch_bounds__(256) void warp_bwd_tile_kernel(
+__global__ __launch_bounds__(256, CW <= 4 ? 4 : 2) void warp_bwd_tile_kernel(
     const float *__restrict__ image, const float *__restrict__ gout, const void *__restrict__ ctx,
-    int npart, float *__restrict__ gimage, float *__restrict__ gflow_part, int *__restrict__ flag,
-    int B, int C, int H, int W, int tiles_x, int tiles_y, int nsplit, int dbg) {
+    int npart, float *__restrict__ gimage, float *__restrict__ gflow, int B, int C, int H, int W,
+    int tiles_x, int tiles_y, int nsplit, int pad_mode, int dbg) {
 #ifndef CERB_ABLATE
     dbg = 0;
 #endif
     // per channel: the tile + one dummy word per lane (taps that miss the tile add 0 there)
     constexpr int PS = TH * TW + 64;
     __shared__ long long acc[CW * PS];
-    __shared__ int red[4][2];
+    __shared__ int red[4][6];
+    __shared__ float gfl[256][2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int bid = blockIdx.x;
     const int split = bid % nsplit; bid /= nsplit;
@@ -445,88 +398,124 @@ __global__ __launch_bounds__(256) void warp_bwd_tile_kernel(
     const float *pos = ctx_pos(ctx) + static_cast<int64_t>(b) * 2 * plane;
     const float *go = gout + (static_cast<int64_t>(b) * C + c0) * plane;
 
-    // tap extent: max over the context's per-workgroup partials (first loads in flight)
-    int rx = 0, ry = 0;
+    // ---- scan region of THIS tile (first loads in flight) ----
+    // The context holds one tap extent per 64-pixel strip (per forward workgroup).  A strip
+    // matters to this tile only if its own extent reaches it, so a fast object widens the
+    // scan of the tiles around it and nobody else's -- there is no global limit and no
+    // fallback.  (Contexts of more than kCtxPartials strips fold strips j, j+npart, ... into
+    // one partial: the test stays conservative.)
+    int rx0 = W, rx1 = -1, ry0 = H, ry1 = -1;   // bounding box of the contributing strips
+    int emx = 0, emy = 0;                        // largest extent among them
     {
         const int2 *ext = static_cast<const int2 *>(ctx);
-        for (int i = tid; i < npart; i += 256) {
-            const int2 e = ext[i];
-            rx = max(rx, e.x); ry = max(ry, e.y);
+        const int spp = (plane + kPix - 1) / kPix;   // strips per image
+        for (int j = tid; j < spp; j += 256) {
+            const int2 e = ext[(b * spp + j) % npart];
+            const int p0 = j * kPix, p1 = min(p0 + kPix, plane) - 1;
+            const int sy0 = p0 / W, sy1 = p1 / W;
+            const int sx0 = sy0 == sy1 ? p0 % W : 0, sx1 = sy0 == sy1 ? p1 % W : W - 1;
+            const bool hit = (e.x | e.y) != 0 && sx0 - e.x < tx0 + TW && sx1 + e.x >= tx0 &&
+                             sy0 - e.y < ty0 + TH && sy1 + e.y >= ty0;
+            if (hit) {
+                rx0 = min(rx0, sx0); rx1 = max(rx1, sx1);
+                ry0 = min(ry0, sy0); ry1 = max(ry1, sy1);
+                emx = max(emx, e.x); emy = max(emy, e.y);
+            }
         }
     }
 
-    // ---- grad_flow partial of this channel split for the tile's own pixels ----
-    // Independent of the extent, so it goes first: its two round trips (positions, then
-    // gradOutput + image taps) overlap the partials read above and the LDS zeroing below.
-    // (If the extent turns out too large the finish launch recomputes grad_flow; the
-    // partials written here are then simply ignored.)
-    if (gflow_part && !(dbg & 1)) {
-        const float *im = image + (static_cast<int64_t>(b) * C + c0) * plane;
-        float *gp = gflow_part + (static_cast<int64_t>(split) * B + b) * 2 * plane;
-        constexpr int NP = TH * TW / 256;   // own pixels per thread
-        static_assert(TW == 64 && TH % 4 == 0, "lane = column, wave + 4k = row");
-        float ixp[NP], iyp[NP];
-#pragma unroll
-        for (int k = 0; k < NP; ++k) {
-            const int y = min(ty0 + wave + 4 * k, H - 1), x = min(tx0 + lane, W - 1);
-            ixp[k] = pos[y * W + x];
-            iyp[k] = pos[plane + y * W + x];
-        }
-#pragma unroll 2
-        for (int k = 0; k < NP; ++k) {
-            const int y = ty0 + wave + 4 * k, x = tx0 + lane;
-            const bool live = y < H && x < W;
+    // ---- grad_flow of this workgroup's share of the tile's own pixels, ALL channels ----
+    // The nsplit workgroups of a tile split its pixels (not the channels) for this part, so
+    // every pixel's channel sum is finished here: no partials, no second launch.  Independent
+    // of the scan region, so it goes first: its two round trips (positions, then gradOutput
+    // + image taps) overlap the strip read above and the LDS zeroing below.
+    if (gflow && !(dbg & 1)) {
+        const float *im = image + static_cast<int64_t>(b) * C * plane;
+        const float *gob = gout + static_cast<int64_t>(b) * C * plane;
+        const int ppw = (TH * TW + nsplit - 1) / nsplit;     // own pixels per workgroup
+        int ppad = 1;
+        while (ppad < ppw && ppad < 256) ppad <<= 1;         // pixels per round (power of two)
+        const int ncg = 256 / ppad;                           // channel groups
+        const int m = tid % ppad, cgi = tid / ppad;
+        for (int r0 = 0; r0 < ppw; r0 += ppad) {
+            const int q = split * ppw + r0 + m;               // tile-linear pixel
+            const int y = ty0 + q / TW, x = tx0 + q % TW;
+            const bool live = r0 + m < ppw && q < TH * TW && y < H && x < W;
             const int p = min(y, H - 1) * W + min(x, W - 1);
-            const float x0f = floorf(ixp[k]), y0f = floorf(iyp[k]);
+            const float ixp = pos[p], iyp = pos[plane + p];
+            const float x0f = floorf(ixp), y0f = floorf(iyp);
             const float x1f = x0f + 1.f, y1f = y0f + 1.f;
             const int x0 = static_cast<int>(x0f), y0 = static_cast<int>(y0f);
             const bool okx0 = x0 >= 0 && x0 < W, okx1 = x0 + 1 >= 0 && x0 + 1 < W;
             const bool oky0 = y0 >= 0 && y0 < H, oky1 = y0 + 1 >= 0 && y0 + 1 < H;
             const int o00 = y0 * W + x0;
-            float g[CW], vnw[CW], vne[CW], vsw[CW], vse[CW];
-#pragma unroll
-            for (int c = 0; c < CW; ++c) {
-                const int cc = min(c, cw - 1);
-                g[c] = go[cc * plane + p];
-                const float *q = im + cc * plane + o00;
-                load_taps<false, float, float>(q, oky0 && okx0, oky0 && okx1, vnw[c], vne[c]);
-                load_taps<false, float, float>(q + W, oky1 && okx0, oky1 && okx1, vsw[c], vse[c]);
-            }
             float gix = 0.f, giy = 0.f;
+            constexpr int kU = 8;  // channels per trip: 40 independent loads in flight per lane
+            for (int c = cgi; c < C; c += kU * ncg) {
+                float g[kU], vnw[kU], vne[kU], vsw[kU], vse[kU];
 #pragma unroll
-            for (int c = 0; c < CW; ++c) {
-                if (c >= cw) break;
-                gix += (-vnw[c] * (y1f - iyp[k]) + vne[c] * (y1f - iyp[k]) -
-                        vsw[c] * (iyp[k] - y0f) + vse[c] * (iyp[k] - y0f)) * g[c];
-                giy += (-vnw[c] * (x1f - ixp[k]) - vne[c] * (ixp[k] - x0f) +
-                        vsw[c] * (x1f - ixp[k]) + vse[c] * (ixp[k] - x0f)) * g[c];
+                for (int u = 0; u < kU; ++u) {
+                    const int cc = c + u * ncg;
+                    const bool on = cc < C;
+                    const int64_t cp = static_cast<int64_t>(on ? cc : c) * plane;
+                    g[u] = *tap_ptr(gob + cp + p, on);
+                    const float *qd = im + cp + o00;
+                    load_taps<false, float, float>(qd, oky0 && okx0, oky0 && okx1, vnw[u], vne[u]);
+                    load_taps<false, float, float>(qd + W, oky1 && okx0, oky1 && okx1, vsw[u], vse[u]);
+                }
+#pragma unroll
+                for (int u = 0; u < kU; ++u) {
+                    gix += (-vnw[u] * (y1f - iyp) + vne[u] * (y1f - iyp) - vsw[u] * (iyp - y0f) +
+                            vse[u] * (iyp - y0f)) * g[u];
+                    giy += (-vnw[u] * (x1f - ixp) - vne[u] * (ixp - x0f) + vsw[u] * (x1f - ixp) +
+                            vse[u] * (ixp - x0f)) * g[u];
+                }
             }
-            if (live) { gp[p] = gix; gp[plane + p] = giy; }
+            gfl[tid][0] = gix;
+            gfl[tid][1] = giy;
+            __syncthreads();
+            if (cgi == 0 && live) {
+                float sx = 0.f, sy = 0.f;
+                for (int k = 0; k < ncg; ++k) { sx += gfl[m + k * ppad][0]; sy += gfl[m + k * ppad][1]; }
+                // clip_coordinates_set_grad from the clamped position, then autograd's order:
+                // grad_grid = mult * sum ; through norm_grid: / (size-1) then * 2.0
+                float mx = static_cast<float>(W) / 2.0f, my = static_cast<float>(H) / 2.0f;
+                if (pad_mode == CERB_PAD_BORDER) {
+                    if (ixp <= 0.f || ixp >= static_cast<float>(W - 1)) mx = 0.f;
+                    if (iyp <= 0.f || iyp >= static_cast<float>(H - 1)) my = 0.f;
+                }
+                float *gf = gflow + static_cast<int64_t>(b) * 2 * plane + p;
+                gf[0] = mx * sx / static_cast<float>(W - 1) * 2.0f;
+                gf[plane] = my * sy / static_cast<float>(H - 1) * 2.0f;
+            }
+            __syncthreads();
         }
     }
+    if (!gimage) return;
 
-    wave_max2(rx, ry);
-    if (lane == 0) { red[wave][0] = rx; red[wave][1] = ry; }
+    // region = (tile grown by the largest contributing extent) within (bounding box of the
+    // contributing strips): workgroup-wide min / max
+#pragma unroll
+    for (int msk = 32; msk >= 1; msk >>= 1) {
+        rx0 = min(rx0, __shfl_xor(rx0, msk, 64)); rx1 = max(rx1, __shfl_xor(rx1, msk, 64));
+        ry0 = min(ry0, __shfl_xor(ry0, msk, 64)); ry1 = max(ry1, __shfl_xor(ry1, msk, 64));
+        emx = max(emx, __shfl_xor(emx, msk, 64)); emy = max(emy, __shfl_xor(emy, msk, 64));
+    }
+    if (lane == 0) {
+        red[wave][0] = rx0; red[wave][1] = rx1; red[wave][2] = ry0; red[wave][3] = ry1;
+        red[wave][4] = emx; red[wave][5] = emy;
+    }
     for (int i = tid; i < CW * PS; i += 256) acc[i] = 0;
     __syncthreads();
-    rx = max(max(red[0][0], red[1][0]), max(red[2][0], red[3][0]));
-    ry = max(max(red[0][1], red[1][1]), max(red[2][1], red[3][1]));
-    const bool fallback = rx > kMaxExtent || ry > kMaxExtent;  // the finish launch scatters
-    if (blockIdx.x == 0 && tid == 0) *flag = fallback ? 1 : 0;
+    emx = max(max(red[0][4], red[1][4]), max(red[2][4], red[3][4]));
+    emy = max(max(red[0][5], red[1][5]), max(red[2][5], red[3][5]));
+    const int xs = max(min(min(red[0][0], red[1][0]), min(red[2][0], red[3][0])), tx0 - emx);
+    const int xe = min(max(max(red[0][1], red[1][1]), max(red[2][1], red[3][1])) + 1, tx0 + TW + emx);
+    const int ys = max(min(min(red[0][2], red[1][2]), min(red[2][2], red[3][2])), ty0 - emy);
+    const int ye = min(max(max(red[0][3], red[1][3]), max(red[2][3], red[3][3])) + 1, ty0 + TH + emy);
+    const int rw = max(xe - xs, 0), n = rw * max(ye - ys, 0);
 
     float *dst = gimage + (static_cast<int64_t>(b) * C + c0) * plane;
-    if (fallback) {
-        for (int i = tid; i < cw * TH * TW; i += 256) {
-            const int c = i / (TH * TW), rem = i % (TH * TW);
-            const int yy = ty0 + rem / TW, xx = tx0 + rem % TW;
-            if (yy < H && xx < W) dst[static_cast<int64_t>(c) * plane + yy * W + xx] = 0.f;
-        }
-        return;
-    }
-
-    const int ys = max(0, ty0 - ry), ye = min(H, ty0 + TH + ry);
-    const int xs = max(0, tx0 - rx), xe = min(W, tx0 + TW + rx);
-    const int rw = xe - xs, n = (ye - ys) * rw;
     unsigned long long *acc64 = reinterpret_cast<unsigned long long *>(acc);
     unsigned long long *dummy = acc64 + TH * TW + lane;
 
@@ -586,7 +575,7 @@ __global__ __launch_bounds__(256) void warp_bwd_tile_kernel(
     };
 
     float scale = 1.f, unscale = 1.f;
-    if (dbg & 4) {
+    if ((dbg & 4) || n == 0) {   // nothing lands in this tile: it is written as zeros
     } else if (n <= 256 * NS) {
         // ---- the whole scan fits one batch: sources stay in registers between the max
         // reduction and the accumulation (tap extents up to ~8 px on interior tiles) ----
@@ -700,13 +689,12 @@ static int ctx_partials(int B, int H, int W) {
     return static_cast<int>(std::min<int64_t>(nstrips, kCtxPartials));
 }
 
-// workspace of the tiled backward: int[4] {fallback flag, pad...}, the grad_flow partials
-// float[nsplit][B][2][H][W] (nsplit = ceil(C/4) channel splits), and room for a context in
-// case the caller has none from the forward
+// workspace of the tiled backward: 16 reserved bytes + room for a context in case the caller
+// has none from the forward
 constexpr int kTileCW = 4;
 int64_t warp_backward_workspace_bytes(int B, int C, int H, int W) {
-    const int64_t nsplit = (C + kTileCW - 1) / kTileCW;
-    return 16 + nsplit * B * 2 * H * W * static_cast<int64_t>(sizeof(float)) + ctx_bytes(B, H, W);
+    (void)C;
+    return 16 + ctx_bytes(B, H, W);
 }
 
 int warp_forward(const void *image, const void *flow, void *out, void *ctx, int64_t ctx_size,
@@ -756,55 +744,56 @@ int warp_backward(const void *image, const void *flow, const void *gout, void *g
                        (reinterpret_cast<uintptr_t>(workspace) & 7) == 0 &&
                        static_cast<int64_t>(C) * plane < 0x7fffffff;
     if (tiled) {
-        constexpr int TH = 16, TW = 64, CW = kTileCW;  // 34 KiB of int64 accumulators
-        int *flag = static_cast<int *>(workspace);
-        float *gflow_part = reinterpret_cast<float *>(flag + 4);
-        const int nsplit = (C + CW - 1) / CW;
+        constexpr int TH = 16, TW = 64;
         int rc;
         if (!ctx) {
             // no forward context: positions + tap extents from the flow (one extra launch)
-            void *own = gflow_part + static_cast<int64_t>(nsplit) * B * 2 * plane;
-            hipLaunchKernelGGL(warp_context_kernel, dim3(ctx_partials(B, H, W)), dim3(256), 0, s,
+            void *own = static_cast<char *>(workspace) + 16;
+            hipLaunchKernelGGL(warp_context_kernel, dim3(ctx_partials(B, H, W)), dim3(kPix), 0, s,
                                static_cast<const float *>(flow), own, B, H, W, pad_mode);
             if ((rc = launch_status())) return rc;
             ctx = own;
         }
         const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
-        const int64_t blocks = static_cast<int64_t>(B) * tiles_x * tiles_y * nsplit;
+        const int64_t tiles = static_cast<int64_t>(B) * tiles_x * tiles_y;
         const int npart = ctx_partials(B, H, W);
+        // channels per workgroup: 4 (34 KiB of int64 accumulators, 4 workgroups per CU); 8 halves
+        // the redundant scanning but measured slower at every level (44 vs 50 us at level 3)
+        const bool cw8 = option_value("warp_tile_cw") == 8;
+        const int nsplit = cw8 ? (C + 7) / 8 : (C + 3) / 4;
+        const int64_t blocks = tiles * nsplit;
         if (blocks > 0x7fffffff) return CERB_ETOOLARGE;
-        // 1. tiles: grad_image + grad_flow partials (zero fill + flag when the extent is too large)
-        hipLaunchKernelGGL((warp_bwd_tile_kernel<TH, TW, CW, 10>), dim3(static_cast<unsigned>(blocks)),
-                           dim3(256), 0, s, static_cast<const float *>(image),
-                           static_cast<const float *>(gout), ctx, npart,
-                           static_cast<float *>(gimage), gflow ? gflow_part : nullptr, flag, B, C,
-                           H, W, tiles_x, tiles_y, nsplit, option_value("corr_debug_ablate"));
-        if ((rc = launch_status())) return rc;
-        // 2. finish: sums the grad_flow partials; on the flag, the whole job by scatter instead
-        const WarpFinish fin{flag, gflow_part, ctx_pos(ctx), nsplit};
-        hipLaunchKernelGGL((warp_bwd_kernel<float, false, 4>), grid, dim3(kPix * 4), 0, s,
-                           static_cast<const float *>(image), static_cast<const float *>(flow),
-                           static_cast<const float *>(gout), static_cast<float *>(gimage),
-                           static_cast<float *>(gflow), fin, B, C, H, W, pad_mode);
+        // ONE launch: grad_image tiles + grad_flow
+        if (cw8)
+            hipLaunchKernelGGL((warp_bwd_tile_kernel<TH, TW, 8, 5>), dim3(static_cast<unsigned>(blocks)),
+                               dim3(256), 0, s, static_cast<const float *>(image),
+                               static_cast<const float *>(gout), ctx, npart,
+                               static_cast<float *>(gimage), static_cast<float *>(gflow), B, C, H,
+                               W, tiles_x, tiles_y, nsplit, pad_mode, option_value("corr_debug_ablate"));
+        else
+            hipLaunchKernelGGL((warp_bwd_tile_kernel<TH, TW, 4, 10>), dim3(static_cast<unsigned>(blocks)),
+                               dim3(256), 0, s, static_cast<const float *>(image),
+                               static_cast<const float *>(gout), ctx, npart,
+                               static_cast<float *>(gimage), static_cast<float *>(gflow), B, C, H,
+                               W, tiles_x, tiles_y, nsplit, pad_mode, option_value("corr_debug_ablate"));
         return launch_status();
     }
     if (gimage) {
         hipError_t e = hipMemsetAsync(gimage, 0, static_cast<size_t>(B) * C * plane * esz, s);
         if (e != hipSuccess) return static_cast<int>(e);
     }
-    const WarpFinish none{nullptr, nullptr, nullptr, 0};
     if (option_value("warp_pair_taps") == 1) {
         CERB_PICK_CG(C, CERB_DISPATCH(dtype, hipLaunchKernelGGL(
             (warp_bwd_kernel<T, true, CG>), grid, dim3(kPix * CG), 0, s,
             static_cast<const T *>(image), static_cast<const T *>(flow),
-            static_cast<const T *>(gout), static_cast<T *>(gimage), static_cast<T *>(gflow), none,
-            B, C, H, W, pad_mode)))
+            static_cast<const T *>(gout), static_cast<T *>(gimage), static_cast<T *>(gflow), B, C,
+            H, W, pad_mode)))
     } else {
         CERB_PICK_CG(C, CERB_DISPATCH(dtype, hipLaunchKernelGGL(
             (warp_bwd_kernel<T, false, CG>), grid, dim3(kPix * CG), 0, s,
             static_cast<const T *>(image), static_cast<const T *>(flow),
-            static_cast<const T *>(gout), static_cast<T *>(gimage), static_cast<T *>(gflow), none,
-            B, C, H, W, pad_mode)))
+            static_cast<const T *>(gout), static_cast<T *>(gimage), static_cast<T *>(gflow), B, C,
+            H, W, pad_mode)))
     }
     return launch_status();
 }

@@ -157,6 +157,7 @@ int cerberus_flow_warp_backward(const void *image, const void *flow,
  *                          2/3 = three displacement groups, 4 = LDS-DMA (fp32, W % 4 == 0)
  *   "corr_bwd_cslice"    : 0 = auto, else channels per backward workgroup
  *   "warp_pair_taps"     : warp gather variant (0 default, 1 paired everywhere, 2 unpaired)
+ *   "warp_tile_cw"       : channels per warp-backward tile workgroup (0 auto, 4, 8)
  * Returns CERB_EINVAL for an unknown key. */
 int cerberus_set_option(const char *key, int value);
 int cerberus_get_option(const char *key, int *value);

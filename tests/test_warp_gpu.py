@@ -241,3 +241,21 @@ def test_tiled_grad_image_fixed_point_is_scale_free_and_deterministic(mag):
         assert rel_err(a.double().cpu().numpy() / mag, rgi.numpy()) < TOL
     c, _ = torch.ops.cerberus.flow_warp_backward(i, f, g * 8.0, 1, 0, True, False)
     assert torch.equal(c, a * 8.0)
+
+
+def test_backward_with_more_strips_than_context_partials():
+    """More than 2048 64-pixel strips: the forward folds several strips into one extent
+    partial (grid-stride); the tile kernel's reach test must stay conservative."""
+    shape = (1, 4, 300, 520)     # 2438 strips; W not a multiple of 64: strips straddle rows
+    img, go = dev(hash_uniform(shape, 71)), dev(hash_uniform(shape, 73))
+    flo = hash_uniform((1, 2, 300, 520), 72, -3.0, 3.0)
+    flo[0, :, 100:140, 200:260] += 45.0          # one fast object: only nearby tiles scan wide
+    flo = dev(flo)
+    out, ctx = torch.ops.cerberus.flow_warp_ctx(img, flo, 1, 0)
+    gi, gf = torch.ops.cerberus.flow_warp_backward_ctx(img, flo, ctx, go, 1, 0, True, True)
+    gi0, gf0 = torch.ops.cerberus.flow_warp_backward(img, flo, go, 1, 0, True, True)
+    assert torch.equal(gi, gi0) and torch.equal(gf, gf0)
+    ref, rgi, rgf = oracle.flow_warp_grads_ref(img.cpu(), flo.cpu(), go.cpu(), "border")
+    assert rel_err(out.cpu().numpy(), ref.numpy()) < TOL
+    assert rel_err(gi.cpu().numpy(), rgi.numpy()) < TOL
+    assert rel_err(gf.cpu().numpy(), rgf.numpy()) < TOL

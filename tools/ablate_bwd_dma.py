@@ -15,9 +15,8 @@ x1 = torch.from_numpy(hash_uniform((B, C, H, W), 1)).cuda()
 x2 = torch.from_numpy(hash_uniform((B, C, H, W), 2)).cuda()
 go = torch.from_numpy(hash_uniform((B, 81, H, W), 3)).cuda()
 _lib.set_option("corr_bwd_variant", 4)
-names = {0: "full", 64: "launch only", 32: "prologue + gather", 2: "no DMA in loop", 4: "no LDS reads/FMA",
-         8: "FMA without LDS reads", 1: "no stores", 2 + 4 + 1: "gather + empty loop (barriers)",
-         2 + 8: "no DMA, no LDS reads", 2 + 1 + 8: "FMA only"}
+names = {0: "full", 64: "launch only", 32: "prologue + gather", 2: "no DMA in loop", 1: "no stores",
+         3: "no DMA, no stores", 4: "no LDS reads/FMA", 2 + 4 + 1: "gather + empty loop (barriers)"}
 for m in names:
     _lib.set_option("corr_debug_ablate", m)
     med, mn = timeit(lambda: ops.correlation_backward(x1, x2, go, *P), 20, 5)

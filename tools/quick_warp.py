@@ -11,6 +11,8 @@ from tools.tune_corr import timeit
 from bench import Workload
 ops = torch.ops.cerberus
 kind = sys.argv[1] if len(sys.argv) > 1 else "smooth"
+if len(sys.argv) > 2:
+    _lib.set_option("warp_tile_cw", int(sys.argv[2]))
 for lvl, (C, H, W) in enumerate(pyramid_shapes()):
     if lvl == 0:
         continue
