@@ -1,0 +1,99 @@
+"""hipGraph capture of a whole flow-head training step.
+
+One step of ``PWCNetHead`` (``nnet_models/pwcnet_sfd.py:163-203`` in the reference) is ~100
+small launches per direction -- warps, correlations, 1x1 and 3x3 convolutions, upsamples and
+their backward kernels -- most of them a few microseconds long at the coarse pyramid levels,
+so at small batch the step is host-launch-bound.  Everything in it is static-shape and
+stream-ordered (the HIP ops of this package allocate only through torch's caching allocator
+and never synchronise), so the whole step -- both flow directions, loss, backward and
+optionally the optimizer update -- can be captured ONCE into a hipGraph and replayed.
+
+This is plain ``torch.cuda.CUDAGraph`` (= hipGraph on ROCm) plumbing; no tracing compiler.
+"""
+from typing import Callable, List, Optional, Sequence
+
+import torch
+
+__all__ = ["GraphedFlowStep"]
+
+
+class GraphedFlowStep:
+    """Capture ``loss_fn(head(pyr1, pyr2), head(pyr2, pyr1))`` + backward (+ ``optimizer.step()``)
+    into one hipGraph.
+
+    ``pyr1`` / ``pyr2`` are the feature pyramids of the two frames, low resolution first, as
+    the reference's ``PWCNetHead.forward`` receives them in ``im_pyr[1]``.  Call the object
+    with new pyramids of the same shapes: they are copied into the static input buffers, the
+    graph is replayed, and the (static) loss tensor and flow lists are returned -- clone them
+    if they must survive the next call.  Parameter ``.grad`` tensors are static too.
+
+    The optimizer, if given, must be graph-capturable (e.g. ``torch.optim.Adam(...,
+    capturable=True)``).  ``bidirectional=False`` captures the forward direction only.
+    """
+
+    def __init__(self, head: torch.nn.Module, loss_fn: Callable[[List[torch.Tensor]], torch.Tensor],
+                 pyr1: Sequence[torch.Tensor], pyr2: Sequence[torch.Tensor],
+                 optimizer: Optional[torch.optim.Optimizer] = None, bidirectional: bool = True,
+                 input_grads: bool = False, warmup: int = 3):
+        if not pyr1[0].is_cuda:
+            raise RuntimeError("GraphedFlowStep needs the pyramids on the GPU (there is no CPU "
+                               "path for the HIP ops)")
+        self.head, self.loss_fn, self.optimizer = head, loss_fn, optimizer
+        self.bidirectional, self.input_grads = bidirectional, input_grads
+        self.static1 = [t.detach().clone().requires_grad_(input_grads) for t in pyr1]
+        self.static2 = [t.detach().clone().requires_grad_(input_grads) for t in pyr2]
+        self.params = [p for p in head.parameters() if p.requires_grad]
+
+        # warm-up on a side stream (MIOpen picks its algorithms, the allocator its blocks)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(max(1, warmup)):
+                self._step(set_to_none=True)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.loss, self.flows_fw, self.flows_bw = self._step(set_to_none=True)
+        # the gradient tensors the graph writes (graph-pool memory): kept here and re-attached
+        # on every call, so that an outside ``zero_grad(set_to_none=True)`` or an eager step in
+        # between cannot leave ``p.grad`` pointing somewhere the replay does not write
+        self.param_grads = [p.grad for p in self.params]
+        self.input_grads1 = [t.grad for t in self.static1]
+        self.input_grads2 = [t.grad for t in self.static2]
+
+    # one eager step on the static buffers (also what gets captured)
+    def _step(self, set_to_none):
+        if self.optimizer is not None:
+            self.optimizer.zero_grad(set_to_none=set_to_none)
+        else:
+            for p in self.params:
+                p.grad = None
+        for t in self.static1 + self.static2:
+            t.grad = None
+        fw = self.head((None, self.static1), (None, self.static2))
+        bw = self.head((None, self.static2), (None, self.static1)) if self.bidirectional else []
+        loss = self.loss_fn(list(fw) + list(bw))
+        loss.backward()
+        if self.optimizer is not None:
+            self.optimizer.step()
+        return loss, list(fw), list(bw)
+
+    def __call__(self, pyr1: Sequence[torch.Tensor], pyr2: Sequence[torch.Tensor]):
+        if len(pyr1) != len(self.static1) or len(pyr2) != len(self.static2):
+            raise RuntimeError("GraphedFlowStep: pyramid depth differs from the captured one")
+        with torch.no_grad():
+            for dst, src in zip(self.static1 + self.static2, list(pyr1) + list(pyr2)):
+                if dst.shape != src.shape:
+                    raise RuntimeError("GraphedFlowStep: shape %s differs from the captured %s"
+                                       % (tuple(src.shape), tuple(dst.shape)))
+                dst.copy_(src)
+        self.graph.replay()
+        for p, g in zip(self.params, self.param_grads):
+            p.grad = g
+        return self.loss, self.flows_fw, self.flows_bw
+
+    def input_gradients(self):
+        """Static gradients of the input pyramids (``input_grads=True`` at construction)."""
+        return self.input_grads1, self.input_grads2

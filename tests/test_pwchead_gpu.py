@@ -65,3 +65,45 @@ def test_both_directions_training_step_runs_and_is_finite():
         opt.step()
     assert torch.isfinite(loss)
     assert all(torch.isfinite(p.grad).all() for p in head.parameters())
+
+
+def test_graphed_flow_step_equals_eager():
+    """the whole bidirectional head step captured into one hipGraph must give
+    the eager step's loss, flows and gradients, for the captured inputs and for new ones."""
+    from cerberusnet_amd.graphs import GraphedFlowStep
+    torch.manual_seed(3)
+    head = build("FlowEstimatorLite").to(DEV)
+    shapes = [(2, c, 8 * 2 ** l, 16 * 2 ** l) for l, c in enumerate(reversed(CHANS))]
+    mk = lambda: [torch.randn(s, device=DEV) for s in shapes]
+    loss_fn = lambda flows: sum(f.abs().mean() for f in flows)
+
+    def eager(p1, p2):
+        for p in head.parameters():
+            p.grad = None
+        a = [t.clone().requires_grad_(True) for t in p1]
+        b = [t.clone().requires_grad_(True) for t in p2]
+        fw = head((None, a), (None, b))
+        bw = head((None, b), (None, a))
+        loss = loss_fn(list(fw) + list(bw))
+        loss.backward()
+        return (loss.detach().clone(), [f.detach().clone() for f in fw],
+                [p.grad.detach().clone() for p in head.parameters()],
+                [t.grad.detach().clone() for t in a])
+
+    p1, p2 = mk(), mk()
+    step = GraphedFlowStep(head, loss_fn, p1, p2, input_grads=True)
+    for trial in range(2):
+        if trial:
+            p1, p2 = mk(), mk()
+        loss, fw, _ = step(p1, p2)
+        g_loss, g_fw = loss.detach().clone(), [f.detach().clone() for f in fw]
+        g_par = [p.grad.detach().clone() for p in head.parameters()]
+        g_in = [g.detach().clone() for g in step.input_gradients()[0]]
+        e_loss, e_fw, e_par, e_in = eager(p1, p2)
+        assert abs(float(g_loss) - float(e_loss)) <= 1e-5 * abs(float(e_loss))
+        for a, b in zip(g_fw, e_fw):
+            assert rel_err(a.cpu().numpy(), b.cpu().numpy()) < 1e-5
+        for a, b in zip(g_par + g_in, e_par + e_in):
+            assert l2_err(a.cpu().numpy(), b.cpu().numpy()) < 1e-3
+    with pytest.raises(RuntimeError, match="shape"):
+        step([t[:1] for t in p1], p2)
