@@ -926,18 +926,33 @@ __device__ __forceinline__ void bwd_dma_step(
         float2v a0[3] = {float2v{0.f, 0.f}, float2v{0.f, 0.f}, float2v{0.f, 0.f}};
         float2v a1[3] = {float2v{0.f, 0.f}, float2v{0.f, 0.f}, float2v{0.f, 0.f}};
         float s0 = 0.f, s1 = 0.f;
+        // Row r+1's window reads are issued BEFORE row r's FMAs and pinned there: left to
+        // itself hipcc reads a row, waits for its first value at once and steps lgkmcnt(4..1)
+        // through the FMAs -- four waits per row and the LDS latency exposed nine times per
+        // channel in an issue-bound loop.  Pipelined, one lgkmcnt(5) per row remains.
+        float2v w[kND][5];
+#pragma unroll
+        for (int q = 0; q < 5; ++q) w[0][q] = ld2v_nomerge(wp + 2 * q);
 #pragma unroll
         for (int dyi = 0; dyi < kND; ++dyi) {
-            float2v w[5];
+            if (dyi + 1 < kND) {
 #pragma unroll
-            for (int q = 0; q < 5; ++q) w[q] = ld2v_nomerge(wp + dyi * K::RS + 2 * q);
+                for (int q = 0; q < 5; ++q) w[dyi + 1][q] = ld2v_nomerge(wp + (dyi + 1) * K::RS + 2 * q);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // this row has landed once at most the next row's 5 reads are pending (in-order
+            // return): s_waitcnt lgkmcnt(5) / (0) with vmcnt and expcnt left at their maxima
+            if (dyi + 1 < kND) __builtin_amdgcn_s_waitcnt(0xC57F);
+            else __builtin_amdgcn_s_waitcnt(0xC07F);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                a0[dyi % 3] = pkfma(g0p[dyi][j], w[j], a0[dyi % 3]);
-                a1[dyi % 3] = pkfma(g1p[dyi][j], w[j + 1], a1[dyi % 3]);
+                a0[dyi % 3] = pkfma(g0p[dyi][j], w[dyi][j], a0[dyi % 3]);
+                a1[dyi % 3] = pkfma(g1p[dyi][j], w[dyi][j + 1], a1[dyi % 3]);
             }
-            s0 = fmaf(g0s[dyi], w[4].x, s0);
-            s1 = fmaf(g1s[dyi], w[0].y, s1);
+            s0 = fmaf(g0s[dyi], w[dyi][4].x, s0);
+            s1 = fmaf(g1s[dyi], w[dyi][0].y, s1);
+            __builtin_amdgcn_sched_barrier(0);
         }
         const float2v t0 = a0[0] + a0[1] + a0[2], t1 = a1[0] + a1[1] + a1[2];
         const float r0 = (t0.x + t0.y + s0) * inv_nelems, r1 = (t1.x + t1.y + s1) * inv_nelems;
