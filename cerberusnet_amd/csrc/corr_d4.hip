@@ -820,18 +820,36 @@ __global__ __launch_bounds__(K::THREADS, 2) void corr_bwd_d4_kernel(
             float2v a0[3] = {float2v{0.f, 0.f}, float2v{0.f, 0.f}, float2v{0.f, 0.f}};
             float2v a1[3] = {float2v{0.f, 0.f}, float2v{0.f, 0.f}, float2v{0.f, 0.f}};
             float s0 = 0.f, s1 = 0.f;
+            // row r+1's reads ahead of row r's FMAs, one lgkmcnt(5) per row (see bwd_dma_step);
+            // not where it would spill (the fp32 8x64 tile also holds its staging registers)
+            constexpr bool kPipe = K::TSXP == 16 || sizeof(T) == 2;
+            float2v w[kND][5];
+#pragma unroll
+            for (int q = 0; q < 5; ++q) w[0][q] = ld2v_nomerge(wp + 2 * q);
 #pragma unroll
             for (int dyi = 0; dyi < kND; ++dyi) {
-                float2v w[5];
+                if (kPipe) {
+                    if (dyi + 1 < kND) {
 #pragma unroll
-                for (int q = 0; q < 5; ++q) w[q] = ld2v_nomerge(wp + dyi * K::RS + 2 * q);
+                        for (int q = 0; q < 5; ++q)
+                            w[dyi + 1][q] = ld2v_nomerge(wp + (dyi + 1) * K::RS + 2 * q);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (dyi + 1 < kND) __builtin_amdgcn_s_waitcnt(0xC57F);
+                    else __builtin_amdgcn_s_waitcnt(0xC07F);
+                    __builtin_amdgcn_sched_barrier(0);
+                } else if (dyi > 0) {
+#pragma unroll
+                    for (int q = 0; q < 5; ++q) w[dyi][q] = ld2v_nomerge(wp + dyi * K::RS + 2 * q);
+                }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    a0[dyi % 3] = pkfma(g0p[dyi][j], w[j], a0[dyi % 3]);
-                    a1[dyi % 3] = pkfma(g1p[dyi][j], w[j + 1], a1[dyi % 3]);
+                    a0[dyi % 3] = pkfma(g0p[dyi][j], w[dyi][j], a0[dyi % 3]);
+                    a1[dyi % 3] = pkfma(g1p[dyi][j], w[dyi][j + 1], a1[dyi % 3]);
                 }
-                s0 = fmaf(g0s[dyi], w[4].x, s0);
-                s1 = fmaf(g1s[dyi], w[0].y, s1);
+                s0 = fmaf(g0s[dyi], w[dyi][4].x, s0);
+                s1 = fmaf(g1s[dyi], w[dyi][0].y, s1);
+                if (kPipe) __builtin_amdgcn_sched_barrier(0);
             }
             const float2v t0 = a0[0] + a0[1] + a0[2], t1 = a1[0] + a1[1] + a1[2];
             const float r0 = (t0.x + t0.y + s0) * inv_nelems, r1 = (t1.x + t1.y + s1) * inv_nelems;
@@ -1254,18 +1272,27 @@ __global__ __launch_bounds__(K::THREADS, 3) void corr_bwd_d4_g3_kernel(
             const float *wp = wbase + i * K::PS;
             float2v a0 = float2v{0.f, 0.f}, a1 = float2v{0.f, 0.f};
             float s0 = 0.f, s1 = 0.f;
+            float2v w[3][5];
+#pragma unroll
+            for (int q = 0; q < 5; ++q) w[0][q] = ld2v_nomerge(wp + 2 * q);
 #pragma unroll
             for (int dl = 0; dl < 3; ++dl) {
-                float2v w[5];
+                if (dl + 1 < 3) {
 #pragma unroll
-                for (int q = 0; q < 5; ++q) w[q] = ld2v_nomerge(wp + dl * K::RS + 2 * q);
+                    for (int q = 0; q < 5; ++q) w[dl + 1][q] = ld2v_nomerge(wp + (dl + 1) * K::RS + 2 * q);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (dl + 1 < 3) __builtin_amdgcn_s_waitcnt(0xC57F);
+                else __builtin_amdgcn_s_waitcnt(0xC07F);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    a0 = pkfma(g0p[dl][j], w[j], a0);
-                    a1 = pkfma(g1p[dl][j], w[j + 1], a1);
+                    a0 = pkfma(g0p[dl][j], w[dl][j], a0);
+                    a1 = pkfma(g1p[dl][j], w[dl][j + 1], a1);
                 }
-                s0 = fmaf(g0s[dl], w[4].x, s0);
-                s1 = fmaf(g1s[dl], w[0].y, s1);
+                s0 = fmaf(g0s[dl], w[dl][4].x, s0);
+                s1 = fmaf(g1s[dl], w[dl][0].y, s1);
+                __builtin_amdgcn_sched_barrier(0);
             }
             // partial sums of this displacement group -> LDS
             *reinterpret_cast<float2v *>(part + ((i * 3 + grp) * (NSW * 64) + slot_lane) * 2) =
