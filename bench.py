@@ -402,8 +402,8 @@ def main():
     if rank == 0:
         per = per_kernel_times(wl, max(2, args.probe_steps))
         kern = dict(wl.kernels())
-        # dominant single KERNEL: warp_bwd is a sequence of three kernels + a memset, so the
-        # longest individual launch of the step is a correlation kernel
+        # dominant kernel: the longest correlation launch of the step (BASELINE's second metric
+        # is the correlation's achieved HBM rate)
         dominant = max((k for k in per if k.startswith("corr")), key=lambda k: per[k])
         ach = kern[dominant] / per[dominant] / 1e9
         corr_t = sum(v for k, v in per.items() if k.startswith("corr"))

@@ -46,7 +46,7 @@ with open("%s/%s_pmc_counters.csv" % (out_dir, tag), "w") as f:
 
 REPS = 5  # tools/prof_kernels.py --reps
 traffic = {"_note": "bytes per op call at 4 pairs, level 3 (32x128x256); read = 2*FETCH_SIZE KiB "
-                    "(gfx950 correction), write = WRITE_SIZE KiB; warp_bwd sums its tile + finish kernels"}
+                    "(gfx950 correction), write = WRITE_SIZE KiB; warp_bwd is its tile kernel (one launch)"}
 for lab, ctr in per_dispatch.items():
     if "FETCH_SIZE" in ctr and "WRITE_SIZE" in ctr:
         rd = 2.0 * sum(ctr["FETCH_SIZE"]) / REPS * 1024.0
