@@ -182,17 +182,21 @@ def per_kernel_times(wl, reps):
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             keep = [fn() for _ in range(reps)]
-        graph.replay()
+        # The first few replays after an idle gap run up to 30 % slow (clock / power ramp:
+        # tools/timing_spread.py), the step itself runs in steady state: replay a few times
+        # untimed, then report the AVERAGE launch duration over 12 timed replays.
+        for _ in range(6):
+            graph.replay()
         torch.cuda.synchronize()
         samples = []
-        for _ in range(5):
+        for _ in range(12):
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
             graph.replay()
             b.record()
             torch.cuda.synchronize()
             samples.append(a.elapsed_time(b) * 1e-3 / reps)
-        out[label] = float(np.median(samples))
+        out[label] = float(np.mean(samples))
         del keep, graph
     return out
 
