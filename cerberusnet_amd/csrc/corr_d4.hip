@@ -888,13 +888,13 @@ __global__ __launch_bounds__(K::THREADS, 2) void corr_bwd_d4_kernel(
 //    drops the store), so "chunk k has landed" is a fixed s_waitcnt vmcnt(N).  N counts
 //    only the younger DMA loads, which is correct whether or not stores retire in order
 //    with loads.
-template <int CC_, int NB_>
+template <int CC_, int NB_, int NW_ = 4, int LPI_ = 48>
 struct BwdDmaCfg {
     static constexpr int CC = CC_, NB = NB_;
-    static constexpr int TSXP = 32, TW = 64, RPW = 2, NW = 4, TH = NW * RPW;
+    static constexpr int TSXP = 32, TW = 64, RPW = 2, NW = NW_, TH = NW * RPW;
     static constexpr int HR = TH + 2 * kD, HW4 = (TW + 2 * kD) / 4, RS = HW4 * 4, PS = HR * RS;
     static constexpr int THREADS = 64 * NW;
-    static constexpr int LPI = 48;                        // active lanes per DMA instruction
+    static constexpr int LPI = LPI_;                      // active lanes per DMA instruction
     static constexpr int SLOTS = CC * HR * HW4;           // 16-byte slots per chunk
     static constexpr int DW = SLOTS / (NW * LPI);         // DMA instructions per wave per chunk
     static constexpr int BUF = CC * PS;
@@ -990,7 +990,7 @@ __device__ __forceinline__ void bwd_dma_step(
 #endif
 
 template <typename K>
-__global__ __launch_bounds__(K::THREADS, 2) void corr_bwd_d4_dma_kernel(
+__global__ __launch_bounds__(K::THREADS, K::NW == 4 ? 2 : 1) void corr_bwd_d4_dma_kernel(
     const float *__restrict__ x1, const float *__restrict__ x2, const float *__restrict__ gout,
     float *__restrict__ gin1, float *__restrict__ gin2, int C, int H, int W, int tiles_x,
     int tiles_y, int cslice, int nslice, int dbg) {
@@ -1445,8 +1445,10 @@ int launch_bwd_dma(const char *name, const void *in1, const void *in2, const voi
     const int64_t tiles = static_cast<int64_t>(g.B) * tiles_x * tiles_y;
     int cslice = option_value("corr_bwd_cslice");
     if (cslice <= 0) {
+        // enough workgroups for every CU: two 4-wave workgroups or one 8-wave workgroup each
+        const int64_t want = K::NW == 4 ? 512 : 256;
         cslice = g.C;
-        while (cslice > 8 && 2 * tiles * ((g.C + cslice - 1) / cslice) < 512) cslice = (cslice + 1) / 2;
+        while (cslice > 8 && 2 * tiles * ((g.C + cslice - 1) / cslice) < want) cslice = (cslice + 1) / 2;
     }
     cslice = std::max(K::CC, (cslice + K::CC - 1) / K::CC * K::CC);
     const int nslice = (g.C + cslice - 1) / cslice;
