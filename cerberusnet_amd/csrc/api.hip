@@ -10,7 +10,7 @@ namespace cerb {
 namespace {
 struct Option { const char *key; std::atomic<int> value; };
 Option g_options[] = {{"corr_force_generic", {0}},   // 1: always use the generic kernels
-                      {"corr_fwd_variant", {0}},     // 0: auto, 1..8: force a register-staged variant, 9: LDS-DMA
+                      {"corr_fwd_variant", {0}},     // 0: auto, 1..8: force a register-staged variant, 9..13: LDS-DMA
                       {"corr_bwd_cslice", {0}},      // 0: auto, else channels per backward workgroup
                       {"corr_debug_ablate", {0}},    // timing ablation mask (WRONG results when != 0)
                       {"warp_pair_taps", {0}},

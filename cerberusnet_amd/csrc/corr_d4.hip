@@ -421,33 +421,41 @@ __global__ __launch_bounds__(K::THREADS, K::WPS) void corr_fwd_d4_kernel(
 }
 
 // ============================================================================
-// forward, LDS-DMA variant (fp32, 4x64 tile, vector path only)
+// forward, LDS-DMA variant (fp32, vector path only)
 // ============================================================================
-// Same tile, lane mapping and FMA loop as corr_fwd_d4_kernel<S=1,TSX=16,RB=1>, different
-// data movement: a TENTH wavefront is a dedicated loader.  It streams channel chunks into a
-// ring of NB LDS buffers with global_load_lds (LDS-DMA: no VGPR round trip, no ds_write),
-// NB-1 chunks ahead, and only ever executes {address arithmetic, DMA issue, s_waitcnt vmcnt,
-// s_barrier}; the nine compute wavefronts only execute {s_barrier, ds_read, FMA}.  hipcc
-// places a conservative vmcnt(0) before every ds_read that follows an LDS-DMA in the SAME
-// wave (see tools/ubench/glds_test.hip) -- with the roles split across waves that wait is
-// free: the compute waves have no vector-memory operation in flight.
-// LDS image of a chunk (linear in DMA slot order, 16 B per slot):
-//   x2 window: CC planes x 12 rows x 18 slots (row stride 72 floats, conflict-free with ROT=2)
-//   x1 tile  : CC planes x  4 rows x 16 slots; slot j of row r holds strip (j - 2r) mod 16, so
-//              the lane that owns that strip reads position (lane % 16): the rotation is
-//              applied to the DMA *source* address, the LDS side stays linear.
-template <int CC_, int NB_>
+// Same tiles, lane mapping and FMA loop as corr_fwd_d4_kernel<S,TSX,RB=1>, different data
+// movement: a TENTH wavefront is a dedicated loader.  It streams channel chunks into a ring
+// of NB LDS buffers with buffer_load ... lds (LDS-DMA: no VGPR round trip, no ds_write), NB-1
+// chunks ahead, and only ever executes {DMA issue, s_waitcnt vmcnt, s_barrier}; the nine
+// compute wavefronts only execute {s_barrier, ds_read, FMA}.  hipcc places a conservative
+// vmcnt(0) before every ds_read that follows an LDS-DMA in the SAME wave (tools/ubench/
+// glds_test.hip) -- with the roles split across waves that wait is free: the compute waves
+// have no vector-memory operation in flight.
+// LDS image of a chunk (plane pl = i*S + g: channel i of the chunk, lane group g):
+//   x2 windows: NCH planes x HR rows x HW4 16-byte slots, row stride RS = 4*HW4 floats, plane
+//               stride PS (residue as in the staged kernels: conflict-free ds_read_b128);
+//               one DMA instruction = RPI whole rows of one plane.
+//   x1 tiles  : per chunk channel i ONE instruction of 64 slots: lane L stores the strip it
+//               will itself read, at float offset 4*L -- linear, conflict free; the strip
+//               rotation of the x2 side is applied to the DMA source address.
+template <int S_, int TSX_, int CC_, int NB_, int ROT_, int PRES_>
 struct FwdDmaCfg {
-    static constexpr int CC = CC_, NB = NB_;
-    static constexpr int TSX = 16, TH = 4, TW = 64, HR = TH + 2 * kD, HW4 = TSX + 2;
-    static constexpr int PS = HR * HW4 * 4;        // 864 floats
-    static constexpr int PS1 = TH * TSX * 4;       // 256 floats
-    static constexpr int NINST = CC * (HR / 3 + 1);       // DMA wave-instructions per chunk
-    static constexpr int BUF = CC * (PS + PS1);           // floats per ring buffer
+    static constexpr int S = S_, TSX = TSX_, CC = CC_, NB = NB_, ROT = ROT_;
+    static constexpr int NS = 64 / S;                 // strips per channel group
+    static constexpr int TH = NS / TSX, TW = TSX * kP;
+    static constexpr int HR = TH + 2 * kD, HW4 = TSX + 2, RS = HW4 * 4;
+    static constexpr int PS = pad_to_residue(HR * RS, PRES_);
+    static constexpr int NCH = S * CC;                // channel planes per chunk
+    static constexpr int RPI = 64 / HW4;              // window rows per DMA instruction
+    static constexpr int NI2 = (HR + RPI - 1) / RPI;  // DMA instructions per x2 plane
+    static constexpr int NINST = NCH * NI2 + CC;      // DMA wave-instructions per chunk
+    static constexpr int BUF = NCH * PS + CC * 256;   // floats per ring buffer
     static constexpr int THREADS = 64 * (kND + 1);
     static constexpr size_t LDS_BYTES = sizeof(float) * NB * BUF;
+    static_assert(NS % TSX == 0, "strips must tile rows");
     static_assert(NINST * (NB - 2) <= 63, "vmcnt is 6 bits");
-    static_assert(HR % 3 == 0, "x2 window is issued as three-row groups");
+    static_assert(NB >= 3 && NB <= 4, "ring depth");
+    static_assert(PS % 4 == 0, "16B alignment");
 };
 
 typedef __attribute__((address_space(3))) void *lds_void_ptr;
@@ -471,14 +479,19 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
 }
 
 template <typename K>
-__global__ __launch_bounds__(K::THREADS, 5) void corr_fwd_d4_dma_kernel(
+__global__ __launch_bounds__(K::THREADS, K::S == 1 ? 5 : 3) void corr_fwd_d4_dma_kernel(
     const float *__restrict__ x1, const float *__restrict__ x2, float *__restrict__ out, int C,
     int H, int W, int tiles_x, int tiles_y, float slope, int64_t out_bstride) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int CC = K::CC, NB = K::NB, NINST = K::NINST;
+    constexpr int S = K::S, TSX = K::TSX, CC = K::CC, NB = K::NB, NINST = K::NINST;
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
+    // lane -> (channel group, tile row, strip); the loader uses the same mapping for x1
+    const int cg = lane / K::NS;
+    const int si = lane % K::NS;
+    const int r = si / TSX;
+    const int sx = (K::ROT == 0) ? si % TSX : (si % TSX + TSX - (K::ROT * r) % TSX) % TSX;
 
     int bid = xcd_swizzle(blockIdx.x, gridDim.x);
     const int tx = __builtin_amdgcn_readfirstlane(bid % tiles_x); bid /= tiles_x;
@@ -486,58 +499,61 @@ __global__ __launch_bounds__(K::THREADS, 5) void corr_fwd_d4_dma_kernel(
     const int b = __builtin_amdgcn_readfirstlane(bid / tiles_y);
     const int x0 = tx * K::TW, y0 = ty * K::TH;
     const int plane = H * W;
-    const int nchunks = (C + CC - 1) / CC;
+    const int Cg = C / S;  // channels per group (launcher guarantees C % S == 0)
+    const int nchunks = (Cg + CC - 1) / CC;
 
 #if defined(__HIP_DEVICE_COMPILE__)  // buffer-resource builtins exist in the device pass only
     if (wave == kND) {
         // ------------------------------ loader wavefront ------------------------------
         // Buffer-resource DMA: an offset at or beyond num_records reads zeros, so padding and
         // the channel tail need no branch and no zero block; the plane / chunk advance goes
-        // into the scalar offset, which leaves FIVE per-lane byte offsets for the whole
-        // kernel (4 three-row groups of the x2 window, 1 for the x1 tile).
+        // into the scalar offset, which leaves NI2 + 1 per-lane byte offsets for the whole
+        // kernel (the row groups of an x2 window, and the lane's own x1 strip).
         constexpr int kDead = static_cast<int>(0x80000000u);
         const int item_bytes = C * plane * 4;
         const __amdgpu_buffer_rsrc_t r1 = uniform_rsrc(x1 + static_cast<int64_t>(b) * C * plane, item_bytes);
         const __amdgpu_buffer_rsrc_t r2 = uniform_rsrc(x2 + static_cast<int64_t>(b) * C * plane, item_bytes);
-        const bool x2lane = lane < 3 * K::HW4;               // 3 rows x 18 slots per DMA
+        const bool x2lane = lane < K::RPI * K::HW4;
         const int lrow = lane / K::HW4, c4 = lane % K::HW4;
         const int gx2 = x0 - kD + 4 * c4;
         const bool xok = gx2 >= 0 && gx2 < W;
-        int v2[K::HR / 3];
+        int v2[K::NI2];
 #pragma unroll
-        for (int rg = 0; rg < K::HR / 3; ++rg) {
-            const int gy = y0 - kD + 3 * rg + lrow;
-            v2[rg] = (xok && gy >= 0 && gy < H) ? (gy * W + gx2) * 4 : kDead;
+        for (int rg = 0; rg < K::NI2; ++rg) {
+            const int row = rg * K::RPI + lrow;
+            const int gy = y0 - kD + row;
+            v2[rg] = (xok && row < K::HR && gy >= 0 && gy < H) ? (gy * W + gx2) * 4 : kDead;
         }
-        const int row1 = lane / K::TSX, pos1 = lane % K::TSX;
-        const int strip1 = (pos1 + K::TSX - (2 * row1) % K::TSX) % K::TSX;  // ROT = 2
-        const int gy1 = y0 + row1, gx1 = x0 + 4 * strip1;
-        const int v1 = (gy1 < H && gx1 < W) ? (gy1 * W + gx1) * 4 : kDead;
+        const int gy1 = y0 + r, gx1 = x0 + 4 * sx;
+        // x1: the lane's own strip of its own group's channel (group offset in the lane part)
+        const int v1 = (gy1 < H && gx1 < W) ? (cg * Cg * plane + gy1 * W + gx1) * 4 : kDead;
         auto issue = [&](int k) {
             float *buf = smem + (k % NB) * K::BUF;
             // scalar byte offsets of the chunk's planes, fixed before the (divergent) lane
             // mask below so that they stay in SGPRs
-            int soff[CC];
+            int soff[K::NCH];
             bool chok[CC];
 #pragma unroll
-            for (int pl = 0; pl < CC; ++pl) {
-                soff[pl] = __builtin_amdgcn_readfirstlane((k * CC + pl) * plane * 4);
-                chok[pl] = k * CC + pl < C;
+            for (int i = 0; i < CC; ++i) {
+                chok[i] = k * CC + i < Cg;
+#pragma unroll
+                for (int g = 0; g < S; ++g)
+                    soff[i * S + g] = __builtin_amdgcn_readfirstlane((g * Cg + k * CC + i) * plane * 4);
             }
             if (x2lane) {
 #pragma unroll
-                for (int pl = 0; pl < CC; ++pl)
+                for (int pl = 0; pl < K::NCH; ++pl)
 #pragma unroll
-                    for (int rg = 0; rg < K::HR / 3; ++rg)
+                    for (int rg = 0; rg < K::NI2; ++rg)
                         __builtin_amdgcn_raw_ptr_buffer_load_lds(
-                            r2, (lds_void_ptr)(buf + pl * K::PS + rg * (3 * K::HW4 * 4)), 16,
-                            chok[pl] ? v2[rg] : kDead, soff[pl], 0, 0);
+                            r2, (lds_void_ptr)(buf + pl * K::PS + rg * (K::RPI * K::RS)), 16,
+                            chok[pl / S] ? v2[rg] : kDead, soff[pl], 0, 0);
             }
 #pragma unroll
-            for (int pl = 0; pl < CC; ++pl)
+            for (int i = 0; i < CC; ++i)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(
-                    r1, (lds_void_ptr)(buf + CC * K::PS + pl * K::PS1), 16, chok[pl] ? v1 : kDead,
-                    soff[pl], 0, 0);
+                    r1, (lds_void_ptr)(buf + K::NCH * K::PS + i * 256), 16, chok[i] ? v1 : kDead,
+                    soff[i * S], 0, 0);   // group 0's plane offset; the group part is in v1
         };
 #pragma unroll
         for (int k = 0; k < NB - 1; ++k)
@@ -545,7 +561,7 @@ __global__ __launch_bounds__(K::THREADS, 5) void corr_fwd_d4_dma_kernel(
         for (int k = 0; k < nchunks; ++k) {
             // this wave's DMAs for chunk k have landed once at most the younger chunks remain
             const int younger = min(NB - 2, nchunks - 1 - k);
-            if (younger >= 2 && NB >= 4) wait_vmcnt<2 * NINST>();
+            if (younger >= 2 && NB >= 4) wait_vmcnt<(NB >= 4 ? 2 : 1) * NINST>();
             else if (younger == 1) wait_vmcnt<NINST>();
             else wait_vmcnt<0>();
             __builtin_amdgcn_s_barrier();  // chunk k visible to the compute waves; k-1 consumed
@@ -556,11 +572,6 @@ __global__ __launch_bounds__(K::THREADS, 5) void corr_fwd_d4_dma_kernel(
 #endif
 
     // -------------------------------- compute wavefronts --------------------------------
-    const int si = lane;                      // S = 1: 64 strips = 4 rows x 16
-    const int r = si / K::TSX;
-    const int pos = si % K::TSX;
-    const int sx = (pos + K::TSX - (2 * r) % K::TSX) % K::TSX;  // strip owned (ROT = 2)
-
     float2v accp[kP][4];
     float accs[kP];
 #pragma unroll
@@ -572,12 +583,12 @@ __global__ __launch_bounds__(K::THREADS, 5) void corr_fwd_d4_dma_kernel(
     for (int k = 0; k < nchunks; ++k) {
         __builtin_amdgcn_s_barrier();
         const float *buf = smem + (k % NB) * K::BUF;
-        const float *X2 = buf + (r + wave) * (K::HW4 * 4) + 4 * sx;
-        const float *X1 = buf + CC * K::PS + r * (K::TSX * 4) + 4 * pos;
+        const float *X2 = buf + cg * K::PS + (r + wave) * K::RS + 4 * sx;
+        const float *X1 = buf + K::NCH * K::PS + 4 * lane;
 #pragma unroll
         for (int i = 0; i < CC; ++i) {
-            const float4 a = ld4(X1 + i * K::PS1);
-            const float *bp = X2 + i * K::PS;
+            const float4 a = ld4(X1 + i * 256);
+            const float *bp = X2 + i * S * K::PS;
             const float4 b0 = ld4(bp), b1 = ld4(bp + 4), b2 = ld4(bp + 8);
             const float av[4] = {a.x, a.y, a.z, a.w};
             const float2v bw[6] = {float2v{b0.x, b0.y}, float2v{b0.z, b0.w}, float2v{b1.x, b1.y},
@@ -596,6 +607,30 @@ __global__ __launch_bounds__(K::THREADS, 5) void corr_fwd_d4_dma_kernel(
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
 
+    // ---- unpack, channel-group reduction with wave64 shuffles ----
+    float acc[kND][kP];
+#pragma unroll
+    for (int p = 0; p < kP; ++p) {
+        const int off = p & 1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            acc[2 * j + off][p] = accp[p][j].x;
+            acc[2 * j + off + 1][p] = accp[p][j].y;
+        }
+        acc[off ? 0 : 8][p] = accs[p];
+    }
+    if (S > 1) {
+#pragma unroll
+        for (int d = 0; d < kND; ++d)
+#pragma unroll
+            for (int p = 0; p < kP; ++p) {
+                float v = acc[d][p];
+#pragma unroll
+                for (int m = K::NS; m < 64; m <<= 1) v += __shfl_xor(v, m, 64);
+                acc[d][p] = v;
+            }
+    }
+    if (cg != 0) return;
     const float inv_nelems = 1.0f / static_cast<float>(C);
     const int64_t obs = out_bstride ? out_bstride : static_cast<int64_t>(kND * kND) * plane;
     float *ob = out + b * obs + static_cast<int64_t>(wave * kND) * plane;
@@ -606,11 +641,7 @@ __global__ __launch_bounds__(K::THREADS, 5) void corr_fwd_d4_dma_kernel(
         float v[4];
 #pragma unroll
         for (int p = 0; p < kP; ++p) {
-            const int off = p & 1;
-            float q;
-            if (d == (off ? 0 : 8)) q = accs[p];
-            else { const int j = (d - off) / 2; q = ((d - off) & 1) ? accp[p][j].y : accp[p][j].x; }
-            q *= inv_nelems;
+            const float q = acc[d][p] * inv_nelems;
             v[p] = q > 0.f ? q : q * slope;
         }
         typedef float f4v __attribute__((ext_vector_type(4)));
@@ -1374,7 +1405,11 @@ using FwdE1 = FwdCfg<16, 4, 1, 2, 0, 24, 16, 16, 3, 2>;  // 1x16 tile, 16 channe
 using FwdA1b = FwdCfg<1, 16, 1, 4, 2, 72, 72, 0, 3, 1>;  // 4x64 tile, small chunks, 3 WGs/CU
 using FwdA1c = FwdCfg<1, 16, 1, 4, 2, 72, 72, 0, 3, 2>;  // 4x64 tile, 2 chunks in flight
 
-using FwdDma4 = FwdDmaCfg<4, 4>;   // 4-channel chunks, ring of 4 (3 chunks in flight)
+using FwdDma4 = FwdDmaCfg<1, 16, 4, 4, 2, 0>;    // 4x64 tile, 4-channel chunks, ring of 4
+using FwdDmaB = FwdDmaCfg<2, 16, 4, 3, 2, 0>;    // 2x64 tile, 2 channel groups
+using FwdDmaC = FwdDmaCfg<4, 16, 2, 3, 0, 0>;    // 1x64 tile, 4 channel groups
+using FwdDmaD = FwdDmaCfg<8, 8, 2, 3, 0, 32>;    // 1x32 tile, 8 channel groups
+using FwdDmaE = FwdDmaCfg<16, 4, 2, 3, 0, 16>;   // 1x16 tile, 16 channel groups
 
 template <typename K>
 int launch_fwd_dma(const char *name, const void *in1, const void *in2, void *outp,
@@ -1539,26 +1574,57 @@ int fwd_dispatch(const void *x1, const void *x2, void *o, const CorrGeom &g, flo
                 if (vec) return launch_fwd_dma<FwdDma4>("corr_fwd_d4_dma_4x64", x1, x2, o, g, slope, obs, s);
             }
             break;
+        case 10: case 11: case 12: case 13:
+            if constexpr (sizeof(T) == 4) {
+                if (vec) {
+                    const int v = option_value("corr_fwd_variant");
+                    if (v == 10 && g.C % 2 == 0)
+                        return launch_fwd_dma<FwdDmaB>("corr_fwd_d4_dma_2x64_s2", x1, x2, o, g, slope, obs, s);
+                    if (v == 11 && g.C % 4 == 0)
+                        return launch_fwd_dma<FwdDmaC>("corr_fwd_d4_dma_1x64_s4", x1, x2, o, g, slope, obs, s);
+                    if (v == 12 && g.C % 8 == 0)
+                        return launch_fwd_dma<FwdDmaD>("corr_fwd_d4_dma_1x32_s8", x1, x2, o, g, slope, obs, s);
+                    if (v == 13 && g.C % 16 == 0)
+                        return launch_fwd_dma<FwdDmaE>("corr_fwd_d4_dma_1x16_s16", x1, x2, o, g, slope, obs, s);
+                }
+            }
+            break;
         default: break;
     }
     // Smallest channel split that still yields >= 256 workgroups (one per CU); the tile
     // sweep on MI355X (tools/tune_corr.py, profiles/) picked exactly this order.
     const int64_t want = 256;
+    // fp32 vector path: the LDS-DMA kernels (loader wavefront + ring of LDS buffers); same
+    // tiles, lane mapping and summation order as the register-staged ones -> identical bits.
+    // Level 3: 19-21 vs 22 us; levels 0 / 1 / 2: 11.6 / 11.0 / 12.0 vs 12.7 / 13.2 / 13.3 us.
+    const bool dma = sizeof(T) == 4 && vec;
     if (fwd_tiles<FwdA1b>(g) >= want || g.C % 2 != 0) {
-        // fp32 vector path: LDS-DMA ring with a loader wavefront (21.3 vs 22.2 us at level 3,
-        // 15 vs 20 us at 64 channels); same tile, same summation order, identical bits
         if constexpr (sizeof(T) == 4) {
-            if (vec)
-                return launch_fwd_dma<FwdDma4>("corr_fwd_d4_dma_4x64", x1, x2, o, g, slope, obs, s);
+            if (dma) return launch_fwd_dma<FwdDma4>("corr_fwd_d4_dma_4x64", x1, x2, o, g, slope, obs, s);
         }
         return launch_fwd<FwdA1b, T>("corr_fwd_d4_4x64_cc4", x1, x2, o, g, slope, obs, vec, s);
     }
-    if (fwd_tiles<FwdB1>(g) >= want || g.C % 4 != 0)
+    if (fwd_tiles<FwdB1>(g) >= want || g.C % 4 != 0) {
+        if constexpr (sizeof(T) == 4) {
+            if (dma) return launch_fwd_dma<FwdDmaB>("corr_fwd_d4_dma_2x64_s2", x1, x2, o, g, slope, obs, s);
+        }
         return launch_fwd<FwdB1, T>("corr_fwd_d4_2x64_s2", x1, x2, o, g, slope, obs, vec, s);
-    if (fwd_tiles<FwdC1>(g) >= want || g.C % 8 != 0)
+    }
+    if (fwd_tiles<FwdC1>(g) >= want || g.C % 8 != 0) {
+        if constexpr (sizeof(T) == 4) {
+            if (dma) return launch_fwd_dma<FwdDmaC>("corr_fwd_d4_dma_1x64_s4", x1, x2, o, g, slope, obs, s);
+        }
         return launch_fwd<FwdC1, T>("corr_fwd_d4_1x64_s4", x1, x2, o, g, slope, obs, vec, s);
-    if (fwd_tiles<FwdD1>(g) >= want || g.C % 16 != 0)
+    }
+    if (fwd_tiles<FwdD1>(g) >= want || g.C % 16 != 0) {
+        if constexpr (sizeof(T) == 4) {
+            if (dma) return launch_fwd_dma<FwdDmaD>("corr_fwd_d4_dma_1x32_s8", x1, x2, o, g, slope, obs, s);
+        }
         return launch_fwd<FwdD1, T>("corr_fwd_d4_1x32_s8", x1, x2, o, g, slope, obs, vec, s);
+    }
+    if constexpr (sizeof(T) == 4) {
+        if (dma) return launch_fwd_dma<FwdDmaE>("corr_fwd_d4_dma_1x16_s16", x1, x2, o, g, slope, obs, s);
+    }
     return launch_fwd<FwdE1, T>("corr_fwd_d4_1x16_s16", x1, x2, o, g, slope, obs, vec, s);
 }
 

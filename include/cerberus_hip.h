@@ -152,7 +152,8 @@ int cerberus_flow_warp_backward(const void *image, const void *flow,
 /* Diagnostics / tuning knobs (process-wide, read at launch time, default 0):
  *   "corr_force_generic" : 1 = always use the generic kernels (testing)
  *   "corr_fwd_variant"   : 0 = auto, 1..8 = force one register-staged forward variant,
- *                          9 = the LDS-DMA variant (fp32, W % 4 == 0)
+ *                          9..13 = the LDS-DMA variants (fp32, W % 4 == 0) with 1, 2, 4, 8,
+ *                          16 channel groups
  *   "corr_bwd_variant"   : 0 = auto, 1 = all 81 displacements per lane (register-staged),
  *                          2/3 = three displacement groups, 4 = LDS-DMA (fp32, W % 4 == 0)
  *   "corr_bwd_cslice"    : 0 = auto, else channels per backward workgroup

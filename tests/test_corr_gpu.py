@@ -289,7 +289,7 @@ def test_native_library_is_loaded():
     assert "libcerberus_hip.so" in maps
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 8, 9])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13])
 @pytest.mark.parametrize("shape", [(2, 32, 13, 72), (1, 16, 9, 64), (1, 48, 20, 33),
                                    (2, 64, 5, 16), (1, 16, 3, 130), (2, 7, 11, 132)])
 def test_every_tuned_forward_variant(variant, shape):
@@ -328,6 +328,27 @@ def test_tuned_backward_tiles_and_channel_slices(variant, cslice, shape):
     assert name.startswith("corr_bwd_d4"), name
     assert rel_err(g1, r1) < TOL
     assert rel_err(g2, r2) < TOL
+
+
+@pytest.mark.parametrize("staged,dma,shape", [(3, 10, (2, 32, 13, 72)), (4, 11, (1, 48, 20, 136)),
+                                              (5, 12, (2, 64, 5, 48)), (6, 13, (1, 96, 9, 40))])
+def test_channel_group_dma_forward_is_bit_identical_to_the_staged_variant(staged, dma, shape):
+    """Variants 3..6 (2/4/8/16 lane groups, register-staged) and 10..13 (the same tiles fed by
+    the loader wavefront) sum in the same order: identical bits."""
+    x1 = torch.from_numpy(hash_uniform(shape, 56)).to(DEV)
+    x2 = torch.from_numpy(hash_uniform(shape, 57)).to(DEV)
+    outs, names = [], []
+    for v in (staged, dma):
+        _lib.set_option("corr_fwd_variant", v)
+        try:
+            outs.append(torch.ops.cerberus.correlation(x1, x2, 4, 1, 4, 1, 1, 1))
+            names.append(_lib.last_kernel(0))
+        finally:
+            _lib.set_option("corr_fwd_variant", 0)
+    assert "dma" not in names[0] and "dma" in names[1], names
+    assert torch.equal(outs[0], outs[1])
+    ref = oracle.corr_forward_ref(x1.cpu().numpy(), x2.cpu().numpy(), 4, 1, 4, 1, 1)
+    assert rel_err(outs[1].cpu().numpy(), ref) < TOL
 
 
 @pytest.mark.parametrize("shape", [(2, 32, 24, 128), (1, 6, 8, 64), (3, 17, 37, 196)])

@@ -16,7 +16,7 @@ from tools.tune_corr import timeit, P
 variants = [int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else "0,7,9").split(",")]
 pairs = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 ops = torch.ops.cerberus
-shapes = list(pyramid_shapes()) + [(32, 127, 252), (30, 64, 128), (5, 9, 68)]
+shapes = list(pyramid_shapes()) + [(32, 127, 252), (32, 64, 128), (48, 9, 68), (16, 33, 40)]
 for lvl, (C, H, W) in enumerate(shapes):
     B = pairs
     x1 = torch.from_numpy(hash_uniform((B, C, H, W), 1)).cuda()
