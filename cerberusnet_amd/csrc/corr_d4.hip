@@ -1552,6 +1552,14 @@ bool fast_config(const CorrGeom &g, int dtype) {
            static_cast<int64_t>(kND * kND) * g.H * g.W < (1ll << 30);  // 32-bit offsets
 }
 
+// The LDS-DMA kernels address a batch item through 32-bit buffer offsets and use 2^31 as the
+// "out of range" offset: a batch item (and its 81-plane gradOutput) must stay below 2 GiB.
+// Larger items keep the register-staged kernels (64-bit pointers, up to 2^30 elements).
+bool dma_ok(const CorrGeom &g) {
+    return static_cast<int64_t>(g.C) * g.H * g.W < (1ll << 29) &&
+           static_cast<int64_t>(kND * kND) * g.H * g.W < (1ll << 29);
+}
+
 // a 4-element group must be naturally aligned: 16 B (fp32) or 8 B (16-bit storage)
 bool aligned_group(const void *p, int dtype) {
     return (reinterpret_cast<uintptr_t>(p) & (dtype == CERB_F32 ? 15 : 7)) == 0;
@@ -1571,12 +1579,13 @@ int fwd_dispatch(const void *x1, const void *x2, void *o, const CorrGeom &g, flo
         case 8: return launch_fwd<FwdA1c, T>("corr_fwd_d4_4x64_cc4x2", x1, x2, o, g, slope, obs, vec, s);
         case 9:
             if constexpr (sizeof(T) == 4) {
-                if (vec) return launch_fwd_dma<FwdDma4>("corr_fwd_d4_dma_4x64", x1, x2, o, g, slope, obs, s);
+                if (vec && dma_ok(g))
+                    return launch_fwd_dma<FwdDma4>("corr_fwd_d4_dma_4x64", x1, x2, o, g, slope, obs, s);
             }
             break;
         case 10: case 11: case 12: case 13:
             if constexpr (sizeof(T) == 4) {
-                if (vec) {
+                if (vec && dma_ok(g)) {
                     const int v = option_value("corr_fwd_variant");
                     if (v == 10 && g.C % 2 == 0)
                         return launch_fwd_dma<FwdDmaB>("corr_fwd_d4_dma_2x64_s2", x1, x2, o, g, slope, obs, s);
@@ -1597,7 +1606,7 @@ int fwd_dispatch(const void *x1, const void *x2, void *o, const CorrGeom &g, flo
     // fp32 vector path: the LDS-DMA kernels (loader wavefront + ring of LDS buffers); same
     // tiles, lane mapping and summation order as the register-staged ones -> identical bits.
     // Level 3: 19-21 vs 22 us; levels 0 / 1 / 2: 11.6 / 11.0 / 12.0 vs 12.7 / 13.2 / 13.3 us.
-    const bool dma = sizeof(T) == 4 && vec;
+    const bool dma = sizeof(T) == 4 && vec && dma_ok(g);
     if (fwd_tiles<FwdA1b>(g) >= want || g.C % 2 != 0) {
         if constexpr (sizeof(T) == 4) {
             if (dma) return launch_fwd_dma<FwdDma4>("corr_fwd_d4_dma_4x64", x1, x2, o, g, slope, obs, s);
@@ -1639,7 +1648,8 @@ int bwd_dispatch(const void *x1, const void *x2, const void *go, void *g1, void 
         case 3: return launch_bwd_g3<BwdG3Wide4, T>("corr_bwd_d4_g3_8x64", x1, x2, go, g1, g2, g, vec, s);
         case 4:
             if constexpr (sizeof(T) == 4) {
-                if (vec) return launch_bwd_dma<BwdDma2x5>("corr_bwd_d4_dma_8x64", x1, x2, go, g1, g2, g, s);
+                if (vec && dma_ok(g))
+                    return launch_bwd_dma<BwdDma2x5>("corr_bwd_d4_dma_8x64", x1, x2, go, g1, g2, g, s);
             }
             break;
         default: break;
@@ -1651,7 +1661,8 @@ int bwd_dispatch(const void *x1, const void *x2, const void *go, void *g1, void 
         return launch_bwd_g3<BwdG3Wide4, T>("corr_bwd_d4_g3_8x64", x1, x2, go, g1, g2, g, vec, s);
     // fp32 vector path: same kernel with the channel window streamed by LDS-DMA (identical bits)
     if constexpr (sizeof(T) == 4) {
-        if (vec) return launch_bwd_dma<BwdDma2x5>("corr_bwd_d4_dma_8x64", x1, x2, go, g1, g2, g, s);
+        if (vec && dma_ok(g))
+            return launch_bwd_dma<BwdDma2x5>("corr_bwd_d4_dma_8x64", x1, x2, go, g1, g2, g, s);
     }
     return launch_bwd<BwdWide, T>("corr_bwd_d4_8x64", x1, x2, go, g1, g2, g, vec, s);
 }

@@ -369,6 +369,16 @@ __global__ __launch_bounds__(kPix * kCg) void warp_bwd_kernel(
 // reduction): every product w*g <= m is an int32 with a resolution of 2^-30 of the largest
 // gradient in the tile (fp32 itself resolves 2^-24), and 2^33 of them can meet in one pixel.
 // Integer addition commutes, so the result is bit-reproducible (ATen's is not).
+// 64-bit fixed point -> float.  |acc| stays far below 2^53 (int32 contributions, at most a
+// few thousand per pixel), so hi * 2^32 + lo is EXACT in double and the final rounding is the
+// correctly rounded int64 -> float conversion -- in 4 instructions instead of the ~20 of the
+// generic sequence (16 conversions per thread in the write-back).
+__device__ __forceinline__ float fixed64_to_float(long long acc) {
+    const int hi = static_cast<int>(acc >> 32);
+    const unsigned lo = static_cast<unsigned>(acc);
+    return static_cast<float>(fma(static_cast<double>(hi), 4294967296.0, static_cast<double>(lo)));
+}
+
 __device__ __forceinline__ unsigned long long fixed64(float scaled) {
     return static_cast<unsigned long long>(static_cast<long long>(__float2int_rn(scaled)));
 }
@@ -651,7 +661,7 @@ __global__ __launch_bounds__(256, CW <= 4 ? 4 : 2) void warp_bwd_tile_kernel(
         const int yy = ty0 + rem / TW, xx = tx0 + rem % TW;
         if (yy < H && xx < W)
             dst[static_cast<int64_t>(c) * plane + yy * W + xx] =
-                static_cast<float>(acc[c * PS + rem]) * unscale;
+                fixed64_to_float(acc[c * PS + rem]) * unscale;
     }
 }
 
