@@ -919,10 +919,10 @@ __global__ __launch_bounds__(K::THREADS, 2) void corr_bwd_d4_kernel(
 //    drops the store), so "chunk k has landed" is a fixed s_waitcnt vmcnt(N).  N counts
 //    only the younger DMA loads, which is correct whether or not stores retire in order
 //    with loads.
-template <int CC_, int NB_, int NW_ = 4, int LPI_ = 48>
+template <int CC_, int NB_, int NW_ = 4, int LPI_ = 48, int TSXP_ = 32>
 struct BwdDmaCfg {
     static constexpr int CC = CC_, NB = NB_;
-    static constexpr int TSXP = 32, TW = 64, RPW = 2, NW = NW_, TH = NW * RPW;
+    static constexpr int TSXP = TSXP_, TW = 2 * TSXP, RPW = 64 / TSXP, NW = NW_, TH = NW * RPW;
     static constexpr int HR = TH + 2 * kD, HW4 = (TW + 2 * kD) / 4, RS = HW4 * 4, PS = HR * RS;
     static constexpr int THREADS = 64 * NW;
     static constexpr int LPI = LPI_;                      // active lanes per DMA instruction
@@ -1539,6 +1539,7 @@ int launch_bwd_g3(const char *name, const void *in1, const void *in2, const void
 using BwdG3Wide = BwdG3Cfg<32, 4, 72, 2>;    // 4x64 tile, 6 wavefronts
 using BwdG3Wide4 = BwdG3Cfg<32, 2, 72, 4>;   // 8x64 tile, 12 wavefronts
 using BwdDma2x5 = BwdDmaCfg<2, 5>;   // 8x64 tile, 2-channel chunks, ring of 5
+using BwdDmaNarrow = BwdDmaCfg<2, 5, 4, 60, 16>;   // 16x32 tile (rows 40 floats apart: partly 2-way LDS conflicts)
 using BwdWide = BwdCfg<32, 2, 72>;    // 8x64 tile
 // Tried and rejected on MI355X (level 3 / level 2, 4 pairs): 16x64 tiles with 8 wavefronts
 // (55.8 / 39.0 us vs 45.6 / 29.2: fewer workgroups in flight outweighs the smaller halo) and
@@ -1640,8 +1641,13 @@ int fwd_dispatch(const void *x1, const void *x2, void *o, const CorrGeom &g, flo
 template <typename T>
 int bwd_dispatch(const void *x1, const void *x2, const void *go, void *g1, void *g2,
                  const CorrGeom &g, bool vec, hipStream_t s) {
-    if (g.W <= 32)
+    if (g.W <= 32) {
+        if constexpr (sizeof(T) == 4) {
+            if (vec && dma_ok(g) && option_value("corr_bwd_variant") != 1)
+                return launch_bwd_dma<BwdDmaNarrow>("corr_bwd_d4_dma_16x32", x1, x2, go, g1, g2, g, s);
+        }
         return launch_bwd<BwdNarrow, T>("corr_bwd_d4_16x32", x1, x2, go, g1, g2, g, vec, s);
+    }
     switch (option_value("corr_bwd_variant")) {
         case 1: return launch_bwd<BwdWide, T>("corr_bwd_d4_8x64", x1, x2, go, g1, g2, g, vec, s);
         case 2: return launch_bwd_g3<BwdG3Wide, T>("corr_bwd_d4_g3_4x64", x1, x2, go, g1, g2, g, vec, s);

@@ -351,7 +351,8 @@ def test_channel_group_dma_forward_is_bit_identical_to_the_staged_variant(staged
     assert rel_err(outs[1].cpu().numpy(), ref) < TOL
 
 
-@pytest.mark.parametrize("shape", [(2, 32, 24, 128), (1, 6, 8, 64), (3, 17, 37, 196)])
+@pytest.mark.parametrize("shape", [(2, 32, 24, 128), (1, 6, 8, 64), (3, 17, 37, 196), (2, 24, 21, 32),
+                                   (1, 7, 16, 28)])
 def test_dma_kernels_are_bit_identical_to_the_register_staged_ones(shape):
     """The LDS-DMA kernels change the data movement only (same tile, same lane mapping, same
     summation order): their results must equal the register-staged kernels bit for bit."""

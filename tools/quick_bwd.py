@@ -17,7 +17,7 @@ variants = [int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else "1,4").split(
 cslices = [int(v) for v in (sys.argv[2] if len(sys.argv) > 2 else "0").split(",")]
 pairs = int(sys.argv[3]) if len(sys.argv) > 3 else 4
 ops = torch.ops.cerberus
-shapes = list(pyramid_shapes())[1:] + [(32, 124, 252), (30, 64, 128), (5, 9, 68), (7, 40, 72)]
+shapes = list(pyramid_shapes()) + [(32, 124, 252), (30, 64, 128), (5, 9, 68), (7, 40, 72)]
 for C, H, W in shapes:
     B = pairs
     x1 = torch.from_numpy(hash_uniform((B, C, H, W), 1)).cuda()
