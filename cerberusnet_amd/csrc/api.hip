@@ -16,7 +16,7 @@ Option g_options[] = {{"corr_force_generic", {0}},   // 1: always use the generi
                       {"warp_pair_taps", {0}},
                              // 0: default, 1: pairs everywhere, 2: none
                       {"warp_tile_cw", {0}},         // 0: auto, 4 / 8: channels per warp-backward tile workgroup
-                      {"corr_bwd_variant", {0}}};    // 0: auto, 1: all-81 per lane, 2/3: 3 dy groups, 4: LDS-DMA
+                      {"corr_bwd_variant", {0}}};    // 0: auto, 1: all-81 per lane, 2/3: 3 dy groups, 4/5: LDS-DMA (8x64 / 16x32 tile)
 thread_local const char *t_last_kernel[2] = {"none", "none"};
 
 Option *find_option(const char *key) {

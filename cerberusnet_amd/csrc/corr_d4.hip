@@ -1658,6 +1658,12 @@ int bwd_dispatch(const void *x1, const void *x2, const void *go, void *g1, void 
                     return launch_bwd_dma<BwdDma2x5>("corr_bwd_d4_dma_8x64", x1, x2, go, g1, g2, g, s);
             }
             break;
+        case 5:
+            if constexpr (sizeof(T) == 4) {
+                if (vec && dma_ok(g))
+                    return launch_bwd_dma<BwdDmaNarrow>("corr_bwd_d4_dma_16x32", x1, x2, go, g1, g2, g, s);
+            }
+            break;
         default: break;
     }
     // few tiles (coarse level): the displacement-group kernel puts 3x the wavefronts on the

@@ -155,7 +155,8 @@ int cerberus_flow_warp_backward(const void *image, const void *flow,
  *                          9..13 = the LDS-DMA variants (fp32, W % 4 == 0) with 1, 2, 4, 8,
  *                          16 channel groups
  *   "corr_bwd_variant"   : 0 = auto, 1 = all 81 displacements per lane (register-staged),
- *                          2/3 = three displacement groups, 4 = LDS-DMA (fp32, W % 4 == 0)
+ *                          2/3 = three displacement groups, 4 / 5 = LDS-DMA with the 8x64 /
+ *                          16x32 tile (fp32, W % 4 == 0)
  *   "corr_bwd_cslice"    : 0 = auto, else channels per backward workgroup
  *   "warp_pair_taps"     : warp gather variant (0 default, 1 paired everywhere, 2 unpaired)
  *   "warp_tile_cw"       : channels per warp-backward tile workgroup (0 auto, 4, 8)
