@@ -1353,11 +1353,17 @@ __global__ __launch_bounds__(K::THREADS, 3) void corr_bwd_d4_g3_kernel(
 }
 
 // ---- host side -------------------------------------------------------------
-// LDS above 64 KiB needs an explicit opt-in, once per kernel (flag owned by the call site)
+// LDS above 64 KiB needs an explicit opt-in, once per kernel AND device (function attributes
+// are per device): one bit per device ordinal in a mask owned by the call site (a benign
+// race at worst sets the attribute twice)
 template <typename Kern>
-int ensure_lds(Kern kern, size_t bytes, bool *done) {
-    if (bytes <= 64 * 1024 || *done) return CERB_OK;
-    *done = true;
+int ensure_lds(Kern kern, size_t bytes, uint64_t *done) {
+    if (bytes <= 64 * 1024) return CERB_OK;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    const uint64_t bit = 1ull << (dev & 63);
+    if (*done & bit) return CERB_OK;
+    *done |= bit;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize,
                                        static_cast<int>(bytes));
@@ -1375,7 +1381,7 @@ int launch_fwd(const char *name, const void *in1, const void *in2, void *outp, c
     const int64_t blocks = static_cast<int64_t>(g.B) * tiles_x * tiles_y;
     if (blocks > 0x7fffffff) return CERB_ETOOLARGE;
     int rc;
-    static bool lds_v = false, lds_s = false;
+    static uint64_t lds_v = 0, lds_s = 0;
     const int dbg = option_value("corr_debug_ablate");
     if (vec) {
         note_kernel(0, name);
@@ -1417,7 +1423,7 @@ int launch_fwd_dma(const char *name, const void *in1, const void *in2, void *out
     const int tiles_x = (g.W + K::TW - 1) / K::TW, tiles_y = (g.H + K::TH - 1) / K::TH;
     const int64_t blocks = static_cast<int64_t>(g.B) * tiles_x * tiles_y;
     if (blocks > 0x7fffffff) return CERB_ETOOLARGE;
-    static bool lds_done = false;
+    static uint64_t lds_done = 0;
     int rc;
     if ((rc = ensure_lds(corr_fwd_d4_dma_kernel<K>, K::LDS_BYTES, &lds_done))) return rc;
     note_kernel(0, name);
@@ -1453,7 +1459,7 @@ int launch_bwd(const char *name, const void *in1, const void *in2, const void *g
     if (tiles * nslice * 2 > 0x7fffffff) return CERB_ETOOLARGE;
     const dim3 grid(static_cast<unsigned>(tiles * nslice * 2));
     int rc;
-    static bool lds_v = false, lds_s = false;
+    static uint64_t lds_v = 0, lds_s = 0;
     const int dbg = option_value("corr_debug_ablate");
     if (vec) {
         note_kernel(1, name);
@@ -1489,7 +1495,7 @@ int launch_bwd_dma(const char *name, const void *in1, const void *in2, const voi
     const int nslice = (g.C + cslice - 1) / cslice;
     const int64_t blocks = tiles * nslice * 2;
     if (blocks > 0x7fffffff) return CERB_ETOOLARGE;
-    static bool lds_done = false;
+    static uint64_t lds_done = 0;
     int rc;
     if ((rc = ensure_lds(corr_bwd_d4_dma_kernel<K>, K::LDS_BYTES, &lds_done))) return rc;
     note_kernel(1, name);
@@ -1517,7 +1523,7 @@ int launch_bwd_g3(const char *name, const void *in1, const void *in2, const void
     if (tiles * nslice * 2 > 0x7fffffff) return CERB_ETOOLARGE;
     const dim3 grid(static_cast<unsigned>(tiles * nslice * 2));
     int rc;
-    static bool lds_v = false, lds_s = false;
+    static uint64_t lds_v = 0, lds_s = 0;
     if (vec) {
         note_kernel(1, name);
         if ((rc = ensure_lds(corr_bwd_d4_g3_kernel<K, T, true>, K::LDS_BYTES, &lds_v))) return rc;
