@@ -130,7 +130,10 @@ __device__ __forceinline__ void wave_max2(int &a, int &b) {
 template <typename T, bool PAIR, int kCg>
 __global__ __launch_bounds__(kPix * kCg) void warp_fwd_kernel(
     const T *__restrict__ image, const T *__restrict__ flow, T *__restrict__ out,
-    void *__restrict__ ctx, int B, int C, int H, int W, int pad_mode, int interp) {
+    void *__restrict__ ctx, int B, int C, int H, int W, int pad_mode, int interp, int dbg) {
+#ifndef CERB_ABLATE
+    dbg = 0;
+#endif
     using A = typename Acc<T>::type;
     const int64_t plane = static_cast<int64_t>(H) * W;
     const int lane = threadIdx.x & (kPix - 1);
@@ -144,8 +147,10 @@ __global__ __launch_bounds__(kPix * kCg) void warp_fwd_kernel(
         if (p >= plane) continue;
         const int y = static_cast<int>(p / W), x = static_cast<int>(p % W);
         const T *fl = flow + static_cast<int64_t>(b) * 2 * plane + p;
-        const Coord<A> cx = source_coord<A>(x, ld(fl), W, pad_mode);
-        const Coord<A> cy = source_coord<A>(y, ld(fl + plane), H, pad_mode);
+        Coord<A> cx = source_coord<A>(x, ld(fl), W, pad_mode);
+        Coord<A> cy = source_coord<A>(y, ld(fl + plane), H, pad_mode);
+        if (dbg & 2) { cx.pos = A(x) + A(0.25); cy.pos = A(y) + A(0.25); }   // ablation: identity-like taps
+        if (dbg & 8) { cx.pos = A(x) + A(0.25) + ld(fl) * A(1e-30); cy.pos = A(y) + A(0.25) + ld(fl + plane) * A(1e-30); }
         const T *img = image + static_cast<int64_t>(b) * C * plane;
         T *dst = out + static_cast<int64_t>(b) * C * plane + p;
         if (interp == CERB_INTERP_NEAREST) {
@@ -194,7 +199,7 @@ __global__ __launch_bounds__(kPix * kCg) void warp_fwd_kernel(
                 acc += v[u][1] * wne;
                 acc += v[u][2] * wsw;
                 acc += v[u][3] * wse;
-                st(dst + cc * plane, acc);
+                if (!(dbg & 1) || acc == A(12345)) st(dst + cc * plane, acc);
             }
         }
     }
@@ -722,12 +727,12 @@ int warp_forward(const void *image, const void *flow, void *out, void *ctx, int6
         CERB_PICK_CG(C, CERB_DISPATCH(dtype, hipLaunchKernelGGL(
             (warp_fwd_kernel<T, true, CG>), grid, dim3(kPix * CG), 0, s,
             static_cast<const T *>(image), static_cast<const T *>(flow), static_cast<T *>(out), ctx,
-            B, C, H, W, pad_mode, interp)))
+            B, C, H, W, pad_mode, interp, option_value("corr_debug_ablate"))))
     } else {
         CERB_PICK_CG(C, CERB_DISPATCH(dtype, hipLaunchKernelGGL(
             (warp_fwd_kernel<T, false, CG>), grid, dim3(kPix * CG), 0, s,
             static_cast<const T *>(image), static_cast<const T *>(flow), static_cast<T *>(out), ctx,
-            B, C, H, W, pad_mode, interp)))
+            B, C, H, W, pad_mode, interp, option_value("corr_debug_ablate"))))
     }
     return launch_status();
 }
