@@ -483,7 +483,7 @@ __global__ __launch_bounds__(K::THREADS, K::S == 1 ? 5 : 3) void corr_fwd_d4_dma
     const float *__restrict__ x1, const float *__restrict__ x2, float *__restrict__ out, int C,
     int H, int W, int tiles_x, int tiles_y, float slope, int64_t out_bstride) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int S = K::S, TSX = K::TSX, CC = K::CC, NB = K::NB, NINST = K::NINST;
+    constexpr int S = K::S, TSX = K::TSX, CC = K::CC, NB = K::NB;
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
@@ -561,8 +561,8 @@ __global__ __launch_bounds__(K::THREADS, K::S == 1 ? 5 : 3) void corr_fwd_d4_dma
         for (int k = 0; k < nchunks; ++k) {
             // this wave's DMAs for chunk k have landed once at most the younger chunks remain
             const int younger = min(NB - 2, nchunks - 1 - k);
-            if (younger >= 2 && NB >= 4) wait_vmcnt<(NB >= 4 ? 2 : 1) * NINST>();
-            else if (younger == 1) wait_vmcnt<NINST>();
+            if (younger >= 2 && NB >= 4) wait_vmcnt<(NB >= 4 ? 2 : 1) * K::NINST>();
+            else if (younger == 1) wait_vmcnt<K::NINST>();
             else wait_vmcnt<0>();
             __builtin_amdgcn_s_barrier();  // chunk k visible to the compute waves; k-1 consumed
             if (k + NB - 1 < nchunks) issue(k + NB - 1);  // into the buffer chunk k-1 used

@@ -706,7 +706,6 @@ static int ctx_partials(int B, int H, int W) {
 
 // workspace of the tiled backward: 16 reserved bytes + room for a context in case the caller
 // has none from the forward
-constexpr int kTileCW = 4;
 int64_t warp_backward_workspace_bytes(int B, int C, int H, int W) {
     (void)C;
     return 16 + ctx_bytes(B, H, W);
