@@ -155,13 +155,20 @@ template <> struct Gmem<hip_bfloat16> {
                            __uint_as_float(raw.y << 16), __uint_as_float(raw.y & 0xFFFF0000u));
     }
     static __device__ __forceinline__ void store1(hip_bfloat16 *p, float v) { *reinterpret_cast<unsigned short *>(p) = narrow(v); }
+    // two floats -> packed bf16 pair: gfx950's v_cvt_pk_bf16_f32 (round to nearest even, NaN
+    // preserved), one instruction instead of the ~10 of the software rounding per value
+    static __device__ __forceinline__ unsigned int narrow2(float a, float b) {
+        typedef float f2v __attribute__((ext_vector_type(2)));
+        typedef __bf16 bf2v __attribute__((ext_vector_type(2)));
+        return __builtin_bit_cast(unsigned int, __builtin_convertvector(f2v{a, b}, bf2v));
+    }
     static __device__ __forceinline__ void store2(hip_bfloat16 *p, float a, float b) {
-        *reinterpret_cast<unsigned int *>(p) = narrow(a) | (static_cast<unsigned int>(narrow(b)) << 16);
+        *reinterpret_cast<unsigned int *>(p) = narrow2(a, b);
     }
     static __device__ __forceinline__ void store4(hip_bfloat16 *p, float4 v) {
         uint2 raw;
-        raw.x = narrow(v.x) | (static_cast<unsigned int>(narrow(v.y)) << 16);
-        raw.y = narrow(v.z) | (static_cast<unsigned int>(narrow(v.w)) << 16);
+        raw.x = narrow2(v.x, v.y);
+        raw.y = narrow2(v.z, v.w);
         *reinterpret_cast<uint2 *>(p) = raw;
     }
 };
