@@ -109,6 +109,36 @@ def test_meta_shapes():
     assert g1.shape == x.shape and g2.shape == x.shape
 
 
+def test_warp_context_ops_are_registered_and_fail_loudly_on_cpu():
+    """The training-path warp ops (forward that saves its backward context, backward that
+    consumes it): schemas, meta shapes consistent with the C ABI's size function, and no
+    silent CPU path -- with and without autograd."""
+    lib = _lib.get()
+    s = str(torch.ops.cerberus.flow_warp_ctx.default._schema)
+    assert s.endswith("-> (Tensor, Tensor)")
+    b = str(torch.ops.cerberus.flow_warp_backward_ctx.default._schema)
+    assert "Tensor context" in b and b.endswith("-> Tensor[]")
+    x = torch.empty(2, 8, 16, 32, device="meta")
+    f = torch.empty(2, 2, 16, 32, device="meta")
+    out, ctx = torch.ops.cerberus.flow_warp_ctx(x, f, 1, 0)
+    assert out.shape == x.shape
+    assert ctx.numel() * ctx.element_size() >= lib.cerberus_flow_warp_context_bytes(2, 16, 32)
+    gi, gf = torch.ops.cerberus.flow_warp_backward_ctx(x, f, ctx, x, 1, 0, True, True)
+    assert gi.shape == x.shape and gf.shape == f.shape
+    xc = torch.randn(1, 4, 8, 8, requires_grad=True)
+    with pytest.raises(RuntimeError, match="no CPU implementation"):
+        ca.flow_warp(xc, torch.zeros(1, 2, 8, 8))            # autograd path -> flow_warp_ctx
+    with pytest.raises(RuntimeError, match="no CPU implementation"):
+        torch.ops.cerberus.flow_warp_backward_ctx(xc.detach(), torch.zeros(1, 2, 8, 8),
+                                                  torch.zeros(16, dtype=torch.int64),
+                                                  xc.detach(), 1, 0, True, True)
+    # context / workspace sizes grow with the shape and never go negative
+    assert lib.cerberus_flow_warp_context_bytes(0, 8, 8) == 2048 * 8
+    assert lib.cerberus_flow_warp_context_bytes(-1, 8, 8) == 0
+    assert (lib.cerberus_flow_warp_backward_workspace_bytes(4, 32, 128, 256)
+            == 16 + lib.cerberus_flow_warp_context_bytes(4, 128, 256))
+
+
 def test_correlation_torch_equals_oracle_restatement():
     import oracle
     a, b = torch.randn(2, 5, 6, 7), torch.randn(2, 5, 6, 7)
