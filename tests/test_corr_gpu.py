@@ -475,3 +475,37 @@ def test_dma_pipelines_with_fewer_chunks_than_ring_buffers(C, hw):
     r1, r2 = oracle.corr_backward_ref(x1, x2, go, 4, 1, 4, 1, 1)
     assert rel_err(out, ref) < TOL
     assert rel_err(g1, r1) < TOL and rel_err(g2, r2) < TOL
+
+
+def test_seeded_random_shape_sweep_tuned_vs_generic():
+    """60 seeded random shapes (odd channel counts, ragged tiles, tiny and wide maps, W % 4 == 0
+    and not): every tuned dispatch (LDS-DMA, register-staged, three-group) against the generic
+    kernels, which the other tests pin to the oracle.  Forward and both gradients."""
+    import numpy as np
+    rng = np.random.RandomState(20240607)
+    kernels = set()
+    for trial in range(60):
+        B = int(rng.randint(1, 4))
+        C = int(rng.choice([1, 2, 3, 5, 8, 12, 17, 32, 48, 64, 96]))
+        H = int(rng.randint(1, 41))
+        W = int(rng.choice([4, 8, 12, 20, 28, 32, 36, 64, 68, 100, 128, 132, 200])) + int(rng.randint(0, 2)) * int(rng.randint(0, 4))
+        shape = (B, C, H, W)
+        x1 = torch.from_numpy(hash_uniform(shape, 900 + trial)).to(DEV)
+        x2 = torch.from_numpy(hash_uniform(shape, 1900 + trial)).to(DEV)
+        go = torch.from_numpy(hash_uniform((B, 81, H, W), 2900 + trial)).to(DEV)
+        p = (4, 1, 4, 1, 1, 1)
+        out = torch.ops.cerberus.correlation(x1, x2, *p)
+        kernels.add(_lib.last_kernel(0))
+        g1, g2 = torch.ops.cerberus.correlation_backward(x1, x2, go, *p)
+        kernels.add(_lib.last_kernel(1))
+        _lib.set_option("corr_force_generic", 1)
+        try:
+            ref = torch.ops.cerberus.correlation(x1, x2, *p)
+            r1, r2 = torch.ops.cerberus.correlation_backward(x1, x2, go, *p)
+        finally:
+            _lib.set_option("corr_force_generic", 0)
+        for a, b, what in ((out, ref, "out"), (g1, r1, "g1"), (g2, r2, "g2")):
+            scale = float(b.abs().max()) or 1.0
+            err = float((a - b).abs().max()) / scale
+            assert err < TOL, (shape, what, err, sorted(kernels))
+    assert any("dma" in k for k in kernels) and any("generic" not in k for k in kernels), kernels

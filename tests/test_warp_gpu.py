@@ -255,3 +255,27 @@ def test_backward_with_more_strips_than_context_partials():
     assert rel_err(out.cpu().numpy(), ref.numpy()) < TOL
     assert rel_err(gi.cpu().numpy(), rgi.numpy()) < TOL
     assert rel_err(gf.cpu().numpy(), rgf.numpy()) < TOL
+
+
+def test_seeded_random_shape_sweep_against_the_oracle():
+    """24 seeded random shapes / flow magnitudes / paddings: forward, grad_image and grad_flow of
+    the context path against the torch-CPU oracle (ragged tiles, single rows, odd channel
+    counts, flows from sub-pixel to larger than the image)."""
+    import numpy as np
+    rng = np.random.RandomState(777)
+    for trial in range(24):
+        B = int(rng.randint(1, 3))
+        C = int(rng.choice([1, 3, 4, 7, 16, 33]))
+        H = int(rng.randint(2, 50))
+        W = int(rng.randint(2, 150))
+        amp = float(rng.choice([0.3, 2.0, 9.0, 40.0, 300.0]))
+        pad = ["border", "zeros"][int(rng.randint(0, 2))]
+        shape = (B, C, H, W)
+        img, go = hash_uniform(shape, 3000 + trial), hash_uniform(shape, 4000 + trial)
+        flo = hash_uniform((B, 2, H, W), 5000 + trial, -amp, amp)
+        ref, rgi, rgf = oracle.flow_warp_grads_ref(torch.from_numpy(img), torch.from_numpy(flo),
+                                                   torch.from_numpy(go), pad)
+        out, gi, gf = hip_warp_with_grads(img, flo, go, pad)
+        assert rel_err(out, ref.numpy()) < TOL, (shape, amp, pad)
+        assert rel_err(gi, rgi.numpy()) < TOL, (shape, amp, pad)
+        assert rel_err(gf, rgf.numpy()) < TOL, (shape, amp, pad)
