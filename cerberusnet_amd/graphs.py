@@ -10,6 +10,7 @@ optionally the optimizer update -- can be captured ONCE into a hipGraph and repl
 
 This is plain ``torch.cuda.CUDAGraph`` (= hipGraph on ROCm) plumbing; no tracing compiler.
 """
+import gc
 from typing import Callable, List, Optional, Sequence
 
 import torch
@@ -44,18 +45,32 @@ class GraphedFlowStep:
         self.static2 = [t.detach().clone().requires_grad_(input_grads) for t in pyr2]
         self.params = [p for p in head.parameters() if p.requires_grad]
 
-        # warm-up on a side stream (MIOpen picks its algorithms, the allocator its blocks)
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
+        # Warm-up AND capture run on ONE private stream.  Autograd pins every leaf's
+        # AccumulateGrad node to the stream that was current when the node was created; with
+        # the warm-up on one side stream and the capture on another (torch.cuda.graph's
+        # default), the nodes kept alive from the warm-up made the engine hop streams inside
+        # the capture ("AccumulateGrad node's stream does not match ...", round-1 driver log).
+        # The warm-up lets MIOpen pick its algorithms and the allocator its blocks.
+        self.stream = torch.cuda.Stream()
+        self.stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.stream):
             for _ in range(max(1, warmup)):
                 self._step(set_to_none=True)
-        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.current_stream().wait_stream(self.stream)
         torch.cuda.synchronize()
+        gc.collect()   # autograd graphs of the warm-up (Function ctx cycles) die before capture
 
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.loss, self.flows_fw, self.flows_bw = self._step(set_to_none=True)
+        with torch.cuda.graph(self.graph, stream=self.stream):
+            loss, fw, bw = self._step(set_to_none=True)
+        # static outputs WITHOUT their autograd graph: a kept grad_fn would keep the captured
+        # step's AccumulateGrad nodes (pinned to the capture stream) alive, and a later eager
+        # backward on another stream would have to hop to it
+        self.loss = loss.detach()
+        self.flows_fw = [f.detach() for f in fw]
+        self.flows_bw = [f.detach() for f in bw]
+        del loss, fw, bw
+        gc.collect()
         # the gradient tensors the graph writes (graph-pool memory): kept here and re-attached
         # on every call, so that an outside ``zero_grad(set_to_none=True)`` or an eager step in
         # between cannot leave ``p.grad`` pointing somewhere the replay does not write

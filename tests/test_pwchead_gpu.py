@@ -69,41 +69,53 @@ def test_both_directions_training_step_runs_and_is_finite():
 
 def test_graphed_flow_step_equals_eager():
     """the whole bidirectional head step captured into one hipGraph must give
-    the eager step's loss, flows and gradients, for the captured inputs and for new ones."""
+    the eager step's loss, flows and gradients, for the captured inputs and for new ones.
+
+    The comparison is BIT-EXACT and runs with MIOpen's deterministic algorithms.  Measured on
+    MI355X (tools/diag_graph_step.py, round 2): with the default (atomic) convolution
+    algorithms two EAGER runs of the same step already differ -- flows by 2e-7 and, because a
+    last-bit change of a flow value can flip a floor() in the warp's bilinear taps, the finest
+    level's input gradient by up to 1.7e-3 in l2 (0.5 % of its elements) -- which is what made
+    the round-1 form of this test (l2 < 1e-3, default algorithms) flaky.  With deterministic
+    algorithms eager == eager == graph replay, to the last bit, for every tensor: every kernel
+    of this package is bit-reproducible, so that is the honest bar."""
     from cerberusnet_amd.graphs import GraphedFlowStep
-    torch.manual_seed(3)
-    head = build("FlowEstimatorLite").to(DEV)
-    shapes = [(2, c, 8 * 2 ** l, 16 * 2 ** l) for l, c in enumerate(reversed(CHANS))]
-    mk = lambda: [torch.randn(s, device=DEV) for s in shapes]
-    loss_fn = lambda flows: sum(f.abs().mean() for f in flows)
+    det = torch.backends.cudnn.deterministic
+    torch.backends.cudnn.deterministic = True
+    try:
+        torch.manual_seed(3)
+        head = build("FlowEstimatorLite").to(DEV)
+        shapes = [(2, c, 8 * 2 ** l, 16 * 2 ** l) for l, c in enumerate(reversed(CHANS))]
+        mk = lambda: [torch.randn(s, device=DEV) for s in shapes]
+        loss_fn = lambda flows: sum(f.abs().mean() for f in flows)
 
-    def eager(p1, p2):
-        for p in head.parameters():
-            p.grad = None
-        a = [t.clone().requires_grad_(True) for t in p1]
-        b = [t.clone().requires_grad_(True) for t in p2]
-        fw = head((None, a), (None, b))
-        bw = head((None, b), (None, a))
-        loss = loss_fn(list(fw) + list(bw))
-        loss.backward()
-        return (loss.detach().clone(), [f.detach().clone() for f in fw],
-                [p.grad.detach().clone() for p in head.parameters()],
-                [t.grad.detach().clone() for t in a])
+        def eager(p1, p2):
+            for p in head.parameters():
+                p.grad = None
+            a = [t.clone().requires_grad_(True) for t in p1]
+            b = [t.clone().requires_grad_(True) for t in p2]
+            fw = head((None, a), (None, b))
+            bw = head((None, b), (None, a))
+            loss = loss_fn(list(fw) + list(bw))
+            loss.backward()
+            return (loss.detach().clone(), [f.detach().clone() for f in fw],
+                    [p.grad.detach().clone() for p in head.parameters()],
+                    [t.grad.detach().clone() for t in a] + [t.grad.detach().clone() for t in b])
 
-    p1, p2 = mk(), mk()
-    step = GraphedFlowStep(head, loss_fn, p1, p2, input_grads=True)
-    for trial in range(2):
-        if trial:
-            p1, p2 = mk(), mk()
-        loss, fw, _ = step(p1, p2)
-        g_loss, g_fw = loss.detach().clone(), [f.detach().clone() for f in fw]
-        g_par = [p.grad.detach().clone() for p in head.parameters()]
-        g_in = [g.detach().clone() for g in step.input_gradients()[0]]
-        e_loss, e_fw, e_par, e_in = eager(p1, p2)
-        assert abs(float(g_loss) - float(e_loss)) <= 1e-5 * abs(float(e_loss))
-        for a, b in zip(g_fw, e_fw):
-            assert rel_err(a.cpu().numpy(), b.cpu().numpy()) < 1e-5
-        for a, b in zip(g_par + g_in, e_par + e_in):
-            assert l2_err(a.cpu().numpy(), b.cpu().numpy()) < 1e-3
-    with pytest.raises(RuntimeError, match="shape"):
-        step([t[:1] for t in p1], p2)
+        p1, p2 = mk(), mk()
+        step = GraphedFlowStep(head, loss_fn, p1, p2, input_grads=True)
+        for trial in range(3):
+            if trial:
+                p1, p2 = mk(), mk()
+            loss, fw, _ = step(p1, p2)
+            g_loss, g_fw = loss.detach().clone(), [f.detach().clone() for f in fw]
+            g_par = [p.grad.detach().clone() for p in head.parameters()]
+            g_in = [g.detach().clone() for g in step.input_gradients()[0] + step.input_gradients()[1]]
+            e_loss, e_fw, e_par, e_in = eager(p1, p2)
+            assert torch.equal(g_loss, e_loss)
+            for a, b in zip(g_fw + g_par + g_in, e_fw + e_par + e_in):
+                assert torch.equal(a, b)
+        with pytest.raises(RuntimeError, match="shape"):
+            step([t[:1] for t in p1], p2)
+    finally:
+        torch.backends.cudnn.deterministic = det
