@@ -10,7 +10,7 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libcerberus_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _lock = threading.Lock()
 _lib = None
@@ -30,9 +30,9 @@ PROTOTYPES = {
     "cerberus_correlation_backward": (_I, [_P, _P, _P, _P, _P] + [_I] * 11 + [_P]),
     "cerberus_flow_warp_forward": (_I, [_P, _P, _P] + [_I] * 7 + [_P]),
     "cerberus_flow_warp_context_bytes": (_I64, [_I, _I, _I]),
-    "cerberus_flow_warp_forward_ctx": (_I, [_P, _P, _P, _P, _I64] + [_I] * 7 + [_P]),
+    "cerberus_flow_warp_forward_ctx": (_I, [_P, _P, _P, _P, _I64] + [_I] * 8 + [_P]),
     "cerberus_flow_warp_backward_workspace_bytes": (_I64, [_I, _I, _I, _I]),
-    "cerberus_flow_warp_backward": (_I, [_P, _P, _P, _P, _P, _P, _I64, _P, _I64] + [_I] * 7 + [_P]),
+    "cerberus_flow_warp_backward": (_I, [_P, _P, _P, _P, _P, _P, _I64, _P, _I64] + [_I] * 8 + [_P]),
     "cerberus_set_option": (_I, [ctypes.c_char_p, _I]),
     "cerberus_get_option": (_I, [ctypes.c_char_p, ctypes.POINTER(_I)]),
     "cerberus_last_kernel": (ctypes.c_char_p, [_I]),

@@ -8,31 +8,33 @@
 
 namespace cerb {
 namespace {
-struct Option { const char *key; std::atomic<int> value; };
-Option g_options[] = {{"corr_force_generic", {0}},   // 1: always use the generic kernels
-                      {"corr_fwd_variant", {0}},     // 0: auto, 1..8: force a register-staged variant, 9..13: LDS-DMA
-                      {"corr_bwd_cslice", {0}},      // 0: auto, else channels per backward workgroup
-                      {"corr_debug_ablate", {0}},    // timing ablation mask (WRONG results when != 0)
-                      {"warp_pair_taps", {0}},
-                             // 0: default, 1: pairs everywhere, 2: none
-                      {"warp_tile_cw", {0}},         // 0: auto, 4 / 8: channels per warp-backward tile workgroup
-                      {"corr_bwd_variant", {0}}};    // 0: auto, 1: all-81 per lane, 2/3: 3 dy groups, 4/5: LDS-DMA (8x64 / 16x32 tile)
+// indexed by OptId (common.h)
+const char *const g_option_names[OPT_COUNT] = {
+    "corr_force_generic",   // 1: always use the generic kernels
+    "corr_fwd_variant",     // 0: auto, 1..8: force a register-staged variant, 9..13: LDS-DMA
+    "corr_bwd_variant",     // 0: auto, 1: all-81 per lane, 2/3: 3 dy groups, 4/5: LDS-DMA, 6: dy-streaming
+    "corr_bwd_cslice",      // 0: auto, else channels per backward workgroup
+    "warp_pair_taps",       // 0: default, 1: pairs everywhere, 2: none
+    "warp_tile_ranges",     // 0: auto, else channel ranges per warp-backward tile
+    "warp_tile_h",          // 0: auto, 8 / 16: rows per warp-backward tile
+    "warp_force_scatter",   // 1: warp backward by global atomics (ATen's method) even with a context
+#ifdef CERB_ABLATE
+    "corr_debug_ablate",    // timing ablation mask (WRONG results when != 0); ablation builds only
+#endif
+};
+std::atomic<int> g_option_values[OPT_COUNT];
 thread_local const char *t_last_kernel[2] = {"none", "none"};
 
-Option *find_option(const char *key) {
-    for (auto &o : g_options)
-        if (!std::strcmp(o.key, key)) return &o;
-    return nullptr;
+int find_option(const char *key) {
+    for (int i = 0; i < OPT_COUNT; ++i)
+        if (!std::strcmp(g_option_names[i], key)) return i;
+    return -1;
 }
 
 bool dtype_ok(int dtype) { return dtype >= CERB_F32 && dtype <= CERB_F64; }
 }  // namespace
 
-int option_force_generic() { return g_options[0].value.load(std::memory_order_relaxed); }
-int option_value(const char *key) {
-    Option *o = find_option(key);
-    return o ? o->value.load(std::memory_order_relaxed) : 0;
-}
+int option(OptId id) { return g_option_values[id].load(std::memory_order_relaxed); }
 void note_kernel(int which, const char *name) { t_last_kernel[which & 1] = name; }
 }  // namespace cerb
 
@@ -81,12 +83,11 @@ int cerberus_correlation_forward_ex(const void *input1, const void *input2, void
     if (rc) return rc;
     if (B == 0) return CERB_OK;
     if (!input1 || !input2 || !output) return CERB_EINVAL;
-    if (B > 65535) return CERB_ETOOLARGE;
     if (out_batch_stride != 0 &&
         out_batch_stride < static_cast<int64_t>(g.oC) * g.oH * g.oW)
         return CERB_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (!option_force_generic()) {
+    if (!option(OPT_CORR_FORCE_GENERIC)) {
         rc = corr_d4_forward(input1, input2, output, g, negative_slope, out_batch_stride, dtype, s);
         if (rc != CERB_EUNSUPPORTED) return rc;
     }
@@ -119,9 +120,8 @@ int cerberus_correlation_backward(const void *input1, const void *input2, const 
     if (stride1 != 1) return CERB_ESTRIDE1;
     if (B == 0) return CERB_OK;
     if (!input1 || !input2 || !grad_output || !grad_input1 || !grad_input2) return CERB_EINVAL;
-    if (B > 65535) return CERB_ETOOLARGE;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (!option_force_generic()) {
+    if (!option(OPT_CORR_FORCE_GENERIC)) {
         rc = corr_d4_backward(input1, input2, grad_output, grad_input1, grad_input2, g, dtype, s);
         if (rc != CERB_EUNSUPPORTED) return rc;
     }
@@ -133,7 +133,6 @@ int cerberus_correlation_backward(const void *input1, const void *input2, const 
 static int warp_args_ok(int B, int C, int H, int W, int pad_mode, int interp_mode, int dtype) {
     if (!dtype_ok(dtype)) return CERB_EDTYPE;
     if (B < 0 || C <= 0 || H <= 0 || W <= 0) return CERB_EINVAL;
-    if (B > 65535) return CERB_ETOOLARGE;
     if (pad_mode < CERB_PAD_ZEROS || pad_mode > CERB_PAD_REFLECTION) return CERB_EMODE;
     if (interp_mode < CERB_INTERP_BILINEAR || interp_mode > CERB_INTERP_NEAREST) return CERB_EMODE;
     return CERB_OK;
@@ -142,7 +141,7 @@ static int warp_args_ok(int B, int C, int H, int W, int pad_mode, int interp_mod
 int cerberus_flow_warp_forward(const void *image, const void *flow, void *out, int B, int C, int H,
                                int W, int pad_mode, int interp_mode, int dtype, void *stream) {
     return cerberus_flow_warp_forward_ctx(image, flow, out, nullptr, 0, B, C, H, W, pad_mode,
-                                          interp_mode, dtype, stream);
+                                          interp_mode, dtype, dtype, stream);
 }
 
 int64_t cerberus_flow_warp_context_bytes(int B, int H, int W) {
@@ -152,13 +151,15 @@ int64_t cerberus_flow_warp_context_bytes(int B, int H, int W) {
 
 int cerberus_flow_warp_forward_ctx(const void *image, const void *flow, void *out, void *context,
                                    int64_t context_bytes, int B, int C, int H, int W,
-                                   int pad_mode, int interp_mode, int dtype, void *stream) {
+                                   int pad_mode, int interp_mode, int dtype, int flow_dtype,
+                                   void *stream) {
     const int rc = warp_args_ok(B, C, H, W, pad_mode, interp_mode, dtype);
     if (rc) return rc;
+    if (!dtype_ok(flow_dtype)) return CERB_EDTYPE;
     if (B == 0) return CERB_OK;
     if (!image || !flow || !out) return CERB_EINVAL;
     return warp_forward(image, flow, out, context, context_bytes, B, C, H, W, pad_mode,
-                        interp_mode, dtype, static_cast<hipStream_t>(stream));
+                        interp_mode, dtype, flow_dtype, static_cast<hipStream_t>(stream));
 }
 
 int64_t cerberus_flow_warp_backward_workspace_bytes(int B, int C, int H, int W) {
@@ -170,30 +171,31 @@ int cerberus_flow_warp_backward(const void *image, const void *flow, const void 
                                 void *grad_image, void *grad_flow, const void *context,
                                 int64_t context_bytes, void *workspace, int64_t workspace_bytes,
                                 int B, int C, int H, int W, int pad_mode, int interp_mode,
-                                int dtype, void *stream) {
+                                int dtype, int flow_dtype, void *stream) {
     const int rc = warp_args_ok(B, C, H, W, pad_mode, interp_mode, dtype);
     if (rc) return rc;
+    if (!dtype_ok(flow_dtype)) return CERB_EDTYPE;
     if (B == 0) return CERB_OK;
     if (!image || !flow || !grad_out) return CERB_EINVAL;
     if (!grad_image && !grad_flow) return CERB_OK;
     return warp_backward(image, flow, grad_out, grad_image, grad_flow, context, context_bytes,
                          workspace, workspace_bytes, B, C, H, W, pad_mode, interp_mode, dtype,
-                         static_cast<hipStream_t>(stream));
+                         flow_dtype, static_cast<hipStream_t>(stream));
 }
 
 int cerberus_set_option(const char *key, int value) {
     if (!key) return CERB_EINVAL;
-    Option *o = find_option(key);
-    if (!o) return CERB_EINVAL;
-    o->value.store(value, std::memory_order_relaxed);
+    const int i = find_option(key);
+    if (i < 0) return CERB_EINVAL;
+    g_option_values[i].store(value, std::memory_order_relaxed);
     return CERB_OK;
 }
 
 int cerberus_get_option(const char *key, int *value) {
     if (!key || !value) return CERB_EINVAL;
-    Option *o = find_option(key);
-    if (!o) return CERB_EINVAL;
-    *value = o->value.load(std::memory_order_relaxed);
+    const int i = find_option(key);
+    if (i < 0) return CERB_EINVAL;
+    *value = g_option_values[i].load(std::memory_order_relaxed);
     return CERB_OK;
 }
 

@@ -61,10 +61,44 @@ static inline int corr_geom_init(CorrGeom &g, int B, int C, int H, int W, int pa
     return CERB_OK;
 }
 
-// process-wide knobs (api.hip)
-int option_force_generic();
-int option_value(const char *key);
+// process-wide knobs (api.hip): resolved to an index at compile time, one relaxed atomic
+// load per use (names only matter to cerberus_set_option / cerberus_get_option)
+enum OptId {
+    OPT_CORR_FORCE_GENERIC = 0,
+    OPT_CORR_FWD_VARIANT,
+    OPT_CORR_BWD_VARIANT,
+    OPT_CORR_BWD_CSLICE,
+    OPT_WARP_PAIR_TAPS,
+    OPT_WARP_TILE_RANGES,
+    OPT_WARP_TILE_H,
+    OPT_WARP_FORCE_SCATTER,
+#ifdef CERB_ABLATE
+    OPT_DEBUG_ABLATE,   // timing-ablation mask: exists in -DCERB_ABLATE builds only
+#endif
+    OPT_COUNT
+};
+int option(OptId id);
+// ablation mask of the correlation kernels: the constant 0 in the product build
+static inline int debug_mask() {
+#ifdef CERB_ABLATE
+    return option(OPT_DEBUG_ABLATE);
+#else
+    return 0;
+#endif
+}
 void note_kernel(int which, const char *name);
+
+// XCD-aware work-item order (speed only, never correctness).  The dispatcher deals
+// workgroups round-robin over the 8 XCDs, each with a private 4 MiB L2, so blocks b and b+8
+// share an L2 but b and b+1 do not.  Remap so that every XCD walks ONE contiguous range of
+// work items: spatial neighbours (which share halo lines) then hit in the same L2 instead
+// of going back to the fabric.  Bijective for any block count.
+__device__ __forceinline__ int xcd_chunk(int bid, int nblocks) {
+    constexpr int kXcd = 8;
+    const int x = bid % kXcd, idx = bid / kXcd;
+    const int q = nblocks / kXcd, rem = nblocks % kXcd;
+    return x * q + min(x, rem) + idx;
+}
 
 // ---- launchers implemented in the kernel translation units ------------------
 // all return hipError_t (as int) of the launch, or a negative CERB_E* code.
@@ -84,11 +118,12 @@ int corr_d4_backward(const void *in1, const void *in2, const void *gout, void *g
 int64_t warp_context_bytes(int B, int H, int W);
 int64_t warp_backward_workspace_bytes(int B, int C, int H, int W);
 int warp_forward(const void *image, const void *flow, void *out, void *ctx, int64_t ctx_size,
-                 int B, int C, int H, int W, int pad_mode, int interp, int dtype, hipStream_t s);
+                 int B, int C, int H, int W, int pad_mode, int interp, int dtype, int flow_dtype,
+                 hipStream_t s);
 int warp_backward(const void *image, const void *flow, const void *gout, void *gimage,
                   void *gflow, const void *ctx, int64_t ctx_size, void *workspace,
                   int64_t workspace_bytes, int B, int C, int H, int W, int pad_mode, int interp,
-                  int dtype, hipStream_t s);
+                  int dtype, int flow_dtype, hipStream_t s);
 
 static inline int launch_status() {
     hipError_t e = hipGetLastError();

@@ -30,6 +30,8 @@
 //
 // No MFMA: this is a gather-reduce (a banded product wastes >7x the flops as a
 // dense GEMM and fp32 MFMA runs at the vector rate anyway).
+#include <atomic>
+
 #include "common.h"
 
 namespace cerb {
@@ -41,20 +43,6 @@ constexpr int kP = 4;            // pixels per lane in forward (one float4)
 
 __host__ __device__ constexpr int pad_to_residue(int x, int res) {
     return x + ((res - x % 64) + 64) % 64;
-}
-
-// XCD-aware work-item order (speed only, never correctness).  The dispatcher deals
-// workgroups round-robin over the 8 XCDs, each with a private 4 MiB L2, so
-// blocks b and b+8 share an L2 but b and b+1 do not.  Remap so that every XCD
-// walks ONE contiguous range of tiles: spatial neighbours (which share halo rows
-// of x2 and the gradOutput tile) then hit in the same L2 instead of going back
-// to the fabric.  Bijective for any block count.  (Measured on the first
-// version: L2 hit rate 20-38 %, fabric reads 2.2x the algorithmic bytes.)
-__device__ __forceinline__ int xcd_swizzle(int bid, int nblocks) {
-    constexpr int kXcd = 8;
-    const int x = bid % kXcd, idx = bid / kXcd;
-    const int q = nblocks / kXcd, rem = nblocks % kXcd;
-    return x * q + min(x, rem) + idx;
 }
 
 // ============================================================================
@@ -215,7 +203,7 @@ __global__ __launch_bounds__(K::THREADS, K::WPS) void corr_fwd_d4_kernel(
     const int r = si / TSX;
     const int sx = (K::ROT == 0) ? si % TSX : (si % TSX + TSX - (K::ROT * r) % TSX) % TSX;
 
-    int bid = xcd_swizzle(blockIdx.x, gridDim.x);
+    int bid = xcd_chunk(blockIdx.x, gridDim.x);
     const int tx = bid % tiles_x; bid /= tiles_x;
     const int ty = bid % tiles_y;
     const int b = bid / tiles_y;
@@ -500,7 +488,7 @@ __global__ __launch_bounds__(K::THREADS, K::S == 1 ? 5 : 3) void corr_fwd_d4_dma
     const int r = si / TSX;
     const int sx = (K::ROT == 0) ? si % TSX : (si % TSX + TSX - (K::ROT * r) % TSX) % TSX;
 
-    int bid = xcd_swizzle(blockIdx.x, gridDim.x);
+    int bid = xcd_chunk(blockIdx.x, gridDim.x);
     const int tx = __builtin_amdgcn_readfirstlane(bid % tiles_x); bid /= tiles_x;
     const int ty = __builtin_amdgcn_readfirstlane(bid % tiles_y);
     const int b = __builtin_amdgcn_readfirstlane(bid / tiles_y);
@@ -707,7 +695,7 @@ __global__ __launch_bounds__(K::THREADS, 2) void corr_bwd_d4_kernel(
 
     // (tile, channel slice, side) with the side fastest: the two workgroups that read
     // the same gradOutput tile are adjacent in the swizzled order -> same XCD, same time
-    int bid = xcd_swizzle(blockIdx.x, gridDim.x);
+    int bid = xcd_chunk(blockIdx.x, gridDim.x);
     const int side = bid & 1; bid >>= 1;         // 0: gradInput1, 1: gradInput2
     const int slice = bid % nslice; bid /= nslice;
     const int tx = bid % tiles_x; bid /= tiles_x;
@@ -1047,7 +1035,7 @@ __global__ __launch_bounds__(K::THREADS, K::NW == 4 ? 2 : 1) void corr_bwd_d4_dm
 
     // runtime divisions run on the VALU: pin the (uniform) results to SGPRs, a buffer
     // resource held in VGPRs costs a waterfall loop around every DMA
-    int bid = xcd_swizzle(blockIdx.x, gridDim.x);
+    int bid = xcd_chunk(blockIdx.x, gridDim.x);
     const int side = __builtin_amdgcn_readfirstlane(bid & 1); bid >>= 1;  // 0: gradInput1
     const int slice = __builtin_amdgcn_readfirstlane(bid % nslice); bid /= nslice;
     const int tx = __builtin_amdgcn_readfirstlane(bid % tiles_x); bid /= tiles_x;
@@ -1184,7 +1172,7 @@ __global__ __launch_bounds__(K::THREADS, 3) void corr_bwd_d4_g3_kernel(
     const int sxp = lane % K::TSXP;
     const int slot_lane = sw * 64 + lane;  // index of this lane's pixel pair inside the tile
 
-    int bid = xcd_swizzle(blockIdx.x, gridDim.x);
+    int bid = xcd_chunk(blockIdx.x, gridDim.x);
     const int side = bid & 1; bid >>= 1;
     const int slice = bid % nslice; bid /= nslice;
     const int tx = bid % tiles_x; bid /= tiles_x;
@@ -1359,22 +1347,296 @@ __global__ __launch_bounds__(K::THREADS, 3) void corr_bwd_d4_g3_kernel(
     }
 }
 
+// ============================================================================
+// backward, displacement-row streaming variant (fp32, vector path)
+// ============================================================================
+// The kernels above keep a pixel's 81 gradOutput values in registers (162 VGPRs for two
+// pixels: 2 waves/SIMD) and stream CHANNELS through LDS; every channel slice gathers those 81
+// values again, and the gather (12 of 38 us at the 32x128x256 level, the same ~85 MB at every
+// level) cannot overlap the FMA phase of its own workgroup.  This kernel turns the loops
+// inside out -- the dual of the forward: the ACCUMULATORS (4 channels x a 4-pixel strip per
+// lane) stay in registers and the nine vertical displacements are streamed, for all the
+// channels of the workgroup at once:
+//
+//   gI1[c][y][x] = 1/C sum_dy sum_dx gO[dy,dx][y][x]       * x2[c][y+dy][x+dx]
+//   gI2[c][y][x] = 1/C sum_ey sum_ex gO[-ey,-ex][y+ey][x+ex] * x1[c][y+ey][x+ex]
+//
+//   step s (dy or ey = s-4), lane = (tile row r, strip sx), wave = 4 channels:
+//     g[j][0..3]  the 9 gradOutput planes of this step at the lane's strip (side 2: the
+//                 plane (-ey,-ex) at the strip shifted by (ey,ex))           <- LDS, 9-15 b128
+//     w[0..11]    window row y+dy of one channel, columns x-4 .. x+7          <- LDS, 3 b128
+//     acc[ch][px] += g[j][px] * w[px+j]                                        36 FMAs / channel
+//
+// so gradOutput is read ONCE per (tile, side) whatever the channel count, nothing is
+// gathered into registers up front, a lane needs ~90 VGPRs (4-5 waves/SIMD), and both LDS
+// images arrive by LDS-DMA a step (gradOutput) or two (window rows) ahead of their use:
+//   * window: a ring of TH+2 image rows x all channels of the workgroup ([row][channel][72
+//     floats]; rows are 32*72 floats apart = 0 mod 64 banks, which is exactly what the
+//     ds_read_b128 lane groups want); each step retires one row and lands one.
+//   * gradOutput: two buffers of [9 planes][TH rows][72 floats] (aligned 16-byte slots with
+//     a 4-pixel halo, out-of-image slots read zeros through the buffer resource: exact, also
+//     for NaN / Inf neighbours); side 2's shift by ex is a compile-time register selection
+//     inside the 12 floats a lane reads.
+// Every wave issues its share of the DMA instructions of a step before it computes, waits
+// with a counted vmcnt for everything but the row it just requested, and the workgroup meets
+// at one barrier per step.
+template <int CB_, int NG_>
+struct BwdRowsCfg {
+    static constexpr int CB = CB_, NG = NG_, CR = CB * NG;     // channels per wave / waves / channels per workgroup
+    static constexpr int TH = 4, TSX = 16, TW = TSX * kP;       // 4 x 64 tile: one wave of strips
+    static constexpr int NRING = TH + 2;
+    static constexpr int RSF = 72;                              // floats per staged row (64 + 2*4 halo)
+    static constexpr int ROWF = CR * RSF;                       // floats per ring row (all channels)
+    static constexpr int GBUF = kND * TH * RSF;                 // floats per gradOutput buffer
+    static constexpr int NGB = 2;
+    static constexpr int THREADS = 64 * NG;
+    static constexpr int ROW_SLOTS = CR * (RSF / 4), G_SLOTS = kND * TH * (RSF / 4);
+    static constexpr int ROW_INSTR = (ROW_SLOTS + 63) / 64, G_INSTR = (G_SLOTS + 63) / 64;
+    static constexpr int ROW_PW = (ROW_INSTR + NG - 1) / NG, G_PW = (G_INSTR + NG - 1) / NG;  // per wave
+    static constexpr size_t LDS_BYTES = sizeof(float) * (NRING * ROWF + NGB * GBUF);
+    static_assert(ROWF % 64 == 0, "ring rows must be a multiple of 64 banks apart");
+    static_assert(ROW_PW <= 2 && G_PW <= 2, "at most two DMA instructions of each kind per wave");
+};
+
+// one ds_read_b128, exactly as written: volatile keeps hipcc from splitting a 16-byte LDS read
+// whose elements are only partly used into ds_read_b32 / ds_read2 pieces (seen in the first
+// build of the kernel below: 96 ds_read_b32 + 56 ds_read2 instead of 48 ds_read_b128)
+typedef float f4v_lds __attribute__((ext_vector_type(4)));
+typedef const volatile __attribute__((address_space(3))) f4v_lds *lds_f4_volatile_ptr;
+__device__ __forceinline__ float4 ld4_lds(const float *p) {
+    const f4v_lds v = *(lds_f4_volatile_ptr)(p);
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+
+#if defined(__HIP_DEVICE_COMPILE__)
+// DMA of one window row (image row gy of every channel of the workgroup) into `wr`
+template <typename K>
+__device__ __forceinline__ void rows_issue_row(float *__restrict__ wr, __amdgpu_buffer_rsrc_t rsrc,
+                                               const int (&voff)[K::ROW_PW], int wave, int gy,
+                                               int H, int W, int c_begin, int plane, bool alive) {
+    constexpr int kDead = static_cast<int>(0x80000000u);
+    const bool ok = alive && gy >= 0 && gy < H;                          // wave-uniform
+    const int soff = __builtin_amdgcn_readfirstlane(ok ? (c_begin * plane + gy * W) * 4 : 0);
+#pragma unroll
+    for (int q = 0; q < K::ROW_PW; ++q) {
+        const int inst = wave + K::NG * q;
+        if (inst < K::ROW_INSTR)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_ptr)(wr + inst * 256), 16,
+                                                     ok ? voff[q] : kDead, soff, 0, 0);
+    }
+}
+
+// DMA of the nine gradOutput planes of step s into `wr` ([plane][row][72 floats])
+template <typename K, int SIDE>
+__device__ __forceinline__ void rows_issue_g(float *__restrict__ wr, __amdgpu_buffer_rsrc_t rsrc,
+                                             int wave, int lane, int s, int x0, int y0, int H,
+                                             int W, int plane, bool alive) {
+    constexpr int kDead = static_cast<int>(0x80000000u);
+#pragma unroll
+    for (int q = 0; q < K::G_PW; ++q) {
+        const int inst = wave + K::NG * q;
+        if (inst >= K::G_INSTR) continue;
+        const int i = inst * 64 + lane;                 // slot index in [plane][row][18 slots]
+        const int j = i / (K::TH * 18), rem = i % (K::TH * 18);
+        const int r = rem / 18, sl = rem % 18;
+        // side 0: plane (s, j) at (y0+r, x0-4+4sl), the halo slots are never read;
+        // side 1: plane (-ey,-ex) = (8-s, 8-j) at the row shifted by ey = s-4; the shift by
+        //         ex = j-4 is applied when the lane picks its 4 floats out of the 12 it reads
+        const int pl = SIDE ? (kND - 1 - s) * kND + (kND - 1 - j) : s * kND + j;
+        const int gy = y0 + r + (SIDE ? s - kD : 0);
+        const int gx = x0 - kD + 4 * sl;
+        const bool ok = alive && i < K::G_SLOTS && gy >= 0 && gy < H && gx >= 0 && gx < W &&
+                        (SIDE || (sl >= 1 && sl <= 16));
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_ptr)(wr + inst * 256), 16,
+                                                 ok ? (pl * plane + gy * W + gx) * 4 : kDead, 0, 0, 0);
+    }
+}
+
+// one step: request the next gradOutput planes and the row after next, then consume step s
+template <typename K, int SIDE>
+__device__ __forceinline__ void rows_step(
+    const float *__restrict__ ring, const float *__restrict__ gbuf, float *__restrict__ row_wr,
+    float *__restrict__ g_wr, __amdgpu_buffer_rsrc_t rsrc_src, __amdgpu_buffer_rsrc_t rsrc_go,
+    const int (&voff)[K::ROW_PW], int wave, int lane, int s, int x0, int y0, int H, int W,
+    int c_begin, int plane, const int (&rowoff)[K::TH > 0 ? 1 : 1], int goff,
+    float (&acc)[K::CB][kP]) {
+    rows_issue_g<K, SIDE>(g_wr, rsrc_go, wave, lane, s + 1, x0, y0, H, W, plane, s + 1 < kND);
+    rows_issue_row<K>(row_wr, rsrc_src, voff, wave, y0 - kD + s + K::TH + 1, H, W, c_begin, plane,
+                      s + 2 < kND);
+    // ---- gradOutput of this step: g[j][px] ----
+    // (sched_barriers pin the order "reads of one block, then its FMAs": left alone hipcc
+    // hoists every LDS read of the step to the top and spills 112 VGPRs)
+    float g[kND][kP];
+    const float *gp = gbuf + goff;
+#pragma unroll
+    for (int j = 0; j < kND; ++j) {
+        const float *pj = gp + j * (K::TH * K::RSF);
+        if (SIDE == 0) {
+            const float4 q = ld4_lds(pj + 4);
+            g[j][0] = q.x; g[j][1] = q.y; g[j][2] = q.z; g[j][3] = q.w;
+        } else {
+            // floats j .. j+3 of the 12-float span: one or two aligned quads
+            const int q0 = j / 4;
+            const float4 a = ld4_lds(pj + 4 * q0);
+            float sp[8] = {a.x, a.y, a.z, a.w, 0.f, 0.f, 0.f, 0.f};
+            if (j % 4) {
+                const float4 b = ld4_lds(pj + 4 * q0 + 4);
+                sp[4] = b.x; sp[5] = b.y; sp[6] = b.z; sp[7] = b.w;
+            }
+#pragma unroll
+            for (int p = 0; p < kP; ++p) g[j][p] = sp[j % 4 + p];
+        }
+    }
+    // ---- window rows, CB channels, 36 FMAs each; channel i+1's reads ride under channel i's FMAs ----
+    const float *wp = ring + rowoff[0];
+    float4 w0 = ld4_lds(wp), w1 = ld4_lds(wp + 4), w2 = ld4_lds(wp + 8);
+#pragma unroll
+    for (int i = 0; i < K::CB; ++i) {
+        float4 n0 = w0, n1 = w1, n2 = w2;
+        if (i + 1 < K::CB) {
+            n0 = ld4_lds(wp + (i + 1) * K::RSF);
+            n1 = ld4_lds(wp + (i + 1) * K::RSF + 4);
+            n2 = ld4_lds(wp + (i + 1) * K::RSF + 8);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // channel i's three reads have returned once at most channel i+1's three are pending
+        if (i + 1 < K::CB) __builtin_amdgcn_s_waitcnt(0xC37F);   // lgkmcnt(3)
+        else __builtin_amdgcn_s_waitcnt(0xC07F);                 // lgkmcnt(0)
+        __builtin_amdgcn_sched_barrier(0);
+        const float w[12] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2.x, w2.y, w2.z, w2.w};
+#pragma unroll
+        for (int jj = 0; jj < kND; ++jj)
+#pragma unroll
+            for (int p = 0; p < kP; ++p) acc[i][p] = fmaf(g[jj][p], w[p + jj], acc[i][p]);
+        __builtin_amdgcn_sched_barrier(0);
+        w0 = n0; w1 = n1; w2 = n2;
+    }
+}
+#endif
+
+template <typename K>
+__global__ __launch_bounds__(K::THREADS, 4) void corr_bwd_d4_rows_kernel(
+    const float *__restrict__ x1, const float *__restrict__ x2, const float *__restrict__ gout,
+    float *__restrict__ gin1, float *__restrict__ gin2, int C, int H, int W, int tiles_x,
+    int tiles_y, int nrange) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int kDead = static_cast<int>(0x80000000u);
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int r = lane / K::TSX, sx = lane % K::TSX;
+
+    // (tile, channel range, side) with the side fastest: the two workgroups that read the
+    // same gradOutput tile are neighbours in the XCD-contiguous order
+    int bid = xcd_chunk(blockIdx.x, gridDim.x);
+    const int side = __builtin_amdgcn_readfirstlane(bid & 1); bid >>= 1;
+    const int range = __builtin_amdgcn_readfirstlane(bid % nrange); bid /= nrange;
+    const int tx = __builtin_amdgcn_readfirstlane(bid % tiles_x); bid /= tiles_x;
+    const int ty = __builtin_amdgcn_readfirstlane(bid % tiles_y);
+    const int b = __builtin_amdgcn_readfirstlane(bid / tiles_y);
+    const int x0 = tx * K::TW, y0 = ty * K::TH;
+    const int c_begin = range * K::CR, c_end = min(C, c_begin + K::CR);
+    const int plane = H * W;
+
+    const float *src = (side == 0 ? x2 : x1) + static_cast<int64_t>(b) * C * plane;
+    float *dstb = (side == 0 ? gin1 : gin2) + static_cast<int64_t>(b) * C * plane;
+    const __amdgpu_buffer_rsrc_t rsrc_src = uniform_rsrc(src, C * plane * 4);
+    const __amdgpu_buffer_rsrc_t rsrc_go =
+        uniform_rsrc(gout + static_cast<int64_t>(b) * (kND * kND) * plane, kND * kND * plane * 4);
+
+    float *ring = smem;
+    float *gbufs = smem + K::NRING * K::ROWF;
+
+    // this wave's window-row DMA slots: slot i of [channel][18 slots] -> per-lane byte offset
+    // relative to (first channel of the range, start of the image row)
+    int voff[K::ROW_PW];
+#pragma unroll
+    for (int q = 0; q < K::ROW_PW; ++q) {
+        const int i = (wave + K::NG * q) * 64 + lane;
+        const int ch = i / 18, sl = i % 18;
+        const int gx = x0 - kD + 4 * sl;
+        voff[q] = (i < K::ROW_SLOTS && c_begin + ch < c_end && gx >= 0 && gx < W)
+                      ? (ch * plane + gx) * 4 : kDead;
+    }
+
+    // ---- prologue: the TH+1 rows of steps 0 and 1, gradOutput of step 0 ----
+#pragma unroll
+    for (int k = 0; k <= K::TH; ++k)
+        rows_issue_row<K>(ring + k * K::ROWF, rsrc_src, voff, wave, y0 - kD + k, H, W, c_begin, plane, true);
+    if (side == 0) rows_issue_g<K, 0>(gbufs, rsrc_go, wave, lane, 0, x0, y0, H, W, plane, true);
+    else rows_issue_g<K, 1>(gbufs, rsrc_go, wave, lane, 0, x0, y0, H, W, plane, true);
+
+    float acc[K::CB][kP];
+#pragma unroll
+    for (int i = 0; i < K::CB; ++i)
+#pragma unroll
+        for (int p = 0; p < kP; ++p) acc[i][p] = 0.f;
+
+    const int goff = r * K::RSF + 4 * sx;                       // lane's span inside a gradOutput plane
+    const int choff = wave * K::CB * K::RSF + 4 * sx;           // lane's span inside a ring row
+    wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+
+    for (int s = 0; s < kND; ++s) {
+        // ring slot of the lane's window row (image row y0-4+s+r) and of the row requested now
+        int slot = s + r;
+        if (slot >= K::NRING) slot -= K::NRING;
+        if (slot >= K::NRING) slot -= K::NRING;
+        const int rowoff[1] = {slot * K::ROWF + choff};
+        const int wslot = (s + K::TH + 1) % K::NRING;
+        const float *g_rd = gbufs + (s & 1) * K::GBUF;
+        float *g_wr = gbufs + ((s + 1) & 1) * K::GBUF;
+        if (side == 0)
+            rows_step<K, 0>(ring, g_rd, ring + wslot * K::ROWF, g_wr, rsrc_src, rsrc_go, voff, wave, lane,
+                            s, x0, y0, H, W, c_begin, plane, rowoff, goff, acc);
+        else
+            rows_step<K, 1>(ring, g_rd, ring + wslot * K::ROWF, g_wr, rsrc_src, rsrc_go, voff, wave, lane,
+                            s, x0, y0, H, W, c_begin, plane, rowoff, goff, acc);
+        // the next step's gradOutput has landed once only this step's row request(s), issued
+        // after it, may still be in flight; every LDS read of this step has returned
+        if (wave + K::NG < K::ROW_INSTR) wait_vmcnt<2>(); else wait_vmcnt<1>();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+
+    // ---- epilogue: 1/C, coalesced 16-byte stores ----
+    const float inv_nelems = 1.0f / static_cast<float>(C);
+    const int y = y0 + r, x = x0 + 4 * sx;
+    if (y < H && x < W) {
+#pragma unroll
+        for (int i = 0; i < K::CB; ++i) {
+            const int c = c_begin + wave * K::CB + i;
+            if (c < c_end) {
+                typedef float f4v __attribute__((ext_vector_type(4)));
+                __builtin_nontemporal_store(
+                    f4v{acc[i][0] * inv_nelems, acc[i][1] * inv_nelems, acc[i][2] * inv_nelems,
+                        acc[i][3] * inv_nelems},
+                    reinterpret_cast<f4v *>(dstb + static_cast<int64_t>(c) * plane + y * W + x));
+            }
+        }
+    }
+#endif
+}
+
 // ---- host side -------------------------------------------------------------
 // LDS above 64 KiB needs an explicit opt-in, once per kernel AND device (function attributes
-// are per device): one bit per device ordinal in a mask owned by the call site (a benign
-// race at worst sets the attribute twice)
+// are per device): one bit per device ordinal in an atomic mask owned by the call site.  The
+// bit is set only AFTER hipFuncSetAttribute has succeeded, so a concurrent caller either sees
+// the bit (attribute in place) or sets the attribute again itself (harmless), and a failed
+// call is retried by the next launch.
 template <typename Kern>
-int ensure_lds(Kern kern, size_t bytes, uint64_t *done) {
+int ensure_lds(Kern kern, size_t bytes, std::atomic<uint64_t> *done) {
     if (bytes <= 64 * 1024) return CERB_OK;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) dev = 0;
     const uint64_t bit = 1ull << (dev & 63);
-    if (*done & bit) return CERB_OK;
-    *done |= bit;
+    if (done->load(std::memory_order_acquire) & bit) return CERB_OK;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize,
                                        static_cast<int>(bytes));
-    return e == hipSuccess ? CERB_OK : static_cast<int>(e);
+    if (e != hipSuccess) return static_cast<int>(e);
+    done->fetch_or(bit, std::memory_order_release);
+    return CERB_OK;
 }
 
 // 16-bit storage is only instantiated for the vector (aligned, W % 4 == 0) path; other
@@ -1388,8 +1650,8 @@ int launch_fwd(const char *name, const void *in1, const void *in2, void *outp, c
     const int64_t blocks = static_cast<int64_t>(g.B) * tiles_x * tiles_y;
     if (blocks > 0x7fffffff) return CERB_ETOOLARGE;
     int rc;
-    static uint64_t lds_v = 0, lds_s = 0;
-    const int dbg = option_value("corr_debug_ablate");
+    static std::atomic<uint64_t> lds_v{0}, lds_s{0};
+    const int dbg = debug_mask();
     if (vec) {
         note_kernel(0, name);
         if ((rc = ensure_lds(corr_fwd_d4_kernel<K, T, true>, K::LDS_BYTES, &lds_v))) return rc;
@@ -1430,7 +1692,7 @@ int launch_fwd_dma(const char *name, const void *in1, const void *in2, void *out
     const int tiles_x = (g.W + K::TW - 1) / K::TW, tiles_y = (g.H + K::TH - 1) / K::TH;
     const int64_t blocks = static_cast<int64_t>(g.B) * tiles_x * tiles_y;
     if (blocks > 0x7fffffff) return CERB_ETOOLARGE;
-    static uint64_t lds_done = 0;
+    static std::atomic<uint64_t> lds_done{0};
     int rc;
     if ((rc = ensure_lds(corr_fwd_d4_dma_kernel<K>, K::LDS_BYTES, &lds_done))) return rc;
     note_kernel(0, name);
@@ -1460,14 +1722,14 @@ int launch_bwd(const char *name, const void *in1, const void *in2, const void *g
     // MI355X: 32 / 16 / 8 / 8 channels for the four W32 levels at batch 4)
     int cslice = g.C;
     while (cslice > 8 && tiles * 2 * ((g.C + cslice - 1) / cslice) < 512) cslice /= 2;
-    if (const int forced = option_value("corr_bwd_cslice")) cslice = forced;
+    if (const int forced = option(OPT_CORR_BWD_CSLICE)) cslice = forced;
     cslice = ((cslice + K::CC - 1) / K::CC) * K::CC;
     const int nslice = (g.C + cslice - 1) / cslice;
     if (tiles * nslice * 2 > 0x7fffffff) return CERB_ETOOLARGE;
     const dim3 grid(static_cast<unsigned>(tiles * nslice * 2));
     int rc;
-    static uint64_t lds_v = 0, lds_s = 0;
-    const int dbg = option_value("corr_debug_ablate");
+    static std::atomic<uint64_t> lds_v{0}, lds_s{0};
+    const int dbg = debug_mask();
     if (vec) {
         note_kernel(1, name);
         if ((rc = ensure_lds(corr_bwd_d4_kernel<K, T, true>, K::LDS_BYTES, &lds_v))) return rc;
@@ -1491,7 +1753,7 @@ int launch_bwd_dma(const char *name, const void *in1, const void *in2, const voi
                    void *g2p, const CorrGeom &g, hipStream_t s) {
     const int tiles_x = (g.W + K::TW - 1) / K::TW, tiles_y = (g.H + K::TH - 1) / K::TH;
     const int64_t tiles = static_cast<int64_t>(g.B) * tiles_x * tiles_y;
-    int cslice = option_value("corr_bwd_cslice");
+    int cslice = option(OPT_CORR_BWD_CSLICE);
     if (cslice <= 0) {
         // enough workgroups for every CU: two 4-wave workgroups or one 8-wave workgroup each
         const int64_t want = K::NW == 4 ? 512 : 256;
@@ -1502,7 +1764,7 @@ int launch_bwd_dma(const char *name, const void *in1, const void *in2, const voi
     const int nslice = (g.C + cslice - 1) / cslice;
     const int64_t blocks = tiles * nslice * 2;
     if (blocks > 0x7fffffff) return CERB_ETOOLARGE;
-    static uint64_t lds_done = 0;
+    static std::atomic<uint64_t> lds_done{0};
     int rc;
     if ((rc = ensure_lds(corr_bwd_d4_dma_kernel<K>, K::LDS_BYTES, &lds_done))) return rc;
     note_kernel(1, name);
@@ -1510,7 +1772,7 @@ int launch_bwd_dma(const char *name, const void *in1, const void *in2, const voi
                        dim3(K::THREADS), K::LDS_BYTES, s, static_cast<const float *>(in1),
                        static_cast<const float *>(in2), static_cast<const float *>(goutp),
                        static_cast<float *>(g1p), static_cast<float *>(g2p), g.C, g.H, g.W, tiles_x,
-                       tiles_y, cslice, nslice, option_value("corr_debug_ablate"));
+                       tiles_y, cslice, nslice, debug_mask());
     return launch_status();
 }
 
@@ -1524,13 +1786,13 @@ int launch_bwd_g3(const char *name, const void *in1, const void *in2, const void
     const int64_t tiles = static_cast<int64_t>(g.B) * tiles_x * tiles_y;
     int cslice = g.C;
     while (cslice > 16 && tiles * 2 * ((g.C + cslice - 1) / cslice) < 256) cslice /= 2;
-    if (const int forced = option_value("corr_bwd_cslice")) cslice = forced;
+    if (const int forced = option(OPT_CORR_BWD_CSLICE)) cslice = forced;
     cslice = ((cslice + K::CC - 1) / K::CC) * K::CC;
     const int nslice = (g.C + cslice - 1) / cslice;
     if (tiles * nslice * 2 > 0x7fffffff) return CERB_ETOOLARGE;
     const dim3 grid(static_cast<unsigned>(tiles * nslice * 2));
     int rc;
-    static uint64_t lds_v = 0, lds_s = 0;
+    static std::atomic<uint64_t> lds_v{0}, lds_s{0};
     if (vec) {
         note_kernel(1, name);
         if ((rc = ensure_lds(corr_bwd_d4_g3_kernel<K, T, true>, K::LDS_BYTES, &lds_v))) return rc;
@@ -1559,6 +1821,28 @@ using BwdWide = BwdCfg<32, 2, 72>;    // 8x64 tile
 // 4x64 tiles with 2 wavefronts (spills; 83 / 50 us).
 using BwdNarrow = BwdCfg<16, 2, 96>;  // 16x32 tile
 
+using BwdRows = BwdRowsCfg<4, 8>;   // 4x64 tile, 8 waves x 4 channels
+
+template <typename K>
+int launch_bwd_rows(const char *name, const void *in1, const void *in2, const void *goutp, void *g1p,
+                    void *g2p, const CorrGeom &g, hipStream_t s) {
+    const int tiles_x = (g.W + K::TW - 1) / K::TW, tiles_y = (g.H + K::TH - 1) / K::TH;
+    const int64_t tiles = static_cast<int64_t>(g.B) * tiles_x * tiles_y;
+    const int nrange = (g.C + K::CR - 1) / K::CR;
+    const int64_t blocks = tiles * nrange * 2;
+    if (blocks > 0x7fffffff) return CERB_ETOOLARGE;
+    static std::atomic<uint64_t> lds_done{0};
+    int rc;
+    if ((rc = ensure_lds(corr_bwd_d4_rows_kernel<K>, K::LDS_BYTES, &lds_done))) return rc;
+    note_kernel(1, name);
+    hipLaunchKernelGGL((corr_bwd_d4_rows_kernel<K>), dim3(static_cast<unsigned>(blocks)),
+                       dim3(K::THREADS), K::LDS_BYTES, s, static_cast<const float *>(in1),
+                       static_cast<const float *>(in2), static_cast<const float *>(goutp),
+                       static_cast<float *>(g1p), static_cast<float *>(g2p), g.C, g.H, g.W, tiles_x,
+                       tiles_y, nrange);
+    return launch_status();
+}
+
 bool fast_config(const CorrGeom &g, int dtype) {
     return (dtype == CERB_F32 || dtype == CERB_F16 || dtype == CERB_BF16) && g.pad == kD &&
            g.maxd == kD && g.ksize == 1 && g.s1 == 1 && g.s2 == 1 &&
@@ -1582,7 +1866,7 @@ bool aligned_group(const void *p, int dtype) {
 template <typename T>
 int fwd_dispatch(const void *x1, const void *x2, void *o, const CorrGeom &g, float slope,
                  int64_t obs, bool vec, hipStream_t s) {
-    switch (option_value("corr_fwd_variant")) {  // tuning / test hook
+    switch (option(OPT_CORR_FWD_VARIANT)) {  // tuning / test hook
         case 1: return launch_fwd<FwdA2, T>("corr_fwd_d4_8x64", x1, x2, o, g, slope, obs, vec, s);
         case 2: return launch_fwd<FwdA1, T>("corr_fwd_d4_4x64", x1, x2, o, g, slope, obs, vec, s);
         case 3: if (g.C % 2 == 0) return launch_fwd<FwdB1, T>("corr_fwd_d4_2x64_s2", x1, x2, o, g, slope, obs, vec, s); break;
@@ -1600,7 +1884,7 @@ int fwd_dispatch(const void *x1, const void *x2, void *o, const CorrGeom &g, flo
         case 10: case 11: case 12: case 13:
             if constexpr (sizeof(T) == 4) {
                 if (vec && dma_ok(g)) {
-                    const int v = option_value("corr_fwd_variant");
+                    const int v = option(OPT_CORR_FWD_VARIANT);
                     if (v == 10 && g.C % 2 == 0)
                         return launch_fwd_dma<FwdDmaB>("corr_fwd_d4_dma_2x64_s2", x1, x2, o, g, slope, obs, s);
                     if (v == 11 && g.C % 4 == 0)
@@ -1656,12 +1940,12 @@ int bwd_dispatch(const void *x1, const void *x2, const void *go, void *g1, void 
                  const CorrGeom &g, bool vec, hipStream_t s) {
     if (g.W <= 32) {
         if constexpr (sizeof(T) == 4) {
-            if (vec && dma_ok(g) && option_value("corr_bwd_variant") != 1)
+            if (vec && dma_ok(g) && option(OPT_CORR_BWD_VARIANT) != 1)
                 return launch_bwd_dma<BwdDmaNarrow>("corr_bwd_d4_dma_16x32", x1, x2, go, g1, g2, g, s);
         }
         return launch_bwd<BwdNarrow, T>("corr_bwd_d4_16x32", x1, x2, go, g1, g2, g, vec, s);
     }
-    switch (option_value("corr_bwd_variant")) {
+    switch (option(OPT_CORR_BWD_VARIANT)) {
         case 1: return launch_bwd<BwdWide, T>("corr_bwd_d4_8x64", x1, x2, go, g1, g2, g, vec, s);
         case 2: return launch_bwd_g3<BwdG3Wide, T>("corr_bwd_d4_g3_4x64", x1, x2, go, g1, g2, g, vec, s);
         case 3: return launch_bwd_g3<BwdG3Wide4, T>("corr_bwd_d4_g3_8x64", x1, x2, go, g1, g2, g, vec, s);
@@ -1675,6 +1959,12 @@ int bwd_dispatch(const void *x1, const void *x2, const void *go, void *g1, void 
             if constexpr (sizeof(T) == 4) {
                 if (vec && dma_ok(g))
                     return launch_bwd_dma<BwdDmaNarrow>("corr_bwd_d4_dma_16x32", x1, x2, go, g1, g2, g, s);
+            }
+            break;
+        case 6:
+            if constexpr (sizeof(T) == 4) {
+                if (vec && dma_ok(g))
+                    return launch_bwd_rows<BwdRows>("corr_bwd_d4_rows_4x64", x1, x2, go, g1, g2, g, s);
             }
             break;
         default: break;

@@ -21,6 +21,7 @@
 // meet in LDS, wave 0 stores -- deterministic, no atomics.  The image gradient
 // is a data-dependent scatter: fp32/fp64 hardware atomics, as ATen does.
 #include <algorithm>
+#include <type_traits>
 
 #include "common.h"
 
@@ -28,6 +29,25 @@ namespace cerb {
 namespace {
 
 constexpr int kPix = 64;         // pixels per workgroup = one wavefront
+
+// A "strip" is the 64 pixels one wavefront owns: kStripH rows x kStripW columns.  Two rows
+// instead of one: the lower tap row of the strip's first pixel row is the upper tap row of
+// its second, so a wave touches 3 source rows for 2 rows of pixels instead of 2 for 1
+// (round 1: 1 x 64 strips, fabric reads 1.9x the algorithmic bytes), and strips are walked
+// in an XCD-aware order so that vertical neighbours meet in one L2.
+constexpr int kStripH = 2, kStripW = kPix / kStripH;
+struct Strips {
+    int nx, ny;                                    // strips per row / per column of one image
+    __host__ __device__ Strips(int H, int W)
+        : nx((W + kStripW - 1) / kStripW), ny((H + kStripH - 1) / kStripH) {}
+    __host__ __device__ int per_image() const { return nx * ny; }
+    // pixel of (strip j of an image, lane); false when the lane is outside the image
+    __device__ __forceinline__ bool pixel(int j, int lane, int H, int W, int &x, int &y) const {
+        y = (j / nx) * kStripH + lane / kStripW;
+        x = (j % nx) * kStripW + lane % kStripW;
+        return x < W && y < H;
+    }
+};
 
 template <typename A> struct Coord {
     A pos;   // source index after unnormalise + padding
@@ -98,59 +118,82 @@ __device__ __forceinline__ void load_taps(const T *q, bool ok0, bool ok1, A &v0,
 
 // ---- backward context ----------------------------------------------------------
 // What the forward already knows and the backward needs again: every pixel's sample
-// position (after unnormalise + padding) and how far a tap can land from its own pixel.
-// Saved by the forward (cerberus_flow_warp_forward_ctx) the backward is two launches with no
+// position (after unnormalise + padding) and, per 64-pixel strip, the SIGNED range of tap
+// displacements (tap - own pixel) of the strip's in-image taps.  Signed ranges instead of a
+// magnitude: under a smooth flow a grad_image tile is fed by (the tile shifted by -flow), not
+// by (the tile grown by |flow|) -- 1.1x instead of 2.3x the tile at +-6 px.
+// Saved by the forward (cerberus_flow_warp_forward_ctx) the backward is one launch with no
 // pre-pass; without it the backward first runs warp_context_kernel over the flow.
-//   int   ext[kCtxPartials][2]   per-workgroup max tap extent (x, y); the first
-//                                min(B*ceil(HW/64), kCtxPartials) slots are written and read
-//   float pos[B][2][H][W]        sample positions (x plane, y plane)
+//   int4  ext[kCtxPartials]     {dx_lo, dx_hi, dy_lo, dy_hi} per producer workgroup (strips
+//                               j, j+npart, ... fold into partial j); empty: lo > hi.  The first
+//                               min(B*ceil(HW/64), kCtxPartials) slots are written and read
+//   float pos[B][2][H][W]       sample positions (x plane, y plane)
 constexpr int kCtxPartials = 2048;
+constexpr int kExtEmptyLo = 0x3fffffff, kExtEmptyHi = -0x3fffffff;
 __host__ __device__ inline int64_t ctx_bytes(int B, int H, int W) {
-    return static_cast<int64_t>(kCtxPartials) * 2 * sizeof(int) +
+    return static_cast<int64_t>(kCtxPartials) * 4 * sizeof(int) +
            static_cast<int64_t>(B) * 2 * H * W * sizeof(float);
 }
 __host__ __device__ __forceinline__ float *ctx_pos(void *ctx) {
-    return reinterpret_cast<float *>(static_cast<int *>(ctx) + 2 * kCtxPartials);
+    return reinterpret_cast<float *>(static_cast<int *>(ctx) + 4 * kCtxPartials);
 }
 __host__ __device__ __forceinline__ const float *ctx_pos(const void *ctx) {
-    return reinterpret_cast<const float *>(static_cast<const int *>(ctx) + 2 * kCtxPartials);
+    return reinterpret_cast<const float *>(static_cast<const int *>(ctx) + 4 * kCtxPartials);
 }
 
-// Wave-level max of two non-negative ints.
-__device__ __forceinline__ void wave_max2(int &a, int &b) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
-        a = max(a, __shfl_xor(a, m, 64));
-        b = max(b, __shfl_xor(b, m, 64));
+struct TapRange {
+    int xlo = kExtEmptyLo, xhi = kExtEmptyHi, ylo = kExtEmptyLo, yhi = kExtEmptyHi;
+    // taps x0, x0+1 / y0, y0+1 of the pixel (x, y); only taps inside the image count
+    __device__ __forceinline__ void add(int x, int y, int x0, int y0, int W, int H) {
+        const bool okx0 = x0 >= 0 && x0 < W, okx1 = x0 + 1 >= 0 && x0 + 1 < W;
+        const bool oky0 = y0 >= 0 && y0 < H, oky1 = y0 + 1 >= 0 && y0 + 1 < H;
+        if ((okx0 || okx1) && (oky0 || oky1)) {
+            xlo = min(xlo, (okx0 ? x0 : x0 + 1) - x); xhi = max(xhi, (okx1 ? x0 + 1 : x0) - x);
+            ylo = min(ylo, (oky0 ? y0 : y0 + 1) - y); yhi = max(yhi, (oky1 ? y0 + 1 : y0) - y);
+        }
     }
+    // wave-wide union, lane 0 publishes
+    __device__ __forceinline__ void publish(void *ctx, int slot, int lane) {
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            xlo = min(xlo, __shfl_xor(xlo, m, 64)); xhi = max(xhi, __shfl_xor(xhi, m, 64));
+            ylo = min(ylo, __shfl_xor(ylo, m, 64)); yhi = max(yhi, __shfl_xor(yhi, m, 64));
+        }
+        if (lane == 0) static_cast<int4 *>(ctx)[slot] = make_int4(xlo, xhi, ylo, yhi);
+    }
+};
+
+// float -> int that cannot overflow later index arithmetic (positions can be anything,
+// including NaN / Inf from a diverged flow: v_cvt_i32_f32 saturates, NaN -> 0)
+__device__ __forceinline__ int tap_index(float f) {
+    return min(max(static_cast<int>(f), -(1 << 24)), 1 << 24);
 }
 
 // Grid: 1-D over the B * ceil(HW/64) pixel strips (grid-stride when a context caps the
-// number of workgroups at kCtxPartials).
-template <typename T, bool PAIR, int kCg>
+// number of workgroups at kCtxPartials).  T: image / output storage type, F: flow type
+// (F = float with a 16-bit image keeps full flow precision: the reference's grid_sample runs
+// in fp32 under autocast with whatever precision the flow arrives in).
+template <typename T, typename F, bool PAIR, int kCg>
 __global__ __launch_bounds__(kPix * kCg) void warp_fwd_kernel(
-    const T *__restrict__ image, const T *__restrict__ flow, T *__restrict__ out,
-    void *__restrict__ ctx, int B, int C, int H, int W, int pad_mode, int interp, int dbg) {
-#ifndef CERB_ABLATE
-    dbg = 0;
-#endif
+    const T *__restrict__ image, const F *__restrict__ flow, T *__restrict__ out,
+    void *__restrict__ ctx, int B, int C, int H, int W, int pad_mode, int interp) {
     using A = typename Acc<T>::type;
     const int64_t plane = static_cast<int64_t>(H) * W;
     const int lane = threadIdx.x & (kPix - 1);
     const int cg = threadIdx.x / kPix;
-    const int spp = static_cast<int>((plane + kPix - 1) / kPix);   // strips per plane
+    const Strips strips(H, W);
+    const int spp = strips.per_image();
     const int64_t nstrips = static_cast<int64_t>(B) * spp;
-    int ext_x = 0, ext_y = 0;
-    for (int64_t strip = blockIdx.x; strip < nstrips; strip += gridDim.x) {
+    TapRange range;
+    const int first = xcd_chunk(blockIdx.x, gridDim.x);
+    for (int64_t strip = first; strip < nstrips; strip += gridDim.x) {
         const int b = static_cast<int>(strip / spp);
-        const int64_t p = (strip % spp) * kPix + lane;
-        if (p >= plane) continue;
-        const int y = static_cast<int>(p / W), x = static_cast<int>(p % W);
-        const T *fl = flow + static_cast<int64_t>(b) * 2 * plane + p;
-        Coord<A> cx = source_coord<A>(x, ld(fl), W, pad_mode);
-        Coord<A> cy = source_coord<A>(y, ld(fl + plane), H, pad_mode);
-        if (dbg & 2) { cx.pos = A(x) + A(0.25); cy.pos = A(y) + A(0.25); }   // ablation: identity-like taps
-        if (dbg & 8) { cx.pos = A(x) + A(0.25) + ld(fl) * A(1e-30); cy.pos = A(y) + A(0.25) + ld(fl + plane) * A(1e-30); }
+        int x, y;
+        if (!strips.pixel(static_cast<int>(strip % spp), lane, H, W, x, y)) continue;
+        const int64_t p = static_cast<int64_t>(y) * W + x;
+        const F *fl = flow + static_cast<int64_t>(b) * 2 * plane + p;
+        const Coord<A> cx = source_coord<A>(x, static_cast<A>(ld(fl)), W, pad_mode);
+        const Coord<A> cy = source_coord<A>(y, static_cast<A>(ld(fl + plane)), H, pad_mode);
         const T *img = image + static_cast<int64_t>(b) * C * plane;
         T *dst = out + static_cast<int64_t>(b) * C * plane + p;
         if (interp == CERB_INTERP_NEAREST) {
@@ -167,7 +210,7 @@ __global__ __launch_bounds__(kPix * kCg) void warp_fwd_kernel(
         const A wne = (cx.pos - x0f) * (y1f - cy.pos);
         const A wsw = (x1f - cx.pos) * (cy.pos - y0f);
         const A wse = (cx.pos - x0f) * (cy.pos - y0f);
-        const int x0 = static_cast<int>(x0f), y0 = static_cast<int>(y0f);
+        const int x0 = tap_index(static_cast<float>(x0f)), y0 = tap_index(static_cast<float>(y0f));
         const bool okx0 = x0 >= 0 && x0 < W, okx1 = x0 + 1 >= 0 && x0 + 1 < W;
         const bool oky0 = y0 >= 0 && y0 < H, oky1 = y0 + 1 >= 0 && y0 + 1 < H;
         const int64_t o00 = static_cast<int64_t>(y0) * W + x0;
@@ -175,10 +218,7 @@ __global__ __launch_bounds__(kPix * kCg) void warp_fwd_kernel(
             float *pos = ctx_pos(ctx) + static_cast<int64_t>(b) * 2 * plane + p;
             pos[0] = static_cast<float>(cx.pos);
             pos[plane] = static_cast<float>(cy.pos);
-            if ((okx0 || okx1) && (oky0 || oky1)) {
-                ext_x = max(ext_x, max(abs(x0 - x), abs(x0 + 1 - x)));
-                ext_y = max(ext_y, max(abs(y0 - y), abs(y0 + 1 - y)));
-            }
+            range.add(x, y, x0, y0, W, H);
         }
         constexpr int kU = 4;  // channels per trip: 16 independent taps in flight per lane (8: no faster)
         for (int c = cg; c < C; c += kU * kCg) {
@@ -194,58 +234,46 @@ __global__ __launch_bounds__(kPix * kCg) void warp_fwd_kernel(
             for (int u = 0; u < kU; ++u) {
                 const int cc = c + u * kCg;
                 if (cc >= C) break;
-                // same summation order as before; absent taps contribute exact zeros
+                // absent taps contribute exact zeros
                 A acc = v[u][0] * wnw;
                 acc += v[u][1] * wne;
                 acc += v[u][2] * wsw;
                 acc += v[u][3] * wse;
-                if (!(dbg & 1) || acc == A(12345)) st(dst + cc * plane, acc);
+                st(dst + cc * plane, acc);
             }
         }
     }
-    if (ctx && cg == 0) {   // one wave per workgroup publishes; every slot < gridDim.x is written
-        wave_max2(ext_x, ext_y);
-        if (lane == 0) {
-            int *e = static_cast<int *>(ctx) + 2 * blockIdx.x;
-            e[0] = ext_x; e[1] = ext_y;
-        }
-    }
+    // one wave per workgroup publishes; every slot < gridDim.x is written
+    if (ctx && cg == 0) range.publish(ctx, first, lane);
 }
 
 // Context from the flow alone (backward called without a forward context): same strip ->
 // workgroup mapping as the forward, one wavefront per workgroup.
-__global__ __launch_bounds__(kPix) void warp_context_kernel(const float *__restrict__ flow,
+template <typename F>
+__global__ __launch_bounds__(kPix) void warp_context_kernel(const F *__restrict__ flow,
                                                              void *__restrict__ ctx, int B, int H,
                                                              int W, int pad_mode) {
     const int64_t plane = static_cast<int64_t>(H) * W;
     const int lane = threadIdx.x;
-    const int spp = static_cast<int>((plane + kPix - 1) / kPix);
+    const Strips strips(H, W);
+    const int spp = strips.per_image();
     const int64_t nstrips = static_cast<int64_t>(B) * spp;
-    int ext_x = 0, ext_y = 0;
-    for (int64_t strip = blockIdx.x; strip < nstrips; strip += gridDim.x) {
+    TapRange range;
+    const int first = xcd_chunk(blockIdx.x, gridDim.x);
+    for (int64_t strip = first; strip < nstrips; strip += gridDim.x) {
         const int b = static_cast<int>(strip / spp);
-        const int64_t p = (strip % spp) * kPix + lane;
-        if (p >= plane) continue;
-        const int y = static_cast<int>(p / W), x = static_cast<int>(p % W);
-        const float *fl = flow + static_cast<int64_t>(b) * 2 * plane + p;
-        const Coord<float> cx = source_coord<float>(x, fl[0], W, pad_mode);
-        const Coord<float> cy = source_coord<float>(y, fl[plane], H, pad_mode);
+        int x, y;
+        if (!strips.pixel(static_cast<int>(strip % spp), lane, H, W, x, y)) continue;
+        const int64_t p = static_cast<int64_t>(y) * W + x;
+        const F *fl = flow + static_cast<int64_t>(b) * 2 * plane + p;
+        const Coord<float> cx = source_coord<float>(x, static_cast<float>(ld(fl)), W, pad_mode);
+        const Coord<float> cy = source_coord<float>(y, static_cast<float>(ld(fl + plane)), H, pad_mode);
         float *pos = ctx_pos(ctx) + static_cast<int64_t>(b) * 2 * plane + p;
         pos[0] = cx.pos;
         pos[plane] = cy.pos;
-        const int x0 = static_cast<int>(floorf(cx.pos)), y0 = static_cast<int>(floorf(cy.pos));
-        const bool okx = (x0 >= 0 && x0 < W) || (x0 + 1 >= 0 && x0 + 1 < W);
-        const bool oky = (y0 >= 0 && y0 < H) || (y0 + 1 >= 0 && y0 + 1 < H);
-        if (okx && oky) {
-            ext_x = max(ext_x, max(abs(x0 - x), abs(x0 + 1 - x)));
-            ext_y = max(ext_y, max(abs(y0 - y), abs(y0 + 1 - y)));
-        }
+        range.add(x, y, tap_index(floorf(cx.pos)), tap_index(floorf(cy.pos)), W, H);
     }
-    wave_max2(ext_x, ext_y);
-    if (lane == 0) {
-        int *e = static_cast<int *>(ctx) + 2 * blockIdx.x;
-        e[0] = ext_x; e[1] = ext_y;
-    }
+    range.publish(ctx, first, lane);
 }
 
 // ---- atomics ----------------------------------------------------------------
@@ -276,13 +304,13 @@ __device__ __forceinline__ void atomic_accumulate(__half *p, float v) { atomic_a
 __device__ __forceinline__ void atomic_accumulate(hip_bfloat16 *p, float v) { atomic_accumulate_16(p, v); }
 
 // ---- backward, per-pixel kernel ---------------------------------------------------
-// grad_flow by a deterministic gather (+ optionally grad_image by global float atomics, as
-// ATen does).  Used when the tiled path does not apply (no workspace, not fp32) and for
+// grad_flow by a deterministic gather + grad_image by global float atomics, as ATen does.
+// Used when the tiled path does not apply (fp64, or neither context nor workspace) and for
 // grad_flow alone when grad_image is not wanted.
-template <typename T, bool PAIR, int kCg>
+template <typename T, typename F, bool PAIR, int kCg>
 __global__ __launch_bounds__(kPix * kCg) void warp_bwd_kernel(
-    const T *__restrict__ image, const T *__restrict__ flow, const T *__restrict__ gout,
-    T *__restrict__ gimage, T *__restrict__ gflow, int B, int C, int H, int W, int pad_mode) {
+    const T *__restrict__ image, const F *__restrict__ flow, const T *__restrict__ gout,
+    T *__restrict__ gimage, F *__restrict__ gflow, int B, int C, int H, int W, int pad_mode) {
     using A = typename Acc<T>::type;
     __shared__ A part[kCg][2][kPix];
     const int64_t plane = static_cast<int64_t>(H) * W;
@@ -295,16 +323,16 @@ __global__ __launch_bounds__(kPix * kCg) void warp_bwd_kernel(
     Coord<A> cx{0, 0}, cy{0, 0};
     if (live) {
         const int y = static_cast<int>(p / W), x = static_cast<int>(p % W);
-        const T *fl = flow + static_cast<int64_t>(b) * 2 * plane + p;
-        cx = source_coord<A>(x, ld(fl), W, pad_mode);
-        cy = source_coord<A>(y, ld(fl + plane), H, pad_mode);
+        const F *fl = flow + static_cast<int64_t>(b) * 2 * plane + p;
+        cx = source_coord<A>(x, static_cast<A>(ld(fl)), W, pad_mode);
+        cy = source_coord<A>(y, static_cast<A>(ld(fl + plane)), H, pad_mode);
         const A x0f = floor(cx.pos), y0f = floor(cy.pos);
         const A x1f = x0f + A(1), y1f = y0f + A(1);
         const A wnw = (x1f - cx.pos) * (y1f - cy.pos);
         const A wne = (cx.pos - x0f) * (y1f - cy.pos);
         const A wsw = (x1f - cx.pos) * (cy.pos - y0f);
         const A wse = (cx.pos - x0f) * (cy.pos - y0f);
-        const int x0 = static_cast<int>(x0f), y0 = static_cast<int>(y0f);
+        const int x0 = tap_index(static_cast<float>(x0f)), y0 = tap_index(static_cast<float>(y0f));
         const bool okx0 = x0 >= 0 && x0 < W, okx1 = x0 + 1 >= 0 && x0 + 1 < W;
         const bool oky0 = y0 >= 0 && y0 < H, oky1 = y0 + 1 >= 0 && y0 + 1 < H;
         const int64_t o00 = static_cast<int64_t>(y0) * W + x0;
@@ -354,7 +382,7 @@ __global__ __launch_bounds__(kPix * kCg) void warp_bwd_kernel(
 #pragma unroll
         for (int k = 0; k < kCg; ++k) { sx += part[k][0][lane]; sy += part[k][1][lane]; }
         // autograd order: grad_grid = mult * sum ; through norm_grid: / (size-1) then * 2.0
-        T *gf = gflow + static_cast<int64_t>(b) * 2 * plane + p;
+        F *gf = gflow + static_cast<int64_t>(b) * 2 * plane + p;
         st(gf, cx.mult * sx / static_cast<A>(W - 1) * A(2.0));
         st(gf + plane, cy.mult * sy / static_cast<A>(H - 1) * A(2.0));
     }
@@ -363,310 +391,525 @@ __global__ __launch_bounds__(kPix * kCg) void warp_bwd_kernel(
 // ---- backward, owner-computes tiles ------------------------------------------------
 // ATen's image gradient is a global float-atomic scatter: 4 atomics per (pixel, channel),
 // ~0.1 TB/s when neighbouring lanes hit different rows (measured: 555 us at the 32x128x256
-// level).  Here a workgroup OWNS a TH x TW tile of grad_image for CW channels: it scans every
-// source pixel whose taps can reach the tile (the strips of the context whose own tap extent
-// reaches it), accumulates the taps that fall inside in LDS and writes the tile once with
-// plain coalesced stores: no global atomics, no memset, every output element written exactly
-// once, ONE launch for grad_image and grad_flow.
-// The LDS accumulators are 64-bit FIXED POINT: ds_add_f32 runs at 0.3 lanes/clk/CU on
-// gfx950 (tools/ubench/lds_atomic.hip) against 6.7 for ds_add_u64.  The scale is
-// 2^(30 - exponent(m)), m = max|gradOutput| over the sources this workgroup adds (a block
-// reduction): every product w*g <= m is an int32 with a resolution of 2^-30 of the largest
-// gradient in the tile (fp32 itself resolves 2^-24), and 2^33 of them can meet in one pixel.
-// Integer addition commutes, so the result is bit-reproducible (ATen's is not).
-// 64-bit fixed point -> float.  |acc| stays far below 2^53 (int32 contributions, at most a
-// few thousand per pixel), so hi * 2^32 + lo is EXACT in double and the final rounding is the
-// correctly rounded int64 -> float conversion -- in 4 instructions instead of the ~20 of the
-// generic sequence (16 conversions per thread in the write-back).
-__device__ __forceinline__ float fixed64_to_float(long long acc) {
-    const int hi = static_cast<int>(acc >> 32);
-    const unsigned lo = static_cast<unsigned>(acc);
-    return static_cast<float>(fma(static_cast<double>(hi), 4294967296.0, static_cast<double>(lo)));
-}
+// level).  Here ONE launch holds two kinds of workgroup:
+//
+//  * TILE workgroups own a TH x 64 tile of grad_image for a range of channels.  They find the
+//    source pixels whose taps can reach the tile from the context -- the strips whose signed
+//    tap-displacement range reaches it, clipped to (tile shifted by those ranges) --, keep
+//    each source's tile offset and four bilinear weights in REGISTERS, and then walk their
+//    channels in groups of CW: load gradOutput at the sources (the next group's loads are in
+//    flight while this group accumulates), add the taps into LDS, write the group's tile with
+//    plain coalesced stores.  No global atomics, no memset, every output element written
+//    exactly once.  (Round 1 gave every 4-channel group its own workgroup: 8 workgroups per
+//    tile at 32 channels, each re-reading the positions, re-classifying the region and
+//    walking load -> reduce -> add -> store in lock-step with everyone else.)
+//  * FLOW workgroups (64 pixels x 4 channel groups, like the forward) finish grad_flow: a
+//    gather over the pixel's own taps, independent of the tiles, so the two kinds overlap.
+//
+// The LDS accumulators are FIXED POINT: ds_add_f32 runs at 0.3 lanes/clk/CU on gfx950
+// (tools/ubench/lds_atomic.hip) against 6.7 for the integer adds.  Two channels share one
+// 64-bit slot as two int32 sums: one ds_add_u64 adds (a + (b << 32)) -- half the LDS atomics
+// of one-slot-per-channel, and the LDS-atomic pipe is what bounds this kernel (round 2 PMC:
+// 8.8 us of LDS-busy time per CU at the 32x128x256 level with one channel per slot).  A
+// negative a borrows from the upper half; the borrows add up consistently, so the sums come
+// back exactly: A = int32(low word), B = (V - A) >> 32.
+// Scale: 2^(30 - e - S) with max|gradOutput| < 2^e over the sources of this (tile, channel
+// group) (a block reduction) and 2^S >= the tile's largest tap DENSITY (the sum of bilinear
+// weights landing on one element, measured once per tile with the same adds on a weight
+// plane; ~1 under smooth flows, so S = 1): every |sum| < 2^31, with a resolution of 2^-29 of
+// the tile's largest gradient (fp32 itself resolves 2^-24).  Integer addition commutes, so
+// the result is bit-reproducible (ATen's is not).
+// A plane of accumulators is the tile plus a one-pixel ring: a source is taken iff its
+// north-west tap lies in [-1, TW-1] x [-1, TH-1] of the tile, all four taps then address the
+// padded plane without any per-tap test, and what lands in the ring (taps that belong to a
+// neighbouring tile or fall outside the image) is simply never written out.
+// Non-finite gradients: the block maximum is taken on the bit patterns (NaN > Inf > finite),
+// so one NaN / Inf among the sources is seen; that (tile, group) then accumulates in float
+// (ds_add_f32 on the two halves of the slot: slow, but only diverged steps get here) and
+// NaN / Inf reach exactly the elements they reach in ATen's scatter.
 
-__device__ __forceinline__ unsigned long long fixed64(float scaled) {
-    return static_cast<unsigned long long>(static_cast<long long>(__float2int_rn(scaled)));
-}
-
-template <int TH, int TW, int CW, int NS>
-__global__ __launch_bounds__(256, CW <= 4 ? 4 : 2) void warp_bwd_tile_kernel(
-    const float *__restrict__ image, const float *__restrict__ gout, const void *__restrict__ ctx,
-    int npart, float *__restrict__ gimage, float *__restrict__ gflow, int B, int C, int H, int W,
-    int tiles_x, int tiles_y, int nsplit, int pad_mode, int dbg) {
-#ifndef CERB_ABLATE
-    dbg = 0;
+#ifdef CERB_STAMP
+// diagnostic build only (-DCERB_STAMP): s_memtime at the phase boundaries of the first 64 tile
+// workgroups, fetched with cerberus_debug_stamps(); never compiled into the product
+__device__ unsigned long long g_stamps[64][16];
+#define CERB_STAMP_AT(k)                                                         \
+    do {                                                                         \
+        if (threadIdx.x == 0 && blockIdx.x < 64) g_stamps[blockIdx.x][k] = __builtin_readcyclecounter(); \
+    } while (0)
+#else
+#define CERB_STAMP_AT(k) do {} while (0)
 #endif
-    // per channel: the tile + one dummy word per lane (taps that miss the tile add 0 there)
-    constexpr int PS = TH * TW + 64;
-    __shared__ long long acc[CW * PS];
-    __shared__ int red[4][6];
-    __shared__ float gfl[256][2];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    int bid = blockIdx.x;
-    const int split = bid % nsplit; bid /= nsplit;
-    const int tx = bid % tiles_x; bid /= tiles_x;
-    const int ty = bid % tiles_y;
-    const int b = bid / tiles_y;
-    const int tx0 = tx * TW, ty0 = ty * TH, c0 = split * CW;
-    const int cw = min(CW, C - c0);
-    const int plane = H * W;
-    const float *pos = ctx_pos(ctx) + static_cast<int64_t>(b) * 2 * plane;
-    const float *go = gout + (static_cast<int64_t>(b) * C + c0) * plane;
 
-    // ---- scan region of THIS tile (first loads in flight) ----
-    // The context holds one tap extent per 64-pixel strip (per forward workgroup).  A strip
-    // matters to this tile only if its own extent reaches it, so a fast object widens the
-    // scan of the tiles around it and nobody else's -- there is no global limit and no
-    // fallback.  (Contexts of more than kCtxPartials strips fold strips j, j+npart, ... into
-    // one partial: the test stays conservative.)
-    int rx0 = W, rx1 = -1, ry0 = H, ry1 = -1;   // bounding box of the contributing strips
-    int emx = 0, emy = 0;                        // largest extent among them
+constexpr int kTileW = 64;
+template <int TH> struct TileGeom {
+    static constexpr int PW = kTileW + 2;          // padded row, in accumulators
+    static constexpr int PS = (TH + 2) * PW;       // accumulators per channel plane
+};
+
+template <typename T, typename F, int TH, int CW, int NS>
+__global__ __launch_bounds__(256, 4) void warp_bwd_tile_kernel(
+    const T *__restrict__ image, const T *__restrict__ gout, const void *__restrict__ ctx,
+    int npart, T *__restrict__ gimage, F *__restrict__ gflow, int B, int C, int H, int W,
+    int tiles_x, int tiles_y, int nrange, int crange, int ntile_blocks, int pad_mode) {
+    constexpr int TW = kTileW, PW = TileGeom<TH>::PW, PS = TileGeom<TH>::PS;
+    constexpr int NP = CW / 2;                       // channel pairs = planes of 64-bit slots
+    static_assert(CW % 2 == 0, "channels are accumulated in pairs");
+    __shared__ long long acc[NP * PS];
+    __shared__ int red[4][8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int plane = H * W;
+
+    if (static_cast<int>(blockIdx.x) >= ntile_blocks) {
+        // ------------------------------ FLOW workgroup ------------------------------
+        // one strip of 64 pixels x 4 channel groups (one wave each); positions from the context
+        float(*part)[2][kPix] = reinterpret_cast<float(*)[2][kPix]>(acc);
+        const Strips strips(H, W);
+        const int spp = strips.per_image();
+        const int strip = xcd_chunk(blockIdx.x - ntile_blocks, gridDim.x - ntile_blocks);
+        const int b = strip / spp;
+        int x, y;
+        const bool live = strips.pixel(strip % spp, lane, H, W, x, y);
+        const int p = y * W + x;
+        const int pc = live ? p : 0;
+        const float *pos = ctx_pos(ctx) + static_cast<int64_t>(b) * 2 * plane;
+        const float ixp = pos[pc], iyp = pos[plane + pc];
+        const float x0f = floorf(ixp), y0f = floorf(iyp);
+        const float x1f = x0f + 1.f, y1f = y0f + 1.f;
+        const int x0 = tap_index(x0f), y0 = tap_index(y0f);
+        const bool okx0 = x0 >= 0 && x0 < W, okx1 = x0 + 1 >= 0 && x0 + 1 < W;
+        const bool oky0 = y0 >= 0 && y0 < H, oky1 = y0 + 1 >= 0 && y0 + 1 < H;
+        const int o00 = y0 * W + x0;
+        const T *im = image + static_cast<int64_t>(b) * C * plane;
+        const T *gob = gout + static_cast<int64_t>(b) * C * plane;
+        float gix = 0.f, giy = 0.f;
+        constexpr int kU = 8;  // channels per trip: 40 independent loads in flight per lane
+        for (int c = wave; c < C; c += kU * 4) {
+            float g[kU], vnw[kU], vne[kU], vsw[kU], vse[kU];
+#pragma unroll
+            for (int u = 0; u < kU; ++u) {
+                const int cc = c + u * 4;
+                const bool on = cc < C;
+                const int64_t cp = static_cast<int64_t>(on ? cc : c) * plane;
+                g[u] = ld(tap_ptr(gob + cp + pc, on));
+                const T *qd = im + cp + o00;
+                load_taps<false, T, float>(qd, oky0 && okx0, oky0 && okx1, vnw[u], vne[u]);
+                load_taps<false, T, float>(qd + W, oky1 && okx0, oky1 && okx1, vsw[u], vse[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < kU; ++u) {
+                gix += (-vnw[u] * (y1f - iyp) + vne[u] * (y1f - iyp) - vsw[u] * (iyp - y0f) +
+                        vse[u] * (iyp - y0f)) * g[u];
+                giy += (-vnw[u] * (x1f - ixp) - vne[u] * (ixp - x0f) + vsw[u] * (x1f - ixp) +
+                        vse[u] * (ixp - x0f)) * g[u];
+            }
+        }
+        part[wave][0][lane] = gix;
+        part[wave][1][lane] = giy;
+        __syncthreads();
+        if (wave == 0 && live) {
+            float sx = 0.f, sy = 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { sx += part[k][0][lane]; sy += part[k][1][lane]; }
+            // clip_coordinates_set_grad from the clamped position, then autograd's order:
+            // grad_grid = mult * sum ; through norm_grid: / (size-1) then * 2.0
+            float mx = static_cast<float>(W) / 2.0f, my = static_cast<float>(H) / 2.0f;
+            if (pad_mode == CERB_PAD_BORDER) {
+                if (ixp <= 0.f || ixp >= static_cast<float>(W - 1)) mx = 0.f;
+                if (iyp <= 0.f || iyp >= static_cast<float>(H - 1)) my = 0.f;
+            }
+            F *gf = gflow + static_cast<int64_t>(b) * 2 * plane + p;
+            st(gf, mx * sx / static_cast<float>(W - 1) * 2.0f);
+            st(gf + plane, my * sy / static_cast<float>(H - 1) * 2.0f);
+        }
+        return;
+    }
+
+    // -------------------------------- TILE workgroup --------------------------------
+    // (channel range, tile) with the tile fastest inside one XCD's contiguous share: spatial
+    // neighbours of one channel range (shared gradOutput halo lines) meet in one L2
+    int bid = xcd_chunk(blockIdx.x, ntile_blocks);
+    const int tx = bid % tiles_x; bid /= tiles_x;
+    const int ty = bid % tiles_y; bid /= tiles_y;
+    const int b = bid % B;
+    const int range = bid / B;
+    const int tx0 = tx * TW, ty0 = ty * TH;
+    const int tx1 = min(tx0 + TW, W) - 1, ty1 = min(ty0 + TH, H) - 1;   // last pixel of the tile
+    const int c_begin = range * crange, c_end = min(C, c_begin + crange);
+    const float *pos = ctx_pos(ctx) + static_cast<int64_t>(b) * 2 * plane;
+    (void)nrange;
+
+    CERB_STAMP_AT(0);
+    // ---- scan region ----
+    // The context holds one signed tap-displacement range per 64-pixel strip.  A strip
+    // matters to this tile only if its pixels displaced by its OWN range can reach the tile;
+    // the region is the bounding box of those strips clipped to the tile displaced by the
+    // union of their ranges.  A fast object therefore widens only the tiles it feeds: there
+    // is no global limit and no fallback.
+    int rx0 = kExtEmptyLo, rx1 = kExtEmptyHi, ry0 = kExtEmptyLo, ry1 = kExtEmptyHi;
+    int dxl = kExtEmptyLo, dxh = kExtEmptyHi, dyl = kExtEmptyLo, dyh = kExtEmptyHi;
     {
-        const int2 *ext = static_cast<const int2 *>(ctx);
-        const int spp = (plane + kPix - 1) / kPix;   // strips per image
+        const int4 *ext = static_cast<const int4 *>(ctx);
+        const Strips strips(H, W);
+        const int spp = strips.per_image();
+        // strip j = tid + 256 k as (jy, jx), advanced without divisions in the loop
+        int jy = tid / strips.nx, jx = tid % strips.nx;
+        const int qy = 256 / strips.nx, qx = 256 % strips.nx;
+        const bool folded = static_cast<int64_t>(B) * spp > npart;   // strips share partials
         for (int j = tid; j < spp; j += 256) {
-            const int2 e = ext[(b * spp + j) % npart];
-            const int p0 = j * kPix, p1 = min(p0 + kPix, plane) - 1;
-            const int sy0 = p0 / W, sy1 = p1 / W;
-            const int sx0 = sy0 == sy1 ? p0 % W : 0, sx1 = sy0 == sy1 ? p1 % W : W - 1;
-            const bool hit = (e.x | e.y) != 0 && sx0 - e.x < tx0 + TW && sx1 + e.x >= tx0 &&
-                             sy0 - e.y < ty0 + TH && sy1 + e.y >= ty0;
+            const int slot = b * spp + j;
+            const int4 e = ext[folded ? slot % npart : slot];
+            const int sy0 = jy * kStripH, sy1 = min(sy0 + kStripH, H) - 1;
+            const int sx0 = jx * kStripW, sx1 = min(sx0 + kStripW, W) - 1;
+            const bool hit = e.x <= e.y && sx0 + e.x <= tx1 && sx1 + e.y >= tx0 &&
+                             sy0 + e.z <= ty1 && sy1 + e.w >= ty0;
             if (hit) {
                 rx0 = min(rx0, sx0); rx1 = max(rx1, sx1);
                 ry0 = min(ry0, sy0); ry1 = max(ry1, sy1);
-                emx = max(emx, e.x); emy = max(emy, e.y);
+                dxl = min(dxl, e.x); dxh = max(dxh, e.y);
+                dyl = min(dyl, e.z); dyh = max(dyh, e.w);
             }
+            jx += qx; jy += qy;
+            if (jx >= strips.nx) { jx -= strips.nx; ++jy; }
         }
     }
-
-    // ---- grad_flow of this workgroup's share of the tile's own pixels, ALL channels ----
-    // The nsplit workgroups of a tile split its pixels (not the channels) for this part, so
-    // every pixel's channel sum is finished here: no partials, no second launch.  Independent
-    // of the scan region, so it goes first: its two round trips (positions, then gradOutput
-    // + image taps) overlap the strip read above and the LDS zeroing below.
-    if (gflow && !(dbg & 1)) {
-        const float *im = image + static_cast<int64_t>(b) * C * plane;
-        const float *gob = gout + static_cast<int64_t>(b) * C * plane;
-        const int ppw = (TH * TW + nsplit - 1) / nsplit;     // own pixels per workgroup
-        int ppad = 1;
-        while (ppad < ppw && ppad < 256) ppad <<= 1;         // pixels per round (power of two)
-        const int ncg = 256 / ppad;                           // channel groups
-        const int m = tid % ppad, cgi = tid / ppad;
-        for (int r0 = 0; r0 < ppw; r0 += ppad) {
-            const int q = split * ppw + r0 + m;               // tile-linear pixel
-            const int y = ty0 + q / TW, x = tx0 + q % TW;
-            const bool live = r0 + m < ppw && q < TH * TW && y < H && x < W;
-            const int p = min(y, H - 1) * W + min(x, W - 1);
-            const float ixp = pos[p], iyp = pos[plane + p];
-            const float x0f = floorf(ixp), y0f = floorf(iyp);
-            const float x1f = x0f + 1.f, y1f = y0f + 1.f;
-            const int x0 = static_cast<int>(x0f), y0 = static_cast<int>(y0f);
-            const bool okx0 = x0 >= 0 && x0 < W, okx1 = x0 + 1 >= 0 && x0 + 1 < W;
-            const bool oky0 = y0 >= 0 && y0 < H, oky1 = y0 + 1 >= 0 && y0 + 1 < H;
-            const int o00 = y0 * W + x0;
-            float gix = 0.f, giy = 0.f;
-            constexpr int kU = 8;  // channels per trip: 40 independent loads in flight per lane
-            for (int c = cgi; c < C; c += kU * ncg) {
-                float g[kU], vnw[kU], vne[kU], vsw[kU], vse[kU];
 #pragma unroll
-                for (int u = 0; u < kU; ++u) {
-                    const int cc = c + u * ncg;
-                    const bool on = cc < C;
-                    const int64_t cp = static_cast<int64_t>(on ? cc : c) * plane;
-                    g[u] = *tap_ptr(gob + cp + p, on);
-                    const float *qd = im + cp + o00;
-                    load_taps<false, float, float>(qd, oky0 && okx0, oky0 && okx1, vnw[u], vne[u]);
-                    load_taps<false, float, float>(qd + W, oky1 && okx0, oky1 && okx1, vsw[u], vse[u]);
-                }
-#pragma unroll
-                for (int u = 0; u < kU; ++u) {
-                    gix += (-vnw[u] * (y1f - iyp) + vne[u] * (y1f - iyp) - vsw[u] * (iyp - y0f) +
-                            vse[u] * (iyp - y0f)) * g[u];
-                    giy += (-vnw[u] * (x1f - ixp) - vne[u] * (ixp - x0f) + vsw[u] * (x1f - ixp) +
-                            vse[u] * (ixp - x0f)) * g[u];
-                }
-            }
-            gfl[tid][0] = gix;
-            gfl[tid][1] = giy;
-            __syncthreads();
-            if (cgi == 0 && live) {
-                float sx = 0.f, sy = 0.f;
-                for (int k = 0; k < ncg; ++k) { sx += gfl[m + k * ppad][0]; sy += gfl[m + k * ppad][1]; }
-                // clip_coordinates_set_grad from the clamped position, then autograd's order:
-                // grad_grid = mult * sum ; through norm_grid: / (size-1) then * 2.0
-                float mx = static_cast<float>(W) / 2.0f, my = static_cast<float>(H) / 2.0f;
-                if (pad_mode == CERB_PAD_BORDER) {
-                    if (ixp <= 0.f || ixp >= static_cast<float>(W - 1)) mx = 0.f;
-                    if (iyp <= 0.f || iyp >= static_cast<float>(H - 1)) my = 0.f;
-                }
-                float *gf = gflow + static_cast<int64_t>(b) * 2 * plane + p;
-                gf[0] = mx * sx / static_cast<float>(W - 1) * 2.0f;
-                gf[plane] = my * sy / static_cast<float>(H - 1) * 2.0f;
-            }
-            __syncthreads();
-        }
+    for (int m = 32; m >= 1; m >>= 1) {
+        rx0 = min(rx0, __shfl_xor(rx0, m, 64)); rx1 = max(rx1, __shfl_xor(rx1, m, 64));
+        ry0 = min(ry0, __shfl_xor(ry0, m, 64)); ry1 = max(ry1, __shfl_xor(ry1, m, 64));
+        dxl = min(dxl, __shfl_xor(dxl, m, 64)); dxh = max(dxh, __shfl_xor(dxh, m, 64));
+        dyl = min(dyl, __shfl_xor(dyl, m, 64)); dyh = max(dyh, __shfl_xor(dyh, m, 64));
     }
-    if (!gimage) return;
-
-    // region = (tile grown by the largest contributing extent) within (bounding box of the
-    // contributing strips): workgroup-wide min / max
-#pragma unroll
-    for (int msk = 32; msk >= 1; msk >>= 1) {
-        rx0 = min(rx0, __shfl_xor(rx0, msk, 64)); rx1 = max(rx1, __shfl_xor(rx1, msk, 64));
-        ry0 = min(ry0, __shfl_xor(ry0, msk, 64)); ry1 = max(ry1, __shfl_xor(ry1, msk, 64));
-        emx = max(emx, __shfl_xor(emx, msk, 64)); emy = max(emy, __shfl_xor(emy, msk, 64));
-    }
+    // (folding the boxes with LDS min/max atomics instead of shuffles: 64 lanes on 8 addresses
+    // serialise -- 19k instead of 5k cycles for this phase, measured)
     if (lane == 0) {
         red[wave][0] = rx0; red[wave][1] = rx1; red[wave][2] = ry0; red[wave][3] = ry1;
-        red[wave][4] = emx; red[wave][5] = emy;
+        red[wave][4] = dxl; red[wave][5] = dxh; red[wave][6] = dyl; red[wave][7] = dyh;
     }
-    for (int i = tid; i < CW * PS; i += 256) acc[i] = 0;
     __syncthreads();
-    emx = max(max(red[0][4], red[1][4]), max(red[2][4], red[3][4]));
-    emy = max(max(red[0][5], red[1][5]), max(red[2][5], red[3][5]));
-    const int xs = max(min(min(red[0][0], red[1][0]), min(red[2][0], red[3][0])), tx0 - emx);
-    const int xe = min(max(max(red[0][1], red[1][1]), max(red[2][1], red[3][1])) + 1, tx0 + TW + emx);
-    const int ys = max(min(min(red[0][2], red[1][2]), min(red[2][2], red[3][2])), ty0 - emy);
-    const int ye = min(max(max(red[0][3], red[1][3]), max(red[2][3], red[3][3])) + 1, ty0 + TH + emy);
-    const int rw = max(xe - xs, 0), n = rw * max(ye - ys, 0);
+    rx0 = min(min(red[0][0], red[1][0]), min(red[2][0], red[3][0]));
+    rx1 = max(max(red[0][1], red[1][1]), max(red[2][1], red[3][1]));
+    ry0 = min(min(red[0][2], red[1][2]), min(red[2][2], red[3][2]));
+    ry1 = max(max(red[0][3], red[1][3]), max(red[2][3], red[3][3]));
+    dxl = min(min(red[0][4], red[1][4]), min(red[2][4], red[3][4]));
+    dxh = max(max(red[0][5], red[1][5]), max(red[2][5], red[3][5]));
+    dyl = min(min(red[0][6], red[1][6]), min(red[2][6], red[3][6]));
+    dyh = max(max(red[0][7], red[1][7]), max(red[2][7], red[3][7]));
+    int n = 0, xs = 0, ys = 0, rw = 1;
+    if (rx0 <= rx1) {   // at least one strip reaches the tile (ranges are small ints here)
+        xs = max(rx0, tx0 - dxh);
+        ys = max(ry0, ty0 - dyh);
+        rw = max(min(rx1, tx1 - dxl) + 1 - xs, 0);
+        n = rw * max(min(ry1, ty1 - dyl) + 1 - ys, 0);
+        rw = max(rw, 1);
+    }
+    __syncthreads();    // red[] is reused below
+    CERB_STAMP_AT(1);
 
-    float *dst = gimage + (static_cast<int64_t>(b) * C + c0) * plane;
+    T *dst = gimage + static_cast<int64_t>(b) * C * plane;
+    const T *go = gout + static_cast<int64_t>(b) * C * plane;
     unsigned long long *acc64 = reinterpret_cast<unsigned long long *>(acc);
-    unsigned long long *dummy = acc64 + TH * TW + lane;
 
-    // One batch = up to NS sources per thread with every load in flight together (the first
-    // version walked its sources one by one -- position load -> test -> gradOutput loads ->
-    // atomics, two dependent round trips per source: pure memory latency).
-    // valid bits 0..3: nw, ne, sw, se tap lands inside image AND tile.
-    auto classify = [&](bool on, float ixj, float iyj, int &o) -> unsigned {
-        const int x0 = static_cast<int>(floorf(ixj)), y0 = static_cast<int>(floorf(iyj));
-        const int lx0 = x0 - tx0, ly0 = y0 - ty0;
-        const bool ox0 = on && x0 >= 0 && x0 < W && lx0 >= 0 && lx0 < TW;
-        const bool ox1 = on && x0 + 1 >= 0 && x0 + 1 < W && lx0 + 1 >= 0 && lx0 + 1 < TW;
-        const bool oy0 = y0 >= 0 && y0 < H && ly0 >= 0 && ly0 < TH;
-        const bool oy1 = y0 + 1 >= 0 && y0 + 1 < H && ly0 + 1 >= 0 && ly0 + 1 < TH;
-        o = ly0 * TW + lx0;
-        return (oy0 && ox0 ? 1u : 0u) | (oy0 && ox1 ? 2u : 0u) | (oy1 && ox0 ? 4u : 0u) |
-               (oy1 && ox1 ? 8u : 0u);
+    // One source = one pixel whose taps touch the tile: its pixel index, its offset in the
+    // padded plane and the two tap fractions.  The four weights are rebuilt from the fractions
+    // with the forward's roundings: ix - x0f is exact, and (x0f + 1) - ix is the correctly
+    // rounded 1 - (ix - x0f) either way.
+    struct Src { int pv, o; float fx, fy; };
+    // region pixel (row ry, column rx of the region; `on` = inside it)
+    auto classify = [&](bool on, int ry, int rx, Src &s) -> bool {
+        s.pv = on ? (ys + ry) * W + xs + rx : 0;
+        const float ixj = pos[s.pv], iyj = pos[plane + s.pv];
+        const float x0f = floorf(ixj), y0f = floorf(iyj);
+        const int lx = tap_index(x0f) - tx0 + 1, ly = tap_index(y0f) - ty0 + 1;
+        const bool in = on && lx >= 0 && lx <= TW && ly >= 0 && ly <= TH;
+        s.o = in ? ly * PW + lx : -1;
+        s.fx = ixj - x0f;
+        s.fy = iyj - y0f;
+        return in;
     };
-    // block max of |g| -> fixed-point scale.  Products land below 2^30: one v_cvt_i32_f32 per
-    // contribution (a 64-bit float->int conversion is a 12-instruction sequence),
-    // sign-extended into the 64-bit accumulator.
-    auto block_scale = [&](float gmax, float &scale, float &unscale) {
-        int gb = __float_as_int(gmax), unused = 0;   // non-negative floats order as ints
-        wave_max2(gb, unused);
-        __syncthreads();                              // earlier red[] reads are done
-        if (lane == 0) red[wave][0] = gb;
+    // walks idx = tid + 256 k over the region as (row, column) without divisions
+    struct Walk {
+        int ry, rx, qy, qx, rw;
+        __device__ Walk(int tid, int rw_) : ry(tid / rw_), rx(tid % rw_), qy(256 / rw_), qx(256 % rw_), rw(rw_) {}
+        __device__ __forceinline__ void next() { rx += qx; ry += qy; if (rx >= rw) { rx -= rw; ++ry; } }
+    };
+    // gradOutput of CW channels at one source (channels past the range re-read the last one)
+    auto load_g = [&](const Src &s, int c0, float (&g)[CW]) {
+#pragma unroll
+        for (int c = 0; c < CW; ++c)
+            g[c] = ld(go + static_cast<int64_t>(min(c0 + c, c_end - 1)) * plane + s.pv);
+    };
+    auto absmax_bits = [&](const Src &s, const float (&g)[CW], int gb) {
+        // integer order of |g| bit patterns: NaN > Inf > every finite value
+#pragma unroll
+        for (int c = 0; c < CW; ++c)
+            gb = max(gb, s.o >= 0 ? (__float_as_int(g[c]) & 0x7fffffff) : 0);
+        return gb;
+    };
+    // block maximum of two non-negative ints at once
+    auto block_max2 = [&](int &u, int &v) {
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            u = max(u, __shfl_xor(u, m, 64));
+            v = max(v, __shfl_xor(v, m, 64));
+        }
+        if (lane == 0) { red[wave][0] = u; red[wave][1] = v; }
         __syncthreads();
-        gmax = __int_as_float(max(max(red[0][0], red[1][0]), max(red[2][0], red[3][0])));
+        u = max(max(red[0][0], red[1][0]), max(red[2][0], red[3][0]));
+        v = max(max(red[0][1], red[1][1]), max(red[2][1], red[3][1]));
+        __syncthreads();   // red[] free again
+    };
+    auto block_max = [&](int v) { int u = 0; block_max2(u, v); return v; };
+    // tap density: the same four adds with the weights alone (16.16 fixed point) on a 32-bit
+    // view of the first plane
+    auto add_density = [&](const Src &s) {
+        if (s.o < 0) return;
+        const float ax = 1.0f - s.fx, ay = 1.0f - s.fy;
+        unsigned *d = reinterpret_cast<unsigned *>(acc) + s.o;
+        atomicAdd(d, static_cast<unsigned>(__float2int_rn(ax * ay * 65536.f)));
+        atomicAdd(d + 1, static_cast<unsigned>(__float2int_rn(s.fx * ay * 65536.f)));
+        atomicAdd(d + PW, static_cast<unsigned>(__float2int_rn(ax * s.fy * 65536.f)));
+        atomicAdd(d + PW + 1, static_cast<unsigned>(__float2int_rn(s.fx * s.fy * 65536.f)));
+    };
+    // largest density of the tile (ring included: conservative) -> headroom bits; leaves the
+    // plane zeroed.  `nsrc` bounds the rounding of the 16.16 weights.  The block reduction also
+    // carries the first group's gradient maximum `gb`.
+    auto density_bits = [&](int nsrc, int &gb) {
+        __syncthreads();
+        unsigned *d = reinterpret_cast<unsigned *>(acc);
+        unsigned m = 0;
+        for (int i = tid; i < PS; i += 256) { m = max(m, d[i]); d[i] = 0; }
+        int mi = static_cast<int>(min(m, 0x3fffffffu));
+        block_max2(mi, gb);
+        const unsigned dmax = static_cast<unsigned>(mi) + static_cast<unsigned>(nsrc);
+        // 2^S >= dmax / 65536
+        return max(0, 32 - __clz(static_cast<int>(dmax)) - 16);
+    };
+    // block maximum -> fixed-point scale (or "non-finite": accumulate in float)
+    auto block_scale = [&](int gb, bool reduced, int sbits, float &scale, float &unscale,
+                           bool &nonfinite) {
+        if (!reduced) gb = block_max(gb);   // its barriers also order: accumulators zeroed, write-out done
+        nonfinite = gb >= 0x7f800000;
         int gexp = 0;
-        frexpf(gmax, &gexp);                          // gmax < 2^gexp
-        gexp = max(gexp, -90);                        // keep 2^(30-gexp) finite for denormal maxima
+        frexpf(__int_as_float(gb), &gexp);            // gmax < 2^gexp
+        gexp = max(gexp, -90) + sbits;                // keep the scale finite for denormal maxima
         scale = ldexpf(1.0f, 30 - gexp);
         unscale = ldexpf(1.0f, gexp - 30);
     };
-    auto add_taps = [&](unsigned valid, int o, float ixj, float iyj, const float (&g)[CW],
-                        float scale) {
-        const float x0f = floorf(ixj), y0f = floorf(iyj);
-        const float x1f = x0f + 1.f, y1f = y0f + 1.f;
-        const float w00 = (valid & 1u) ? (x1f - ixj) * (y1f - iyj) * scale : 0.f;
-        const float w01 = (valid & 2u) ? (ixj - x0f) * (y1f - iyj) * scale : 0.f;
-        const float w10 = (valid & 4u) ? (x1f - ixj) * (iyj - y0f) * scale : 0.f;
-        const float w11 = (valid & 8u) ? (ixj - x0f) * (iyj - y0f) * scale : 0.f;
-        unsigned long long *a = acc64 + o;
-        unsigned long long *a00 = (valid & 1u) ? a : dummy;
-        unsigned long long *a01 = (valid & 2u) ? a + 1 : dummy;
-        unsigned long long *a10 = (valid & 4u) ? a + TW : dummy;
-        unsigned long long *a11 = (valid & 8u) ? a + TW + 1 : dummy;
+    auto add_taps = [&](const Src &s, const float (&g)[CW], int cw, float scale, bool nonfinite) {
+        if (s.o < 0) return;
+        const float ax = 1.0f - s.fx, ay = 1.0f - s.fy;
+        const float w00 = ax * ay, w01 = s.fx * ay, w10 = ax * s.fy, w11 = s.fx * s.fy;
+        unsigned long long *a = acc64 + s.o;
+        if (!nonfinite) {
+            // (a, b) -> a + (b << 32) as two's complement: low word a, high word b + (a >> 31)
+            auto pack = [](float va, float vb) {
+                const int ia = __float2int_rn(va), ib = __float2int_rn(vb);
+                return (static_cast<unsigned long long>(static_cast<unsigned>(ib + (ia >> 31))) << 32) |
+                       static_cast<unsigned>(ia);
+            };
 #pragma unroll
-        for (int c = 0; c < CW; ++c) {
-            if (c >= cw) break;
-            // two's-complement add: negative contributions wrap correctly
-            atomicAdd(a00 + c * PS, fixed64(w00 * g[c]));
-            atomicAdd(a01 + c * PS, fixed64(w01 * g[c]));
-            atomicAdd(a10 + c * PS, fixed64(w10 * g[c]));
-            atomicAdd(a11 + c * PS, fixed64(w11 * g[c]));
+            for (int q = 0; q < NP; ++q) {
+                if (2 * q >= cw) break;
+                const float ga = g[2 * q] * scale, gb2 = (2 * q + 1 < cw) ? g[2 * q + 1] * scale : 0.f;
+                atomicAdd(a + q * PS, pack(w00 * ga, w00 * gb2));
+                atomicAdd(a + q * PS + 1, pack(w01 * ga, w01 * gb2));
+                atomicAdd(a + q * PS + PW, pack(w10 * ga, w10 * gb2));
+                atomicAdd(a + q * PS + PW + 1, pack(w11 * ga, w11 * gb2));
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < CW; ++c) {
+                if (c >= cw) break;
+                float *f = reinterpret_cast<float *>(a + (c / 2) * PS) + (c & 1);
+                atomicAdd(f, w00 * g[c]);
+                atomicAdd(f + 2, w01 * g[c]);
+                atomicAdd(f + 2 * PW, w10 * g[c]);
+                atomicAdd(f + 2 * PW + 2, w11 * g[c]);
+            }
+        }
+    };
+    // the group's tile -> global memory; accumulators back to zero for the next group
+    auto write_out = [&](int c0, int cw, float unscale, bool nonfinite) {
+        const int npair = (cw + 1) / 2;
+        for (int i = tid; i < npair * TH * TW; i += 256) {
+            const int q = i / (TH * TW), rem = i % (TH * TW);
+            const int yy = rem / TW, xx = rem % TW;
+            const int slot = q * PS + (yy + 1) * PW + xx + 1;
+            const long long v = acc[slot];
+            acc[slot] = 0;
+            if (ty0 + yy < H && tx0 + xx < W) {
+                const int lo = static_cast<int>(v);
+                const int hi = static_cast<int>((v - lo) >> 32);
+                const float ra = nonfinite ? __int_as_float(lo) : static_cast<float>(lo) * unscale;
+                const float rb = nonfinite ? __int_as_float(static_cast<int>(v >> 32))
+                                           : static_cast<float>(hi) * unscale;
+                T *d = dst + static_cast<int64_t>(c0 + 2 * q) * plane + (ty0 + yy) * W + tx0 + xx;
+                st(d, ra);
+                if (2 * q + 1 < cw) st(d + plane, rb);
+            }
         }
     };
 
-    float scale = 1.f, unscale = 1.f;
-    if ((dbg & 4) || n == 0) {   // nothing lands in this tile: it is written as zeros
-    } else if (n <= 256 * NS) {
-        // ---- the whole scan fits one batch: sources stay in registers between the max
-        // reduction and the accumulation (tap extents up to ~8 px on interior tiles) ----
-        int pv[NS], o[NS];
-        float ix[NS], iy[NS], g[NS][CW];
-        unsigned valid[NS];
+    // ---- region scan: the sources that touch the tile, compacted ----
+    // The region is walked ONCE per workgroup, in batches with all position loads in flight;
+    // the sources whose taps touch the tile (under a rough flow half of the region misses it)
+    // are appended to a list that borrows the accumulators' LDS, then dealt to the threads:
+    // every thread keeps its NS sources in registers for all channel groups, so a group is
+    // one set of gradOutput loads, one block reduction, the adds and the write-out.  The
+    // list order depends on the waves' arrival order; the sums do not (integer adds commute).
+    constexpr int kCap = (NP * PS * 8) / 16 < 256 * NS ? (NP * PS * 8) / 16 : 256 * NS;
+    int4 *list = reinterpret_cast<int4 *>(acc);
+    if (tid == 0) red[1][1] = 0;
+    __syncthreads();
+    {
+        // regions of up to 2560 pixels (a 16 x 64 tile under +-7 px of flow variation) are
+        // classified in ONE batch: all position loads of the workgroup in flight together,
+        // one counter update per wave
+        constexpr int NB = 10;
+        Walk w(tid, rw);
+        for (int base = 0; base < n; base += 256 * NB) {
+            Src s[NB];
+            bool in[NB];
 #pragma unroll
-        for (int j = 0; j < NS; ++j) {
-            const int idx = min(j * 256 + tid, n - 1);  // clamped: always a valid address
-            pv[j] = (ys + idx / rw) * W + xs + idx % rw;
-            ix[j] = pos[pv[j]];
-            iy[j] = pos[plane + pv[j]];
-        }
-        float gmax = 0.f;
-#pragma unroll
-        for (int j = 0; j < NS; ++j) {
-            valid[j] = classify(j * 256 + tid < n, ix[j], iy[j], o[j]);
-#pragma unroll
-            for (int c = 0; c < CW; ++c)
-                g[j][c] = *tap_ptr(go + min(c, cw - 1) * plane + pv[j], valid[j] != 0);
-        }
-#pragma unroll
-        for (int j = 0; j < NS; ++j)
-#pragma unroll
-            for (int c = 0; c < CW; ++c) gmax = fmaxf(gmax, fabsf(g[j][c]));
-        block_scale(gmax, scale, unscale);
-        if (!(dbg & 2)) {
-#pragma unroll
-        for (int j = 0; j < NS; ++j)
-            if (valid[j]) add_taps(valid[j], o[j], ix[j], iy[j], g[j], scale);
-        }
-    } else {
-        // ---- larger extents: pass A finds the maximum, pass B reloads (L1/L2) and adds ----
-        constexpr int NB = 4;
-        float gmax = 0.f;
-        for (int pass = 0; pass < 2; ++pass) {
-            for (int base = 0; base < n; base += 256 * NB) {
-                int pv[NB], o[NB];
-                float ix[NB], iy[NB], g[NB][CW];
-                unsigned valid[NB];
-#pragma unroll
-                for (int j = 0; j < NB; ++j) {
-                    const int idx = min(base + j * 256 + tid, n - 1);
-                    pv[j] = (ys + idx / rw) * W + xs + idx % rw;
-                    ix[j] = pos[pv[j]];
-                    iy[j] = pos[plane + pv[j]];
-                }
-#pragma unroll
-                for (int j = 0; j < NB; ++j) {
-                    valid[j] = classify(base + j * 256 + tid < n, ix[j], iy[j], o[j]);
-#pragma unroll
-                    for (int c = 0; c < CW; ++c)
-                        g[j][c] = *tap_ptr(go + min(c, cw - 1) * plane + pv[j], valid[j] != 0);
-                }
-                if (pass == 0) {
-#pragma unroll
-                    for (int j = 0; j < NB; ++j)
-#pragma unroll
-                        for (int c = 0; c < CW; ++c) gmax = fmaxf(gmax, fabsf(g[j][c]));
-                } else {
-#pragma unroll
-                    for (int j = 0; j < NB; ++j)
-                        if (valid[j]) add_taps(valid[j], o[j], ix[j], iy[j], g[j], scale);
-                }
+            for (int j = 0; j < NB; ++j) {
+                in[j] = classify(base + j * 256 + tid < n, w.ry, w.rx, s[j]);
+                w.next();
             }
-            if (pass == 0) block_scale(gmax, scale, unscale);
+            // ranks by (j, lane) order
+            int rank[NB], total = 0;
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const unsigned long long m = __ballot(in[j]);
+                rank[j] = total + __popcll(m & ((1ull << lane) - 1ull));
+                total += __popcll(m);
+            }
+            int start = 0;
+            if (lane == 0 && total) start = atomicAdd(&red[1][1], total);
+            start = __shfl(start, 0, 64);
+#pragma unroll
+            for (int j = 0; j < NB; ++j)
+                if (in[j] && start + rank[j] < kCap)
+                    list[start + rank[j]] = make_int4(s[j].pv, s[j].o, __float_as_int(s[j].fx),
+                                                      __float_as_int(s[j].fy));
         }
     }
-
     __syncthreads();
-    for (int i = tid; i < cw * TH * TW; i += 256) {
-        const int c = i / (TH * TW), rem = i % (TH * TW);
-        const int yy = ty0 + rem / TW, xx = tx0 + rem % TW;
-        if (yy < H && xx < W)
-            dst[static_cast<int64_t>(c) * plane + yy * W + xx] =
-                fixed64_to_float(acc[c * PS + rem]) * unscale;
+    const int count = red[1][1];
+    __syncthreads();
+    CERB_STAMP_AT(2);
+
+    if (count <= kCap) {
+        Src src[NS];
+        float g[NS][CW];
+        const int ns = (count + 255) / 256;   // sources per thread actually present
+#pragma unroll
+        for (int j = 0; j < NS; ++j) {
+            const int e = j * 256 + tid;
+            const int4 v = list[min(e, kCap - 1)];
+            const bool have = e < count;
+            src[j].pv = have ? v.x : 0;
+            src[j].o = have ? v.y : -1;
+            src[j].fx = __int_as_float(v.z);
+            src[j].fy = __int_as_float(v.w);
+        }
+        __syncthreads();                       // everyone has its sources: the LDS becomes accumulators
+        static_assert((NP * PS) % 2 == 0, "accumulators are zeroed 16 bytes at a time");
+        for (int i = tid; i < NP * PS / 2; i += 256) reinterpret_cast<int4 *>(acc)[i] = make_int4(0, 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < NS; ++j)
+            if (j < ns) load_g(src[j], c_begin, g[j]);
+        __syncthreads();
+        CERB_STAMP_AT(3);
+#pragma unroll
+        for (int j = 0; j < NS; ++j)
+            if (j < ns) add_density(src[j]);
+        int gb0 = 0;
+#pragma unroll
+        for (int j = 0; j < NS; ++j)
+            if (j < ns) gb0 = absmax_bits(src[j], g[j], gb0);
+        const int sbits = density_bits(count, gb0);
+        CERB_STAMP_AT(4);
+        for (int c0 = c_begin; c0 < c_end; c0 += CW) {
+            const int cw = min(CW, c_end - c0);
+            int gb = gb0;
+            if (c0 != c_begin) {
+                gb = 0;
+#pragma unroll
+                for (int j = 0; j < NS; ++j)
+                    if (j < ns) gb = absmax_bits(src[j], g[j], gb);
+            }
+            float scale, unscale;
+            bool nonfinite;
+            block_scale(gb, c0 == c_begin, sbits, scale, unscale, nonfinite);
+            if (c0 == c_begin) CERB_STAMP_AT(5);
+#pragma unroll
+            for (int j = 0; j < NS; ++j)
+                if (j < ns) add_taps(src[j], g[j], cw, scale, nonfinite);
+            if (c0 == c_begin) CERB_STAMP_AT(6);
+            // the next group's gradOutput travels while this group's tile is written out
+            if (c0 + CW < c_end) {
+#pragma unroll
+                for (int j = 0; j < NS; ++j)
+                    if (j < ns) load_g(src[j], c0 + CW, g[j]);
+            }
+            __syncthreads();   // every tap of the group has been added
+            if (c0 == c_begin) CERB_STAMP_AT(7);
+            write_out(c0, cw, unscale, nonfinite);
+            if (c0 == c_begin) CERB_STAMP_AT(8);
+        }
+        CERB_STAMP_AT(9);
+    } else {
+        // ---- more sources than the list holds (flows that pile thousands of pixels onto one
+        // tile): walk the region again per channel group; pass A finds the maximum, pass B
+        // reloads (L1/L2) and adds ----
+        for (int i = tid; i < NP * PS; i += 256) acc[i] = 0;
+        __syncthreads();
+        constexpr int NB = 4;
+        {
+            Walk w(tid, rw);
+            for (int base = 0; base < n; base += 256 * NB) {
+                Src src[NB];
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    classify(base + j * 256 + tid < n, w.ry, w.rx, src[j]);
+                    w.next();
+                }
+#pragma unroll
+                for (int j = 0; j < NB; ++j) add_density(src[j]);
+            }
+        }
+        int unused_gb = 0;
+        const int sbits = density_bits(min(n, 0x3fffffff), unused_gb);
+        for (int c0 = c_begin; c0 < c_end; c0 += CW) {
+            const int cw = min(CW, c_end - c0);
+            float scale = 1.f, unscale = 1.f;
+            bool nonfinite = false;
+            int gb = 0;
+            for (int pass = 0; pass < 2; ++pass) {
+                Walk w(tid, rw);
+                for (int base = 0; base < n; base += 256 * NB) {
+                    Src src[NB];
+                    float g[NB][CW];
+#pragma unroll
+                    for (int j = 0; j < NB; ++j) {
+                        classify(base + j * 256 + tid < n, w.ry, w.rx, src[j]);
+                        w.next();
+                    }
+#pragma unroll
+                    for (int j = 0; j < NB; ++j) load_g(src[j], c0, g[j]);
+                    if (pass == 0) {
+#pragma unroll
+                        for (int j = 0; j < NB; ++j) gb = absmax_bits(src[j], g[j], gb);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < NB; ++j) add_taps(src[j], g[j], cw, scale, nonfinite);
+                    }
+                }
+                if (pass == 0) block_scale(gb, false, sbits, scale, unscale, nonfinite);
+            }
+            __syncthreads();
+            write_out(c0, cw, unscale, nonfinite);
+        }
     }
 }
 
@@ -681,13 +924,16 @@ size_t dtype_size(int dtype) {
 
 }  // namespace
 
-#define CERB_DISPATCH(dtype, ...)                                   \
-    switch (dtype) {                                                \
-        case CERB_F32:  { using T = float;        __VA_ARGS__; break; } \
-        case CERB_F16:  { using T = __half;       __VA_ARGS__; break; } \
-        case CERB_BF16: { using T = hip_bfloat16; __VA_ARGS__; break; } \
-        case CERB_F64:  { using T = double;       __VA_ARGS__; break; } \
-        default: return CERB_EDTYPE;                                \
+// (image dtype, flow dtype) pairs: the flow has the image's type or is fp32
+#define CERB_DISPATCH2(dtype, fdtype, ...)                                              \
+    switch (dtype) {                                                                    \
+        case CERB_F32:  { using T = float; using F = float; __VA_ARGS__; break; }       \
+        case CERB_F16:  if (fdtype == CERB_F32) { using T = __half; using F = float; __VA_ARGS__; } \
+                        else { using T = __half; using F = __half; __VA_ARGS__; } break; \
+        case CERB_BF16: if (fdtype == CERB_F32) { using T = hip_bfloat16; using F = float; __VA_ARGS__; } \
+                        else { using T = hip_bfloat16; using F = hip_bfloat16; __VA_ARGS__; } break; \
+        case CERB_F64:  { using T = double; using F = double; __VA_ARGS__; break; }     \
+        default: return CERB_EDTYPE;                                                    \
     }
 
 // channel groups per workgroup: keep ~8 channels (two 4-channel trips) per lane so that the
@@ -698,9 +944,16 @@ size_t dtype_size(int dtype) {
 
 int64_t warp_context_bytes(int B, int H, int W) { return ctx_bytes(B, H, W); }
 
+#ifdef CERB_STAMP
+extern "C" int cerberus_debug_stamps(void *dst, int bytes) {
+    return static_cast<int>(hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_stamps),
+                                                std::min<size_t>(bytes, sizeof(g_stamps))));
+}
+#endif
+
 // number of extent partials a context of this shape holds (= workgroups of its producer)
 static int ctx_partials(int B, int H, int W) {
-    const int64_t nstrips = B * ((static_cast<int64_t>(H) * W + kPix - 1) / kPix);
+    const int64_t nstrips = static_cast<int64_t>(B) * Strips(H, W).per_image();
     return static_cast<int>(std::min<int64_t>(nstrips, kCtxPartials));
 }
 
@@ -711,102 +964,133 @@ int64_t warp_backward_workspace_bytes(int B, int C, int H, int W) {
     return 16 + ctx_bytes(B, H, W);
 }
 
+static bool flow_dtype_ok(int dtype, int flow_dtype) {
+    return flow_dtype == dtype || (flow_dtype == CERB_F32 && (dtype == CERB_F16 || dtype == CERB_BF16));
+}
+
 int warp_forward(const void *image, const void *flow, void *out, void *ctx, int64_t ctx_size,
-                 int B, int C, int H, int W, int pad_mode, int interp, int dtype, hipStream_t s) {
-    const int64_t plane = static_cast<int64_t>(H) * W;
+                 int B, int C, int H, int W, int pad_mode, int interp, int dtype, int flow_dtype,
+                 hipStream_t s) {
     if (B == 0) return CERB_OK;
-    if (ctx && (ctx_size < ctx_bytes(B, H, W) || (reinterpret_cast<uintptr_t>(ctx) & 7)))
+    if (!flow_dtype_ok(dtype, flow_dtype)) return CERB_EDTYPE;
+    if (ctx && (ctx_size < ctx_bytes(B, H, W) || (reinterpret_cast<uintptr_t>(ctx) & 15)))
         return CERB_EINVAL;
-    const int64_t nstrips = B * ((plane + kPix - 1) / kPix);
+    const int64_t nstrips = static_cast<int64_t>(B) * Strips(H, W).per_image();
     if (nstrips > 0x7fffffff) return CERB_ETOOLARGE;
     // with a context the grid is capped: one extent partial per workgroup (ctx_partials of them)
     const unsigned blocks = static_cast<unsigned>(ctx ? ctx_partials(B, H, W) : nstrips);
     const dim3 grid(blocks);
-    if (option_value("warp_pair_taps") != 2) {  // default: paired taps in the forward gather
-        CERB_PICK_CG(C, CERB_DISPATCH(dtype, hipLaunchKernelGGL(
-            (warp_fwd_kernel<T, true, CG>), grid, dim3(kPix * CG), 0, s,
-            static_cast<const T *>(image), static_cast<const T *>(flow), static_cast<T *>(out), ctx,
-            B, C, H, W, pad_mode, interp, option_value("corr_debug_ablate"))))
+    if (option(OPT_WARP_PAIR_TAPS) != 2) {  // default: paired taps in the forward gather
+        CERB_PICK_CG(C, CERB_DISPATCH2(dtype, flow_dtype, hipLaunchKernelGGL(
+            (warp_fwd_kernel<T, F, true, CG>), grid, dim3(kPix * CG), 0, s,
+            static_cast<const T *>(image), static_cast<const F *>(flow), static_cast<T *>(out), ctx,
+            B, C, H, W, pad_mode, interp)))
     } else {
-        CERB_PICK_CG(C, CERB_DISPATCH(dtype, hipLaunchKernelGGL(
-            (warp_fwd_kernel<T, false, CG>), grid, dim3(kPix * CG), 0, s,
-            static_cast<const T *>(image), static_cast<const T *>(flow), static_cast<T *>(out), ctx,
-            B, C, H, W, pad_mode, interp, option_value("corr_debug_ablate"))))
+        CERB_PICK_CG(C, CERB_DISPATCH2(dtype, flow_dtype, hipLaunchKernelGGL(
+            (warp_fwd_kernel<T, F, false, CG>), grid, dim3(kPix * CG), 0, s,
+            static_cast<const T *>(image), static_cast<const F *>(flow), static_cast<T *>(out), ctx,
+            B, C, H, W, pad_mode, interp)))
     }
+    return launch_status();
+}
+
+template <typename T, typename F, int TH, int NS>
+static int launch_tiles(const void *image, const void *gout, const void *ctx, void *gimage,
+                        void *gflow, int B, int C, int H, int W, int pad_mode, hipStream_t s) {
+    constexpr int CW = 8;
+    const int tiles_x = (W + kTileW - 1) / kTileW, tiles_y = (H + TH - 1) / TH;
+    const int64_t tiles = static_cast<int64_t>(B) * tiles_x * tiles_y;
+    // channel ranges per tile: every range repeats the tile's region scan, so split only as
+    // far as it takes to fill the chip (~2 workgroups per CU), in whole groups of CW channels
+    int nrange = 1;
+    const int groups = (C + CW - 1) / CW;
+    while (nrange < groups && tiles * nrange < 512) nrange *= 2;
+    if (const int forced = option(OPT_WARP_TILE_RANGES)) nrange = forced;
+    nrange = std::max(1, std::min(nrange, groups));
+    const int crange = (groups + nrange - 1) / nrange * CW;
+    nrange = (C + crange - 1) / crange;
+    const int64_t tile_blocks = tiles * nrange;
+    const int64_t flow_blocks = gflow ? static_cast<int64_t>(B) * Strips(H, W).per_image() : 0;
+    if (tile_blocks + flow_blocks > 0x7fffffff) return CERB_ETOOLARGE;
+    hipLaunchKernelGGL((warp_bwd_tile_kernel<T, F, TH, CW, NS>),
+                       dim3(static_cast<unsigned>(tile_blocks + flow_blocks)), dim3(256), 0, s,
+                       static_cast<const T *>(image), static_cast<const T *>(gout), ctx,
+                       ctx_partials(B, H, W), static_cast<T *>(gimage), static_cast<F *>(gflow), B,
+                       C, H, W, tiles_x, tiles_y, nrange, crange, static_cast<int>(tile_blocks),
+                       pad_mode);
     return launch_status();
 }
 
 int warp_backward(const void *image, const void *flow, const void *gout, void *gimage,
                   void *gflow, const void *ctx, int64_t ctx_size, void *workspace,
                   int64_t workspace_bytes, int B, int C, int H, int W, int pad_mode, int interp,
-                  int dtype, hipStream_t s) {
+                  int dtype, int flow_dtype, hipStream_t s) {
     const int64_t plane = static_cast<int64_t>(H) * W;
     if (B == 0) return CERB_OK;
     const size_t esz = dtype_size(dtype);
     if (!esz) return CERB_EDTYPE;
+    if (!flow_dtype_ok(dtype, flow_dtype)) return CERB_EDTYPE;
     if (interp == CERB_INTERP_NEAREST || pad_mode == CERB_PAD_REFLECTION) {
         // nearest: grad_flow is identically zero and grad_image is a pure scatter;
         // no reference caller differentiates through either.
         return CERB_EUNSUPPORTED;
     }
-    if (ctx && (ctx_size < ctx_bytes(B, H, W) || (reinterpret_cast<uintptr_t>(ctx) & 7)))
+    if (ctx && (ctx_size < ctx_bytes(B, H, W) || (reinterpret_cast<uintptr_t>(ctx) & 15)))
         return CERB_EINVAL;
     const dim3 grid(static_cast<unsigned>((plane + kPix - 1) / kPix), B);
-    // tiled (owner-computes) path: fp32, grad_image wanted, caller gave the workspace
-    const bool tiled = gimage && dtype == CERB_F32 && workspace &&
-                       workspace_bytes >= warp_backward_workspace_bytes(B, C, H, W) &&
-                       (reinterpret_cast<uintptr_t>(workspace) & 7) == 0 &&
-                       static_cast<int64_t>(C) * plane < 0x7fffffff;
+    // tiled (owner-computes) path: grad_image wanted, fp32 or 16-bit storage, and a context --
+    // the forward's, or one built here in the caller's workspace
+    const bool ws_ok = workspace && workspace_bytes >= warp_backward_workspace_bytes(B, C, H, W) &&
+                       (reinterpret_cast<uintptr_t>(workspace) & 15) == 0;
+    const bool tiled = gimage && dtype != CERB_F64 && (ctx || ws_ok) &&
+                       static_cast<int64_t>(C) * plane < 0x7fffffff &&
+                       option(OPT_WARP_FORCE_SCATTER) == 0;
     if (tiled) {
-        constexpr int TH = 16, TW = 64;
         int rc;
         if (!ctx) {
-            // no forward context: positions + tap extents from the flow (one extra launch)
+            // no forward context: positions + tap ranges from the flow (one extra launch)
             void *own = static_cast<char *>(workspace) + 16;
-            hipLaunchKernelGGL(warp_context_kernel, dim3(ctx_partials(B, H, W)), dim3(kPix), 0, s,
-                               static_cast<const float *>(flow), own, B, H, W, pad_mode);
+            if (flow_dtype == CERB_F32)
+                hipLaunchKernelGGL(warp_context_kernel<float>, dim3(ctx_partials(B, H, W)), dim3(kPix),
+                                   0, s, static_cast<const float *>(flow), own, B, H, W, pad_mode);
+            else if (flow_dtype == CERB_F16)
+                hipLaunchKernelGGL(warp_context_kernel<__half>, dim3(ctx_partials(B, H, W)), dim3(kPix),
+                                   0, s, static_cast<const __half *>(flow), own, B, H, W, pad_mode);
+            else
+                hipLaunchKernelGGL(warp_context_kernel<hip_bfloat16>, dim3(ctx_partials(B, H, W)),
+                                   dim3(kPix), 0, s, static_cast<const hip_bfloat16 *>(flow), own, B,
+                                   H, W, pad_mode);
             if ((rc = launch_status())) return rc;
             ctx = own;
         }
-        const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
-        const int64_t tiles = static_cast<int64_t>(B) * tiles_x * tiles_y;
-        const int npart = ctx_partials(B, H, W);
-        // channels per workgroup: 4 (34 KiB of int64 accumulators, 4 workgroups per CU); 8 halves
-        // the redundant scanning but measured slower at every level (44 vs 50 us at level 3)
-        const bool cw8 = option_value("warp_tile_cw") == 8;
-        const int nsplit = cw8 ? (C + 7) / 8 : (C + 3) / 4;
-        const int64_t blocks = tiles * nsplit;
-        if (blocks > 0x7fffffff) return CERB_ETOOLARGE;
-        // ONE launch: grad_image tiles + grad_flow
-        if (cw8)
-            hipLaunchKernelGGL((warp_bwd_tile_kernel<TH, TW, 8, 5>), dim3(static_cast<unsigned>(blocks)),
-                               dim3(256), 0, s, static_cast<const float *>(image),
-                               static_cast<const float *>(gout), ctx, npart,
-                               static_cast<float *>(gimage), static_cast<float *>(gflow), B, C, H,
-                               W, tiles_x, tiles_y, nsplit, pad_mode, option_value("corr_debug_ablate"));
-        else
-            hipLaunchKernelGGL((warp_bwd_tile_kernel<TH, TW, 4, 10>), dim3(static_cast<unsigned>(blocks)),
-                               dim3(256), 0, s, static_cast<const float *>(image),
-                               static_cast<const float *>(gout), ctx, npart,
-                               static_cast<float *>(gimage), static_cast<float *>(gflow), B, C, H,
-                               W, tiles_x, tiles_y, nsplit, pad_mode, option_value("corr_debug_ablate"));
-        return launch_status();
+        // ONE launch: grad_image tiles + grad_flow strips.  Tile height: 16 rows, 8 on small
+        // maps (twice the workgroups, a smaller region per workgroup).
+        const int th_opt = option(OPT_WARP_TILE_H);
+        const bool th8 = th_opt ? th_opt == 8 : static_cast<int64_t>(B) * H * W <= 64 * 128 * 4;
+        if (th8) {
+            CERB_DISPATCH2(dtype, flow_dtype, if constexpr (!std::is_same<T, double>::value)
+                return (launch_tiles<T, F, 8, 5>(image, gout, ctx, gimage, gflow, B, C, H, W, pad_mode, s)))
+        } else {
+            CERB_DISPATCH2(dtype, flow_dtype, if constexpr (!std::is_same<T, double>::value)
+                return (launch_tiles<T, F, 16, 6>(image, gout, ctx, gimage, gflow, B, C, H, W, pad_mode, s)))
+        }
+        return CERB_EDTYPE;
     }
     if (gimage) {
         hipError_t e = hipMemsetAsync(gimage, 0, static_cast<size_t>(B) * C * plane * esz, s);
         if (e != hipSuccess) return static_cast<int>(e);
     }
-    if (option_value("warp_pair_taps") == 1) {
-        CERB_PICK_CG(C, CERB_DISPATCH(dtype, hipLaunchKernelGGL(
-            (warp_bwd_kernel<T, true, CG>), grid, dim3(kPix * CG), 0, s,
-            static_cast<const T *>(image), static_cast<const T *>(flow),
-            static_cast<const T *>(gout), static_cast<T *>(gimage), static_cast<T *>(gflow), B, C,
+    if (option(OPT_WARP_PAIR_TAPS) == 1) {
+        CERB_PICK_CG(C, CERB_DISPATCH2(dtype, flow_dtype, hipLaunchKernelGGL(
+            (warp_bwd_kernel<T, F, true, CG>), grid, dim3(kPix * CG), 0, s,
+            static_cast<const T *>(image), static_cast<const F *>(flow),
+            static_cast<const T *>(gout), static_cast<T *>(gimage), static_cast<F *>(gflow), B, C,
             H, W, pad_mode)))
     } else {
-        CERB_PICK_CG(C, CERB_DISPATCH(dtype, hipLaunchKernelGGL(
-            (warp_bwd_kernel<T, false, CG>), grid, dim3(kPix * CG), 0, s,
-            static_cast<const T *>(image), static_cast<const T *>(flow),
-            static_cast<const T *>(gout), static_cast<T *>(gimage), static_cast<T *>(gflow), B, C,
+        CERB_PICK_CG(C, CERB_DISPATCH2(dtype, flow_dtype, hipLaunchKernelGGL(
+            (warp_bwd_kernel<T, F, false, CG>), grid, dim3(kPix * CG), 0, s,
+            static_cast<const T *>(image), static_cast<const F *>(flow),
+            static_cast<const T *>(gout), static_cast<T *>(gimage), static_cast<F *>(gflow), B, C,
             H, W, pad_mode)))
     }
     return launch_status();

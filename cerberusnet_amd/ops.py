@@ -188,11 +188,26 @@ def _warp_check(image, flow, what):
         raise RuntimeError("%s: image and flow on different devices" % what)
 
 
+def _flow_for(img, flow):
+    """The flow as the kernels take it: in the image's dtype, except that an fp32 flow stays
+    fp32 beside a 16-bit image.  (Reference, UnFlowLoss.py:89-93: ``base_grid.type_as(image) +
+    flow12`` promotes to fp32 and grid_sample is on autocast's fp32 list, so a half image with
+    an fp32 flow is sampled at full flow precision -- rounding the flow to fp16/bf16 would
+    cost 0.03-0.25 px at |flow| of 32-512 px.)  The output keeps the image's dtype: the
+    reference's caller casts it back at once (pwcnet_sfd.py:178 ``.type(im1.dtype)``)."""
+    if flow.dtype == torch.float32 and img.dtype in (torch.float16, torch.bfloat16):
+        return flow.contiguous()
+    return flow.to(dtype=img.dtype).contiguous()
+
+
+_CTX_HEADER_BYTES = 2048 * 16   # warp.hip: kCtxPartials x int4 tap ranges
+
+
 def _flow_warp_run(image, flow, pad_mode, interp_mode, want_ctx, what):
     _warp_check(image, flow, what)
     code = _dtype_code(image, what)
     img = image.contiguous()
-    flo = flow.to(dtype=img.dtype).contiguous()
+    flo = _flow_for(img, flow)
     out = torch.empty_like(img)
     B, C, H, W = img.shape
     lib = _lib.get()
@@ -205,7 +220,7 @@ def _flow_warp_run(image, flow, pad_mode, interp_mode, want_ctx, what):
         rc = lib.cerberus_flow_warp_forward_ctx(
             img.data_ptr(), flo.data_ptr(), out.data_ptr(),
             ctx.data_ptr() if want_ctx else None, ctx_bytes, B, C, H, W, pad_mode, interp_mode,
-            code, _stream_ptr(img))
+            code, _DTYPES[flo.dtype], _stream_ptr(img))
     _lib.check(rc, what)
     return out, ctx
 
@@ -222,7 +237,7 @@ def _flow_warp_ctx_cuda(image, flow, pad_mode, interp_mode):
 
 def _flow_warp_ctx_meta(image, flow, pad_mode, interp_mode):
     B, _, H, W = image.shape
-    n = (2048 * 8 + B * 2 * H * W * 4 + 7) // 8
+    n = (_CTX_HEADER_BYTES + B * 2 * H * W * 4 + 7) // 8
     return torch.empty_like(image), image.new_empty((n,), dtype=torch.int64)
 
 
@@ -231,7 +246,7 @@ def _flow_warp_backward_run(image, flow, context, grad_out, pad_mode, interp_mod
     _warp_check(image, flow, what)
     code = _dtype_code(image, what)
     img = image.contiguous()
-    flo = flow.to(dtype=img.dtype).contiguous()
+    flo = _flow_for(img, flow)
     go = grad_out.to(dtype=img.dtype).contiguous()
     if go.shape != img.shape:
         raise RuntimeError("%s: grad_out shape %s, expected %s"
@@ -249,17 +264,20 @@ def _flow_warp_backward_run(image, flow, context, grad_out, pad_mode, interp_mod
                 or context.numel() * context.element_size() < ctx_bytes):
             raise RuntimeError("%s: context does not belong to this image/flow shape" % what)
         ctx_ptr = context.data_ptr()
-    # device scratch for the tiled grad_image (caching allocator: no sync, graph-capturable;
-    # stream-ordered reuse keeps it private to this call)
-    ws_bytes = lib.cerberus_flow_warp_backward_workspace_bytes(B, C, H, W)
-    ws = torch.empty((ws_bytes + 7) // 8, dtype=torch.int64, device=img.device) if need_image else None
+    # device scratch in which the tiled grad_image builds its context when the forward saved
+    # none (caching allocator: no sync, graph-capturable; stream-ordered reuse keeps it
+    # private to this call)
+    ws, ws_bytes = None, 0
+    if need_image and context is None:
+        ws_bytes = lib.cerberus_flow_warp_backward_workspace_bytes(B, C, H, W)
+        ws = torch.empty((ws_bytes + 7) // 8, dtype=torch.int64, device=img.device)
     with torch.cuda.device(img.device):
         rc = lib.cerberus_flow_warp_backward(
             img.data_ptr(), flo.data_ptr(), go.data_ptr(),
             gi.data_ptr() if need_image else None, gf.data_ptr() if need_flow else None,
             ctx_ptr, ctx_bytes,
-            ws.data_ptr() if ws is not None else None, ws_bytes if ws is not None else 0,
-            B, C, H, W, pad_mode, interp_mode, code, _stream_ptr(img))
+            ws.data_ptr() if ws is not None else None, ws_bytes,
+            B, C, H, W, pad_mode, interp_mode, code, _DTYPES[flo.dtype], _stream_ptr(img))
     _lib.check(rc, what)
     return [gi, gf]
 

@@ -7,8 +7,10 @@
  * (outputs included: the caller allocates, the library fully overwrites them).
  * Every entry point enqueues asynchronously on `stream` (a hipStream_t passed
  * as void*, NULL = default stream), never synchronises, allocates nothing
- * (scratch, where needed, is a caller-provided workspace), keeps no global mutable state (re-entrant: autograd may call backward from
- * its own engine thread) and is therefore safe to capture into a hipGraph.
+ * (scratch, where needed, is a caller-provided workspace), keeps no per-call state
+ * (re-entrant: autograd may call backward from its own engine thread; the only process-wide
+ * state is atomic: the tuning knobs below and a per-device "large LDS opted in" mask) and is
+ * therefore safe to capture into a hipGraph.
  *
  * Return value: 0 on success; a negative CERB_E* code for rejected arguments;
  * a positive value is the hipError_t reported by the launch.
@@ -32,7 +34,7 @@
 extern "C" {
 #endif
 
-#define CERBERUS_HIP_ABI_VERSION 2
+#define CERBERUS_HIP_ABI_VERSION 3
 
 /* element types (AT_DISPATCH_FLOATING_TYPES_AND_HALF in the reference,
  * correlation_cuda_kernel.cu:269,303; bf16 is an extension) */
@@ -117,28 +119,34 @@ int cerberus_flow_warp_forward(const void *image, const void *flow, void *out,
                                int interp_mode, int dtype, void *stream);
 
 /* The same forward, additionally saving what the backward needs again (what autograd's
- * save_for_backward is to the reference's grid_sample): every pixel's sample position and
- * the largest distance a tap lands from its own pixel.
- *   context : caller-owned device buffer of cerberus_flow_warp_context_bytes(B,H,W) bytes
- *             (8-byte aligned, contents irrelevant, fully written); NULL = plain forward. */
+ * save_for_backward is to the reference's grid_sample): every pixel's sample position and,
+ * per 64-pixel strip, the signed range of tap displacements.
+ *   context    : caller-owned device buffer of cerberus_flow_warp_context_bytes(B,H,W) bytes
+ *                (16-byte aligned, contents irrelevant, fully written); NULL = plain forward.
+ *                The layout is private to the library (an opaque blob between the two calls).
+ *   flow_dtype : element type of `flow`: equal to `dtype`, or CERB_F32 with a 16-bit image
+ *                (under autocast the reference's grid_sample runs in fp32 on whatever
+ *                precision the flow arrives in: an fp32 flow is not rounded to 16 bits). */
 int64_t cerberus_flow_warp_context_bytes(int B, int H, int W);
 int cerberus_flow_warp_forward_ctx(const void *image, const void *flow, void *out,
                                    void *context, int64_t context_bytes, int B, int C,
                                    int H, int W, int pad_mode, int interp_mode,
-                                   int dtype, void *stream);
+                                   int dtype, int flow_dtype, void *stream);
 
 /* flow_warp backward (autograd of the above w.r.t. image and flow).
- *   grad_image : (B,C,H,W) -- fully overwritten.  With a workspace (fp32): built tile by
- *                tile in LDS in 64-bit fixed point, no global atomics, bit-reproducible.
- *                Without: global float atomics as ATen's (summation order not fixed).
- *   grad_flow  : (B,2,H,W) -- fully overwritten, deterministic
+ *   grad_image : (B,C,H,W), dtype -- fully overwritten.  With a context or a workspace
+ *                (fp32 / fp16 / bf16): built tile by tile in LDS in 64-bit fixed point, no
+ *                global atomics, bit-reproducible; NaN / Inf in grad_out reach the same
+ *                elements as in ATen's scatter.  With neither (or fp64): global float atomics
+ *                as ATen's (summation order not fixed).
+ *   grad_flow  : (B,2,H,W), flow_dtype -- fully overwritten, deterministic
  *   context    : the buffer a cerberus_flow_warp_forward_ctx call with the SAME flow,
  *                shape and pad_mode filled, or NULL (the backward then derives it from the
- *                flow with one extra launch).
+ *                flow with one extra launch, into the workspace).
  *   workspace  : caller-owned device scratch of at least
- *                cerberus_flow_warp_backward_workspace_bytes(B,C,H,W) bytes (8-byte
- *                aligned, contents irrelevant), private to this call until it completes.
- *                NULL or too small selects the global-atomic scatter (ATen's method).
+ *                cerberus_flow_warp_backward_workspace_bytes(B,C,H,W) bytes (16-byte
+ *                aligned, contents irrelevant), private to this call until it completes;
+ *                only needed when context is NULL.
  * Either grad pointer may be NULL to skip that gradient. */
 int64_t cerberus_flow_warp_backward_workspace_bytes(int B, int C, int H, int W);
 int cerberus_flow_warp_backward(const void *image, const void *flow,
@@ -147,7 +155,7 @@ int cerberus_flow_warp_backward(const void *image, const void *flow,
                                 int64_t context_bytes, void *workspace,
                                 int64_t workspace_bytes, int B, int C, int H, int W,
                                 int pad_mode, int interp_mode, int dtype,
-                                void *stream);
+                                int flow_dtype, void *stream);
 
 /* Diagnostics / tuning knobs (process-wide, read at launch time, default 0):
  *   "corr_force_generic" : 1 = always use the generic kernels (testing)
@@ -156,10 +164,12 @@ int cerberus_flow_warp_backward(const void *image, const void *flow,
  *                          16 channel groups
  *   "corr_bwd_variant"   : 0 = auto, 1 = all 81 displacements per lane (register-staged),
  *                          2/3 = three displacement groups, 4 / 5 = LDS-DMA with the 8x64 /
- *                          16x32 tile (fp32, W % 4 == 0)
+ *                          16x32 tile (fp32, W % 4 == 0), 6 = displacement-row streaming
  *   "corr_bwd_cslice"    : 0 = auto, else channels per backward workgroup
  *   "warp_pair_taps"     : warp gather variant (0 default, 1 paired everywhere, 2 unpaired)
- *   "warp_tile_cw"       : channels per warp-backward tile workgroup (0 auto, 4, 8)
+ *   "warp_tile_ranges"   : channel ranges per warp-backward tile (0 auto)
+ *   "warp_tile_h"        : rows per warp-backward tile (0 auto, 8, 16)
+ *   "warp_force_scatter" : 1 = warp backward by global atomics even when a context exists
  * Returns CERB_EINVAL for an unknown key. */
 int cerberus_set_option(const char *key, int value);
 int cerberus_get_option(const char *key, int *value);

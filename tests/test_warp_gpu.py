@@ -154,7 +154,7 @@ def test_backward_without_workspace_uses_scatter_and_matches():
     gf = torch.full_like(flo, 7.0)
     rc = _lib.get().cerberus_flow_warp_backward(
         img.data_ptr(), flo.data_ptr(), go.data_ptr(), gi.data_ptr(), gf.data_ptr(), None, 0,
-        None, 0, 1, 6, 20, 36, 1, 0, 0,
+        None, 0, 1, 6, 20, 36, 1, 0, 0, 0,
         ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
     assert rc == 0
     torch.cuda.synchronize()
@@ -167,7 +167,7 @@ def test_backward_without_workspace_uses_scatter_and_matches():
     ws = torch.empty(2, dtype=torch.int64, device=DEV)
     rc = _lib.get().cerberus_flow_warp_backward(
         img.data_ptr(), flo.data_ptr(), go.data_ptr(), gi2.data_ptr(), None, None, 0,
-        ws.data_ptr(), 16, 1, 6, 20, 36, 1, 0, 0,
+        ws.data_ptr(), 16, 1, 6, 20, 36, 1, 0, 0, 0,
         ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
     assert rc == 0
     torch.cuda.synchronize()
@@ -178,7 +178,7 @@ def test_backward_without_workspace_uses_scatter_and_matches():
     gi3, gf3 = torch.full_like(img, 7.0), torch.full_like(flo, 7.0)
     rc = _lib.get().cerberus_flow_warp_backward(
         img.data_ptr(), flo.data_ptr(), go.data_ptr(), gi3.data_ptr(), gf3.data_ptr(), None, 0,
-        ws.data_ptr(), need, 1, 6, 20, 36, 1, 0, 0,
+        ws.data_ptr(), need, 1, 6, 20, 36, 1, 0, 0, 0,
         ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
     assert rc == 0
     torch.cuda.synchronize()
@@ -187,7 +187,7 @@ def test_backward_without_workspace_uses_scatter_and_matches():
     # a context of the wrong size is rejected
     rc = _lib.get().cerberus_flow_warp_backward(
         img.data_ptr(), flo.data_ptr(), go.data_ptr(), gi3.data_ptr(), gf3.data_ptr(),
-        ws.data_ptr(), 64, ws.data_ptr(), need, 1, 6, 20, 36, 1, 0, 0,
+        ws.data_ptr(), 64, ws.data_ptr(), need, 1, 6, 20, 36, 1, 0, 0, 0,
         ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
     assert rc == -1
 
@@ -279,3 +279,123 @@ def test_seeded_random_shape_sweep_against_the_oracle():
         assert rel_err(out, ref.numpy()) < TOL, (shape, amp, pad)
         assert rel_err(gi, rgi.numpy()) < TOL, (shape, amp, pad)
         assert rel_err(gf, rgf.numpy()) < TOL, (shape, amp, pad)
+
+
+def test_nonfinite_grad_out_reaches_the_same_elements_as_the_oracle():
+    """A NaN / Inf in grad_out must reach grad_image exactly where ATen's scatter puts it (the
+    four taps of that source, that channel) and nowhere else; the fixed-point tiles cannot
+    represent them, so such a (tile, channel group) accumulates in float (the first
+    tiled kernel laundered NaN into 0 and Inf into a finite value)."""
+    shape = (2, 9, 40, 140)
+    img = hash_uniform(shape, 81)
+    flo = hash_uniform((2, 2, 40, 140), 82, -5.0, 5.0)
+    go = hash_uniform(shape, 83)
+    go[0, 1, 3, 3] = np.nan
+    go[0, 5, 20, 77] = np.inf
+    go[1, 8, 39, 139] = -np.inf
+    go[1, 0, 17, 64] = np.nan
+    for pad in ("border", "zeros"):
+        _, rgi, rgf = oracle.flow_warp_grads_ref(torch.from_numpy(img), torch.from_numpy(flo),
+                                                 torch.from_numpy(go), pad)
+        _, gi, gf = hip_warp_with_grads(img, flo, go, pad)
+        rgi, rgf = rgi.numpy(), rgf.numpy()
+        assert np.array_equal(np.isnan(gi), np.isnan(rgi))
+        assert np.array_equal(np.isposinf(gi), np.isposinf(rgi))
+        assert np.array_equal(np.isneginf(gi), np.isneginf(rgi))
+        assert np.isnan(rgi).sum() >= 4 and np.isinf(rgi).sum() >= 2
+        ok = np.isfinite(rgi)
+        assert rel_err(np.where(ok, gi, 0), np.where(ok, rgi, 0)) < TOL
+        assert np.array_equal(np.isfinite(gf), np.isfinite(rgf))
+        okf = np.isfinite(rgf)
+        assert rel_err(np.where(okf, gf, 0), np.where(okf, rgf, 0)) < TOL
+
+
+@pytest.mark.parametrize("dt,tol", [(torch.float16, 2e-3), (torch.bfloat16, 1.6e-2)])
+@pytest.mark.parametrize("shape", [(1, 8, 20, 30), (1, 32, 256, 512)])
+def test_half_backward_is_tiled_deterministic_and_matches_the_oracle(dt, tol, shape):
+    """Config 5 (fp16 mixed precision, 2048x1024: the finest feature warp is 32x256x512): the
+    16-bit backward takes the owner-computes tiles (fp32 fixed-point accumulation, 16-bit I/O),
+    not a 16-bit CAS loop on global memory.  Against the torch-CPU oracle run in fp32 on the same
+    16-bit inputs; bit-reproducible run to run; equal (to 16-bit rounding) to the scatter path."""
+    from cerberusnet_amd import _lib
+    B, C, H, W = shape
+    img = torch.from_numpy(hash_uniform(shape, 91)).to(dt)
+    flo = torch.from_numpy(hash_uniform((B, 2, H, W), 92, -6.0, 6.0)).to(dt)
+    go = torch.from_numpy(hash_uniform(shape, 93)).to(dt)
+    _, rgi, rgf = oracle.flow_warp_grads_ref(img.float(), flo.float(), go.float(), "border")
+    i, f, g = img.to(DEV), flo.to(DEV), go.to(DEV)
+    out, ctx = torch.ops.cerberus.flow_warp_ctx(i, f, 1, 0)
+    gi, gf = torch.ops.cerberus.flow_warp_backward_ctx(i, f, ctx, g, 1, 0, True, True)
+    gi2, gf2 = torch.ops.cerberus.flow_warp_backward_ctx(i, f, ctx, g, 1, 0, True, True)
+    assert gi.dtype == dt and gf.dtype == dt
+    assert torch.equal(gi, gi2) and torch.equal(gf, gf2)
+    assert rel_err(gi.float().cpu().numpy(), rgi.numpy()) < tol
+    assert rel_err(gf.float().cpu().numpy(), rgf.numpy()) < tol
+    if H * W <= 4096:
+        _lib.set_option("warp_force_scatter", 1)
+        try:
+            gis, gfs = torch.ops.cerberus.flow_warp_backward_ctx(i, f, ctx, g, 1, 0, True, True)
+        finally:
+            _lib.set_option("warp_force_scatter", 0)
+        assert rel_err(gis.float().cpu().numpy(), rgi.numpy()) < 4 * tol
+        assert torch.equal(gfs, gf)
+
+
+def test_fp32_flow_beside_a_half_image_keeps_its_precision():
+    """a half image with an fp32 flow is sampled at full flow precision in the
+    reference (grid_sample is on autocast's fp32 list); the flow must not be rounded to the
+    image's dtype.  At |flow| ~ 200 px an fp16 flow is 0.06-0.12 px off."""
+    B, C, H, W = 1, 8, 64, 512
+    img16 = torch.from_numpy(hash_uniform((B, C, H, W), 95)).to(torch.float16)
+    flo = torch.from_numpy(hash_uniform((B, 2, H, W), 96, -1.0, 1.0))
+    flo[:, 0] += 200.37
+    go16 = torch.from_numpy(hash_uniform((B, C, H, W), 97)).to(torch.float16)
+    ref, rgi, rgf = oracle.flow_warp_grads_ref(img16.float(), flo, go16.float(), "border")
+    i = img16.to(DEV).requires_grad_(True)
+    f = flo.to(DEV).requires_grad_(True)
+    out = ca.flow_warp(i, f)
+    assert out.dtype == torch.float16
+    out.backward(go16.to(DEV))
+    assert f.grad.dtype == torch.float32 and i.grad.dtype == torch.float16
+    assert rel_err(out.detach().float().cpu().numpy(), ref.numpy()) < 1e-3      # fp16 output rounding
+    assert rel_err(i.grad.float().cpu().numpy(), rgi.numpy()) < 2e-3
+    assert rel_err(f.grad.cpu().numpy(), rgf.numpy()) < 1e-4
+    # the same call with the flow rounded to fp16 is visibly worse: the test would see it
+    bad = ca.flow_warp(img16.to(DEV), flo.to(DEV).half())
+    assert rel_err(bad.float().cpu().numpy(), ref.numpy()) > 5e-3
+
+
+@pytest.mark.parametrize("th", [8, 16])
+@pytest.mark.parametrize("ranges", [1, 2, 8])
+def test_tile_shapes_and_channel_ranges_agree_bit_for_bit(th, ranges):
+    """Every (tile height, channel ranges per tile) decomposition of the tiled backward adds
+    the same integers: identical bits, uniform translation (the shifted-region case), a
+    zooming flow (several sources per element) and noise."""
+    from cerberusnet_amd import _lib
+    B, C, H, W = 2, 20, 50, 200
+    img, go = dev(hash_uniform((B, C, H, W), 61)), dev(hash_uniform((B, C, H, W), 63))
+    ys, xs = np.meshgrid(np.arange(H, dtype=np.float32), np.arange(W, dtype=np.float32), indexing="ij")
+    flows = {
+        "shift": np.stack([np.full((H, W), 5.3, np.float32), np.full((H, W), -3.6, np.float32)]),
+        "zoom": np.stack([-0.4 * (xs - W / 2), -0.4 * (ys - H / 2)]),
+        "noise": hash_uniform((2, H, W), 62, -9.0, 9.0),
+    }
+    for name, fl in flows.items():
+        flo = dev(np.broadcast_to(fl, (B, 2, H, W)).copy())
+        _, ctx = torch.ops.cerberus.flow_warp_ctx(img, flo, 1, 0)
+        base = torch.ops.cerberus.flow_warp_backward_ctx(img, flo, ctx, go, 1, 0, True, True)
+        _lib.set_option("warp_tile_h", th)
+        _lib.set_option("warp_tile_ranges", ranges)
+        try:
+            got = torch.ops.cerberus.flow_warp_backward_ctx(img, flo, ctx, go, 1, 0, True, True)
+        finally:
+            _lib.set_option("warp_tile_h", 0)
+            _lib.set_option("warp_tile_ranges", 0)
+        _, rgi, rgf = oracle.flow_warp_grads_ref(img.cpu(), flo.cpu(), go.cpu(), "border")
+        assert rel_err(got[0].cpu().numpy(), rgi.numpy()) < TOL, name
+        assert rel_err(got[1].cpu().numpy(), rgf.numpy()) < TOL, name
+        assert torch.equal(got[1], base[1]), name
+        # the fixed-point scale is per (tile, 4-channel group): channel ranges cut on group
+        # boundaries see the same groups, so only the tile height may change the scale
+        if th == 16:
+            assert torch.equal(got[0], base[0]) or H * W * B <= 64 * 128 * 4, name

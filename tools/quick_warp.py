@@ -12,7 +12,9 @@ from bench import Workload
 ops = torch.ops.cerberus
 kind = sys.argv[1] if len(sys.argv) > 1 else "smooth"
 if len(sys.argv) > 2:
-    _lib.set_option("warp_tile_cw", int(sys.argv[2]))
+    _lib.set_option("warp_tile_h", int(sys.argv[2]))
+if len(sys.argv) > 3:
+    _lib.set_option("warp_tile_ranges", int(sys.argv[3]))
 for lvl, (C, H, W) in enumerate(pyramid_shapes()):
     if lvl == 0:
         continue
@@ -26,10 +28,11 @@ for lvl, (C, H, W) in enumerate(pyramid_shapes()):
     k1, _ = timeit(lambda: ops.flow_warp_backward(img, fl, go, 1, 0, False, True), 20, 5)
     noctx, _ = timeit(lambda: ops.flow_warp_backward(img, fl, go, 1, 0, True, True), 20, 5)
     full, _ = timeit(lambda: ops.flow_warp_backward_ctx(img, fl, ctx, go, 1, 0, True, True), 20, 5)
+    tiles, _ = timeit(lambda: ops.flow_warp_backward_ctx(img, fl, ctx, go, 1, 0, True, False), 20, 5)
     gi, gf = ops.flow_warp_backward_ctx(img, fl, ctx, go, 1, 0, True, True)
     gi2, gf2 = ops.flow_warp_backward_ctx(img, fl, ctx, go, 1, 0, True, True)
     wb = (3 * C + 4) * B * H * W * 4
     print("L%d %s fwd %.1f us (+ctx %.1f)  grad_flow only %.1f us  bwd no-ctx %.1f us  bwd ctx %.1f us "
-          "(%.2f TB/s)  reproducible=%s"
-          % (lvl, kind, f, fc, k1, noctx, full, wb / full / 1e6,
+          "(%.2f TB/s; tiles only %.1f us)  reproducible=%s"
+          % (lvl, kind, f, fc, k1, noctx, full, wb / full / 1e6, tiles,
              bool(torch.equal(gi, gi2) and torch.equal(gf, gf2))), flush=True)

@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""GPU, diagnostic build (CERB_EXTRA_HIPCC_FLAGS=-DCERB_STAMP python -m cerberusnet_amd.build --force):
+where a warp-backward TILE workgroup spends its time.  Prints the phase durations (in shader
+cycles and us at 2.4 GHz-ish; read the SHARES) of the first tile workgroups of one launch."""
+import ctypes, os, sys
+import numpy as np
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import cerberusnet_amd  # noqa: F401
+from cerberusnet_amd import _lib
+from cerberusnet_amd.synth import hash_uniform, pyramid_shapes
+from bench import Workload
+ops = torch.ops.cerberus
+lvl = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+kind = sys.argv[2] if len(sys.argv) > 2 else "smooth"
+C, H, W = pyramid_shapes()[lvl]
+B = 4
+img = torch.from_numpy(hash_uniform((B, C, H, W), 1)).cuda()
+go = torch.from_numpy(hash_uniform((B, C, H, W), 2)).cuda()
+fl = Workload._flow(B, H, W, 3, kind, "cuda")
+_, ctx = ops.flow_warp_ctx(img, fl, 1, 0)
+for _ in range(5):
+    ops.flow_warp_backward_ctx(img, fl, ctx, go, 1, 0, True, True)
+torch.cuda.synchronize()
+lib = _lib.get()
+buf = np.zeros((64, 16), dtype=np.uint64)
+rc = lib.cerberus_debug_stamps(buf.ctypes.data_as(ctypes.c_void_p), buf.nbytes)
+assert rc == 0, rc
+names = ["strip scan", "region scan+compact", "deal+zero+load g", "density", "max+scale", "adds",
+         "barrier", "write-out", "rest (other groups)"]
+d = np.diff(buf[:, :10].astype(np.int64), axis=1)
+t0 = buf[:, 0].astype(np.int64)
+print("start skew of the 64 workgroups (cycles): min %d max %d" % (0, int(t0.max() - t0.min())))
+tot = (buf[:, 9].astype(np.int64) - buf[:, 0].astype(np.int64))
+print("total per workgroup: median %d cycles, min %d, max %d" % (np.median(tot), tot.min(), tot.max()))
+for k, nme in enumerate(names):
+    print("  %-22s median %7d  (%4.1f %%)" % (nme, np.median(d[:, k]), 100.0 * np.median(d[:, k]) / np.median(tot)))
