@@ -1394,8 +1394,11 @@ struct BwdRowsCfg {
     static constexpr int ROW_INSTR = (ROW_SLOTS + 63) / 64, G_INSTR = (G_SLOTS + 63) / 64;
     static constexpr int ROW_PW = (ROW_INSTR + NG - 1) / NG, G_PW = (G_INSTR + NG - 1) / NG;  // per wave
     static constexpr size_t LDS_BYTES = sizeof(float) * (NRING * ROWF + NGB * GBUF);
+    // waves per SIMD the register allocator must leave room for: as many workgroups as LDS admits
+    static constexpr int WG_PER_CU = static_cast<int>((160 * 1024) / LDS_BYTES);
+    static constexpr int WPS = (WG_PER_CU * NG + 3) / 4 > 4 ? 4 : (WG_PER_CU * NG + 3) / 4;
     static_assert(ROWF % 64 == 0, "ring rows must be a multiple of 64 banks apart");
-    static_assert(ROW_PW <= 2 && G_PW <= 2, "at most two DMA instructions of each kind per wave");
+    static_assert(ROW_PW <= 4, "the counted wait handles up to four row DMA instructions per wave");
 };
 
 // one ds_read_b128, exactly as written: volatile keeps hipcc from splitting a 16-byte LDS read
@@ -1415,12 +1418,13 @@ __device__ __forceinline__ void rows_issue_row(float *__restrict__ wr, __amdgpu_
                                                const int (&voff)[K::ROW_PW], int wave, int gy,
                                                int H, int W, int c_begin, int plane, bool alive) {
     constexpr int kDead = static_cast<int>(0x80000000u);
+    constexpr int kNoSlot = static_cast<int>(0x80000001u);   // lane past the last slot: masked off
     const bool ok = alive && gy >= 0 && gy < H;                          // wave-uniform
     const int soff = __builtin_amdgcn_readfirstlane(ok ? (c_begin * plane + gy * W) * 4 : 0);
 #pragma unroll
     for (int q = 0; q < K::ROW_PW; ++q) {
         const int inst = wave + K::NG * q;
-        if (inst < K::ROW_INSTR)
+        if (inst < K::ROW_INSTR && (K::ROW_SLOTS % 64 == 0 || voff[q] != kNoSlot))
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_ptr)(wr + inst * 256), 16,
                                                      ok ? voff[q] : kDead, soff, 0, 0);
     }
@@ -1445,10 +1449,13 @@ __device__ __forceinline__ void rows_issue_g(float *__restrict__ wr, __amdgpu_bu
         const int pl = SIDE ? (kND - 1 - s) * kND + (kND - 1 - j) : s * kND + j;
         const int gy = y0 + r + (SIDE ? s - kD : 0);
         const int gx = x0 - kD + 4 * sl;
-        const bool ok = alive && i < K::G_SLOTS && gy >= 0 && gy < H && gx >= 0 && gx < W &&
+        const bool ok = alive && gy >= 0 && gy < H && gx >= 0 && gx < W &&
                         (SIDE || (sl >= 1 && sl <= 16));
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_ptr)(wr + inst * 256), 16,
-                                                 ok ? (pl * plane + gy * W + gx) * 4 : kDead, 0, 0, 0);
+        // lanes past the last slot are masked off: an out-of-range lane still WRITES its zeros,
+        // and the last instruction would run 896 bytes into the other buffer
+        if (i < K::G_SLOTS)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_ptr)(wr + inst * 256), 16,
+                                                     ok ? (pl * plane + gy * W + gx) * 4 : kDead, 0, 0, 0);
     }
 }
 
@@ -1459,10 +1466,17 @@ __device__ __forceinline__ void rows_step(
     float *__restrict__ g_wr, __amdgpu_buffer_rsrc_t rsrc_src, __amdgpu_buffer_rsrc_t rsrc_go,
     const int (&voff)[K::ROW_PW], int wave, int lane, int s, int x0, int y0, int H, int W,
     int c_begin, int plane, const int (&rowoff)[K::TH > 0 ? 1 : 1], int goff,
-    float (&acc)[K::CB][kP]) {
-    rows_issue_g<K, SIDE>(g_wr, rsrc_go, wave, lane, s + 1, x0, y0, H, W, plane, s + 1 < kND);
+    float (&acc)[K::CB][kP], int dbg) {
+    rows_issue_g<K, SIDE>(g_wr, rsrc_go, wave, lane, s + 1, x0, y0, H, W, plane, s + 1 < kND && !(dbg & 1));
+    // the counted wait at the end of the step relies on THIS order (gradOutput, then the row):
+    // the two DMA groups write disjoint restrict regions, so nothing else stops hipcc from
+    // swapping them (it did, in the copy of the loop body it made for odd steps)
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
     rows_issue_row<K>(row_wr, rsrc_src, voff, wave, y0 - kD + s + K::TH + 1, H, W, c_begin, plane,
-                      s + 2 < kND);
+                      s + 2 < kND && !(dbg & 2));
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
     // ---- gradOutput of this step: g[j][px] ----
     // (sched_barriers pin the order "reads of one block, then its FMAs": left alone hipcc
     // hoists every LDS read of the step to the top and spills 112 VGPRs)
@@ -1507,7 +1521,8 @@ __device__ __forceinline__ void rows_step(
 #pragma unroll
         for (int jj = 0; jj < kND; ++jj)
 #pragma unroll
-            for (int p = 0; p < kP; ++p) acc[i][p] = fmaf(g[jj][p], w[p + jj], acc[i][p]);
+            for (int p = 0; p < kP; ++p)
+                if (!(dbg & 4) || jj == 0) acc[i][p] = fmaf(g[jj][p], w[p + jj], acc[i][p]);
         __builtin_amdgcn_sched_barrier(0);
         w0 = n0; w1 = n1; w2 = n2;
     }
@@ -1515,11 +1530,14 @@ __device__ __forceinline__ void rows_step(
 #endif
 
 template <typename K>
-__global__ __launch_bounds__(K::THREADS, 4) void corr_bwd_d4_rows_kernel(
+__global__ __launch_bounds__(K::THREADS, K::WPS) void corr_bwd_d4_rows_kernel(
     const float *__restrict__ x1, const float *__restrict__ x2, const float *__restrict__ gout,
     float *__restrict__ gin1, float *__restrict__ gin2, int C, int H, int W, int tiles_x,
-    int tiles_y, int nrange) {
+    int tiles_y, int nrange, int dbg) {
 #if defined(__HIP_DEVICE_COMPILE__)
+#ifndef CERB_ABLATE
+    dbg = 0;   // timing ablations (1: no gradOutput DMA, 2: no row DMA, 4: no FMAs) exist in -DCERB_ABLATE builds only
+#endif
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int kDead = static_cast<int>(0x80000000u);
     const int tid = threadIdx.x;
@@ -1552,11 +1570,12 @@ __global__ __launch_bounds__(K::THREADS, 4) void corr_bwd_d4_rows_kernel(
     int voff[K::ROW_PW];
 #pragma unroll
     for (int q = 0; q < K::ROW_PW; ++q) {
+        constexpr int kNoSlot = static_cast<int>(0x80000001u);
         const int i = (wave + K::NG * q) * 64 + lane;
         const int ch = i / 18, sl = i % 18;
         const int gx = x0 - kD + 4 * sl;
-        voff[q] = (i < K::ROW_SLOTS && c_begin + ch < c_end && gx >= 0 && gx < W)
-                      ? (ch * plane + gx) * 4 : kDead;
+        voff[q] = i >= K::ROW_SLOTS ? kNoSlot
+                  : (c_begin + ch < c_end && gx >= 0 && gx < W) ? (ch * plane + gx) * 4 : kDead;
     }
 
     // ---- prologue: the TH+1 rows of steps 0 and 1, gradOutput of step 0 ----
@@ -1588,13 +1607,22 @@ __global__ __launch_bounds__(K::THREADS, 4) void corr_bwd_d4_rows_kernel(
         float *g_wr = gbufs + ((s + 1) & 1) * K::GBUF;
         if (side == 0)
             rows_step<K, 0>(ring, g_rd, ring + wslot * K::ROWF, g_wr, rsrc_src, rsrc_go, voff, wave, lane,
-                            s, x0, y0, H, W, c_begin, plane, rowoff, goff, acc);
+                            s, x0, y0, H, W, c_begin, plane, rowoff, goff, acc, dbg);
         else
             rows_step<K, 1>(ring, g_rd, ring + wslot * K::ROWF, g_wr, rsrc_src, rsrc_go, voff, wave, lane,
-                            s, x0, y0, H, W, c_begin, plane, rowoff, goff, acc);
+                            s, x0, y0, H, W, c_begin, plane, rowoff, goff, acc, dbg);
         // the next step's gradOutput has landed once only this step's row request(s), issued
         // after it, may still be in flight; every LDS read of this step has returned
-        if (wave + K::NG < K::ROW_INSTR) wait_vmcnt<2>(); else wait_vmcnt<1>();
+        {
+            int nrow = 0;   // row DMA instructions this wave issued in this step (wave-uniform)
+#pragma unroll
+            for (int q = 0; q < K::ROW_PW; ++q) nrow += (wave + K::NG * q < K::ROW_INSTR) ? 1 : 0;
+            if (nrow == 4) wait_vmcnt<4>();
+            else if (nrow == 3) wait_vmcnt<3>();
+            else if (nrow == 2) wait_vmcnt<2>();
+            else if (nrow == 1) wait_vmcnt<1>();
+            else wait_vmcnt<0>();
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
     }
@@ -1821,7 +1849,10 @@ using BwdWide = BwdCfg<32, 2, 72>;    // 8x64 tile
 // 4x64 tiles with 2 wavefronts (spills; 83 / 50 us).
 using BwdNarrow = BwdCfg<16, 2, 96>;  // 16x32 tile
 
-using BwdRows = BwdRowsCfg<4, 8>;   // 4x64 tile, 8 waves x 4 channels
+using BwdRows = BwdRowsCfg<4, 8>;     // 4x64 tile, 8 waves x 4 channels, 2 workgroups per CU
+using BwdRows44 = BwdRowsCfg<4, 4>;   // 4 waves x 4 channels = 16 channels per workgroup, 3 per CU
+using BwdRows84 = BwdRowsCfg<8, 4>;   // 4 waves x 8 channels
+using BwdRows82 = BwdRowsCfg<8, 2>;   // 2 waves x 8 channels = 16 channels per workgroup
 
 template <typename K>
 int launch_bwd_rows(const char *name, const void *in1, const void *in2, const void *goutp, void *g1p,
@@ -1839,7 +1870,7 @@ int launch_bwd_rows(const char *name, const void *in1, const void *in2, const vo
                        dim3(K::THREADS), K::LDS_BYTES, s, static_cast<const float *>(in1),
                        static_cast<const float *>(in2), static_cast<const float *>(goutp),
                        static_cast<float *>(g1p), static_cast<float *>(g2p), g.C, g.H, g.W, tiles_x,
-                       tiles_y, nrange);
+                       tiles_y, nrange, debug_mask());
     return launch_status();
 }
 
@@ -1967,6 +1998,16 @@ int bwd_dispatch(const void *x1, const void *x2, const void *go, void *g1, void 
                     return launch_bwd_rows<BwdRows>("corr_bwd_d4_rows_4x64", x1, x2, go, g1, g2, g, s);
             }
             break;
+        case 7: case 8: case 9:
+            if constexpr (sizeof(T) == 4) {
+                if (vec && dma_ok(g)) {
+                    const int v = option(OPT_CORR_BWD_VARIANT);
+                    if (v == 7) return launch_bwd_rows<BwdRows44>("corr_bwd_d4_rows_4x64_c16", x1, x2, go, g1, g2, g, s);
+                    if (v == 8) return launch_bwd_rows<BwdRows84>("corr_bwd_d4_rows_4x64_cb8", x1, x2, go, g1, g2, g, s);
+                    return launch_bwd_rows<BwdRows82>("corr_bwd_d4_rows_4x64_cb8_c16", x1, x2, go, g1, g2, g, s);
+                }
+            }
+            break;
         default: break;
     }
     // few tiles (coarse level): the displacement-group kernel puts 3x the wavefronts on the
@@ -1974,10 +2015,16 @@ int bwd_dispatch(const void *x1, const void *x2, const void *go, void *g1, void 
     const int64_t tiles = static_cast<int64_t>(g.B) * ((g.W + 63) / 64) * ((g.H + 7) / 8);
     if (tiles <= 32 && g.C >= 16)
         return launch_bwd_g3<BwdG3Wide4, T>("corr_bwd_d4_g3_8x64", x1, x2, go, g1, g2, g, vec, s);
-    // fp32 vector path: same kernel with the channel window streamed by LDS-DMA (identical bits)
     if constexpr (sizeof(T) == 4) {
-        if (vec && dma_ok(g))
+        if (vec && dma_ok(g)) {
+            // medium maps: the displacement-row streaming kernel reads gradOutput once per
+            // (tile, side) instead of once per channel slice (64x64x128 x4: 21.5 vs 25.9 us);
+            // on the largest maps the all-81-in-registers kernel is still ahead (39 vs 41-45 us)
+            if (tiles <= 128)
+                return launch_bwd_rows<BwdRows84>("corr_bwd_d4_rows_4x64_cb8", x1, x2, go, g1, g2, g, s);
+            // same arithmetic as corr_bwd_d4_kernel, the channel window streamed by LDS-DMA
             return launch_bwd_dma<BwdDma2x5>("corr_bwd_d4_dma_8x64", x1, x2, go, g1, g2, g, s);
+        }
     }
     return launch_bwd<BwdWide, T>("corr_bwd_d4_8x64", x1, x2, go, g1, g2, g, vec, s);
 }

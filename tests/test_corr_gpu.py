@@ -509,3 +509,49 @@ def test_seeded_random_shape_sweep_tuned_vs_generic():
             err = float((a - b).abs().max()) / scale
             assert err < TOL, (shape, what, err, sorted(kernels))
     assert any("dma" in k for k in kernels) and any("generic" not in k for k in kernels), kernels
+
+
+@pytest.mark.parametrize("variant", [6, 7, 8, 9])
+@pytest.mark.parametrize("shape", [(2, 32, 13, 72), (1, 10, 20, 64), (1, 7, 18, 36), (2, 40, 9, 132),
+                                   (1, 64, 4, 64), (3, 33, 37, 196), (1, 1, 1, 68), (2, 12, 8, 256)])
+def test_row_streaming_backward_against_the_oracle(shape, variant):
+    """Variant 6 (accumulators in registers, the nine vertical displacements streamed through
+    an LDS ring by LDS-DMA, all channels of a workgroup at once): ragged tiles in both
+    directions, channel ranges that do not fill a workgroup (C not a multiple of 32) and more
+    than one range, the shifted gradOutput slots of the second gradient at every border."""
+    B, C, H, W = shape
+    x1, x2 = hash_uniform(shape, 143), hash_uniform(shape, 144)
+    go = hash_uniform((B, 81, H, W), 145)
+    r1, r2 = oracle.corr_backward_ref(x1, x2, go, 4, 1, 4, 1, 1)
+    _lib.set_option("corr_bwd_variant", variant)
+    try:
+        g1, g2 = run_bwd(x1, x2, go, (4, 1, 4, 1, 1))
+        name = _lib.last_kernel(1)
+        g1b, g2b = run_bwd(x1, x2, go, (4, 1, 4, 1, 1))
+    finally:
+        _lib.set_option("corr_bwd_variant", 0)
+    assert name.startswith("corr_bwd_d4_rows_4x64"), name
+    assert rel_err(g1, r1) < TOL
+    assert rel_err(g2, r2) < TOL
+    assert np.array_equal(g1, g1b) and np.array_equal(g2, g2b)
+
+
+def test_row_streaming_backward_keeps_nonfinite_gradients_local():
+    """Out-of-image gradOutput slots read exact zeros (buffer bounds), so a NaN / Inf in
+    gradOutput reaches exactly the gradient elements the reference's sums touch."""
+    shape = (1, 8, 12, 64)
+    x1, x2 = hash_uniform(shape, 151), hash_uniform(shape, 152)
+    go = hash_uniform((1, 81, 12, 64), 153)
+    go[0, 40, 5, 0] = np.nan       # centre displacement, left border pixel
+    go[0, 3, 0, 63] = np.inf       # top-right corner
+    r1, r2 = oracle.corr_backward_ref(x1, x2, go, 4, 1, 4, 1, 1)
+    _lib.set_option("corr_bwd_variant", 6)
+    try:
+        g1, g2 = run_bwd(x1, x2, go, (4, 1, 4, 1, 1))
+    finally:
+        _lib.set_option("corr_bwd_variant", 0)
+    assert np.array_equal(np.isfinite(g1), np.isfinite(r1))
+    assert np.array_equal(np.isfinite(g2), np.isfinite(r2))
+    ok1, ok2 = np.isfinite(r1), np.isfinite(r2)
+    assert rel_err(np.where(ok1, g1, 0), np.where(ok1, r1, 0)) < TOL
+    assert rel_err(np.where(ok2, g2, 0), np.where(ok2, r2, 0)) < TOL
