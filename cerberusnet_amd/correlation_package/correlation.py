@@ -79,3 +79,51 @@ class Correlation(torch.nn.Module):
         hyper = tuple(getattr(self, name) for name in _HYPER)
         run = CorrelationFunction.apply if self.training else torch.ops.cerberus.correlation
         return run(input1, input2, *hyper)
+
+
+class CostVolumeConcat(torch.autograd.Function):
+    """``torch.cat([leaky_relu(corr(x1, x2), slope), *others], dim=1)`` with the cost volume
+    written by the correlation kernel straight into the concatenation buffer (the reference
+    builds it in three passes: the op, an in-place ``leaky_relu``, ``torch.cat``:
+    pwcnet_sfd.py:181-187).  Not on the reference's surface: an opt-in beside the drop-in one
+    (SURVEY.md section 8(f)-1).
+
+    The other tensors are copied into their channel slices (what ``cat`` does for them too);
+    backward hands their gradients out as views of the incoming gradient, applies the
+    LeakyReLU derivative from the sign of the stored volume and calls the one-launch
+    correlation backward.  The 81 channels of the buffer are an alias this function reads
+    again in backward: the buffer is the module's own and nobody writes those channels."""
+
+    @staticmethod
+    def forward(ctx, input1, input2, slope, hyper, *others):
+        oc, oh, ow = _ops._corr_out_shape(input1.shape[2], input1.shape[3], hyper[0], hyper[1],
+                                          hyper[2], hyper[3], hyper[4])
+        widths = [t.shape[1] for t in others]
+        buf = input1.new_empty((input1.shape[0], oc + sum(widths), oh, ow))
+        torch.ops.cerberus.correlation_leaky_into(buf, input1, input2, 0, *hyper, slope)
+        at = oc
+        for t, wdt in zip(others, widths):
+            buf[:, at:at + wdt].copy_(t)
+            at += wdt
+        ctx.save_for_backward(input1, input2)
+        ctx.volume = buf.detach()[:, :oc]     # alias, deliberately outside the version check
+        ctx.hyper, ctx.slope, ctx.widths, ctx.oc = tuple(hyper), slope, widths, oc
+        return buf
+
+    @staticmethod
+    def backward(ctx, grad):
+        input1, input2 = ctx.saved_tensors
+        g = grad[:, :ctx.oc]
+        g = torch.where(ctx.volume > 0, g, g * ctx.slope)
+        g1, g2 = torch.ops.cerberus.correlation_backward(input1, input2, g, *ctx.hyper)
+        outs, at = [], ctx.oc
+        for wdt in ctx.widths:
+            outs.append(grad[:, at:at + wdt])
+            at += wdt
+        return (g1, g2, None, None) + tuple(outs)
+
+
+def cost_volume_concat(input1, input2, others, hyper, negative_slope=0.1):
+    """See ``CostVolumeConcat``; ``hyper`` = (pad_size, kernel_size, max_displacement, stride1,
+    stride2, corr_multiply)."""
+    return CostVolumeConcat.apply(input1, input2, float(negative_slope), tuple(hyper), *others)

@@ -60,3 +60,65 @@ def rank0_state_dict(module: torch.nn.Module):
     by the reference (model_trainer.py:106-119 saves ``model_state_dict``)."""
     inner = module.module if isinstance(module, DistributedDataParallel) else module
     return inner.state_dict()
+
+
+class GradientExchange:
+    """The per-step gradient exchange of data-parallel training as a stand-alone piece: a
+    flat gradient buffer, cut into a few large buckets, all-reduced (mean) over the ranks on a
+    SIDE stream so that it overlaps whatever the main stream runs (the next kernels of the
+    step), joined back before the optimizer would read it.
+
+    This is what ``DistributedDataParallel`` does for a module's parameters (``wrap_ddp``);
+    callers that own their step -- a hipGraph replay of the hot path, ``bench.py`` -- use this
+    class to put the same traffic on RCCL / xGMI.  The reference has no multi-GPU training
+    (``utilities/model_trainer.py:57``); the wiring this stands for is the one the north star
+    names (``training_executor.py:26-56`` model construction, ``model_trainer.py:187-226``
+    ``loss.backward(); optimizer.step()``).
+
+    Buckets are large on purpose: xGMI is a point-to-point mesh, a ring all-reduce is bound by
+    one ~153 GB/s link, so few big collectives beat many NVSwitch-sized ones.
+    """
+
+    def __init__(self, numel: int, device: torch.device, bucket_mb: float = 64.0,
+                 dtype: torch.dtype = torch.float32):
+        self.flat = torch.zeros(numel, dtype=dtype, device=device)
+        per = max(1, int(bucket_mb * 2 ** 20) // self.flat.element_size())
+        self.buckets = list(self.flat.split(per))
+        self.on_gpu = device.type == "cuda"
+        self.stream = torch.cuda.Stream(device) if self.on_gpu else None
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        backend = dist.get_backend() if dist.is_initialized() else ""
+        # RCCL averages in the collective; gloo has no AVG: sum, then divide
+        self._avg = backend == "nccl"
+
+    @property
+    def nbytes(self) -> int:
+        return self.flat.numel() * self.flat.element_size()
+
+    def start(self):
+        """Enqueue the all-reduce of every bucket.  On a GPU it runs on the side stream, behind
+        what the main stream has enqueued SO FAR (the producer of the gradients) and beside
+        what it enqueues next."""
+        if self.world == 1:
+            return
+        if self.on_gpu:
+            self.stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.stream):
+                for b in self.buckets:
+                    dist.all_reduce(b, op=dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM)
+                    if not self._avg:
+                        b.div_(self.world)
+        else:
+            for b in self.buckets:
+                dist.all_reduce(b, op=dist.ReduceOp.SUM)
+                b.div_(self.world)
+
+    def finish(self):
+        """The main stream waits for the exchange (the optimizer step would come next)."""
+        if self.world > 1 and self.on_gpu:
+            torch.cuda.current_stream().wait_stream(self.stream)
+
+    @staticmethod
+    def bus_bandwidth(nbytes: int, seconds: float, world: int) -> float:
+        """Ring all-reduce bus bandwidth in bytes/s: algorithmic bytes/s x 2(n-1)/n."""
+        return nbytes / seconds * 2.0 * (world - 1) / world if world > 1 else 0.0

@@ -28,6 +28,13 @@ class GraphedFlowStep:
     graph is replayed, and the (static) loss tensor and flow lists are returned -- clone them
     if they must survive the next call.  Parameter ``.grad`` tensors are static too.
 
+    Caveat (PyTorch, not this package; measured on ROCm 7.2 / torch 2.10, tools/diag_graph_order.py):
+    a multi-block reduction inside ``loss_fn`` -- e.g. ``f.abs().mean()`` over a whole
+    full-resolution flow -- can replay a WRONG scalar when eager GPU work is interleaved
+    between replays, while the flows and every gradient of the same replay are bit-exact.
+    Reduce in block-sized stages (``f.abs().reshape(-1, 4096).mean(1).mean()``) or read the
+    loss from the returned flows.
+
     The optimizer, if given, must be graph-capturable (e.g. ``torch.optim.Adam(...,
     capturable=True)``).  ``bidirectional=False`` captures the forward direction only.
     """
@@ -45,32 +52,26 @@ class GraphedFlowStep:
         self.static2 = [t.detach().clone().requires_grad_(input_grads) for t in pyr2]
         self.params = [p for p in head.parameters() if p.requires_grad]
 
-        # Warm-up AND capture run on ONE private stream.  Autograd pins every leaf's
-        # AccumulateGrad node to the stream that was current when the node was created; with
-        # the warm-up on one side stream and the capture on another (torch.cuda.graph's
-        # default), the nodes kept alive from the warm-up made the engine hop streams inside
-        # the capture ("AccumulateGrad node's stream does not match ...", round-1 driver log).
-        # The warm-up lets MIOpen pick its algorithms and the allocator its blocks.
-        self.stream = torch.cuda.Stream()
-        self.stream.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(self.stream):
+        # Warm-up on a side stream (MIOpen picks its algorithms, the allocator its blocks), then
+        # capture with torch.cuda.graph's own stream and pool: PyTorch's documented whole-step
+        # recipe.  (Round 2 tried two variations and measured both wrong, tools/diag_graph_order.py:
+        # capturing on the warm-up stream, and detaching / collecting the captured outputs right
+        # after the capture -- either way the next EAGER step on the default stream corrupted the
+        # replayed loss scalar while every flow and gradient stayed bit-exact.  The recipe below
+        # is exact; autograd's "AccumulateGrad node's stream does not match" warning it can
+        # print is about an extra stream sync, not about results.)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
             for _ in range(max(1, warmup)):
                 self._step(set_to_none=True)
-        torch.cuda.current_stream().wait_stream(self.stream)
+        torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         gc.collect()   # autograd graphs of the warm-up (Function ctx cycles) die before capture
 
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph, stream=self.stream):
-            loss, fw, bw = self._step(set_to_none=True)
-        # static outputs WITHOUT their autograd graph: a kept grad_fn would keep the captured
-        # step's AccumulateGrad nodes (pinned to the capture stream) alive, and a later eager
-        # backward on another stream would have to hop to it
-        self.loss = loss.detach()
-        self.flows_fw = [f.detach() for f in fw]
-        self.flows_bw = [f.detach() for f in bw]
-        del loss, fw, bw
-        gc.collect()
+        with torch.cuda.graph(self.graph):
+            self.loss, self.flows_fw, self.flows_bw = self._step(set_to_none=True)
         # the gradient tensors the graph writes (graph-pool memory): kept here and re-attached
         # on every call, so that an outside ``zero_grad(set_to_none=True)`` or an eager step in
         # between cannot leave ``p.grad`` pointing somewhere the replay does not write

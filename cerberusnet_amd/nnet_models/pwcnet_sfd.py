@@ -17,6 +17,10 @@ except where noted):
   * ``fuse_leaky=True`` (default): LeakyReLU is applied in the correlation kernel's store
     (``cerberus::correlation_leaky``, SURVEY.md 8(f)-1) -- same values, one pass less over
     the 81-channel volume.
+  * ``fuse_concat=True`` (default, HIP backend with ``fuse_leaky``): the correlation kernel
+    writes its 81 channels straight into the ``torch.cat([out_corr, im1_1by1, flow])`` buffer
+    (:186-187) -- ``CostVolumeConcat``; same values, the 81-channel volume is not re-read and
+    re-written by a concatenation pass.
   * ``correlation_backend``: ``"hip"`` (default; no fallback: CPU tensors raise) or
     ``"torch"`` -- the reference's own pure-PyTorch ``CorrelationTorch`` + ``grid_sample``,
     for CPU-side wiring tests (DDP over gloo) only; never selected automatically.
@@ -27,7 +31,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from ..correlation_package.correlation import Correlation, CorrelationTorch
+from ..correlation_package.correlation import Correlation, CorrelationTorch, cost_volume_concat
 from ..loss_functions.UnFlowLoss import flow_warp, mesh_grid, norm_grid
 from .pwcnet_modules import ContextNetwork, FlowEstimatorDense, FlowEstimatorLite, conv_block
 
@@ -50,6 +54,7 @@ class PWCNetHead(nn.Module):
         self.upsample = upsample
         self.output_level = kwargs.get("output_level", 4)
         self.fuse_leaky = bool(kwargs.get("fuse_leaky", True))
+        self.fuse_concat = bool(kwargs.get("fuse_concat", True))
         self.correlation_backend = kwargs.get("correlation_backend", "hip")
         if self.correlation_backend not in ("hip", "torch"):
             raise ValueError("correlation_backend must be 'hip' or 'torch'")
@@ -106,9 +111,16 @@ class PWCNetHead(nn.Module):
             else:
                 flow = F.interpolate(flow * 2, scale_factor=2, mode="bilinear", align_corners=True)
                 im2_warp = self._warp(im2, flow).type(im1.dtype)
-            out_corr = self._cost_volume(im1, im2_warp)
-            feat, dflow = self.flow_estimator(
-                torch.cat([out_corr, self.conv_1x1[level](im1), flow], dim=1))
+            if self.correlation_backend == "hip" and self.fuse_leaky and self.fuse_concat:
+                c = self.corr
+                est_in = cost_volume_concat(
+                    im1, im2_warp, [self.conv_1x1[level](im1), flow],
+                    (c.pad_size, c.kernel_size, c.max_displacement, c.stride1, c.stride2,
+                     c.corr_multiply), 0.1)
+            else:
+                out_corr = self._cost_volume(im1, im2_warp)
+                est_in = torch.cat([out_corr, self.conv_1x1[level](im1), flow], dim=1)
+            feat, dflow = self.flow_estimator(est_in)
             flow = flow + dflow
             flow = flow + self.context_networks(torch.cat([feat, flow], dim=1))
             flows.append(flow)

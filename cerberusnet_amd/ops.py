@@ -41,6 +41,8 @@ _def.define("correlation_backward(Tensor input1, Tensor input2, Tensor gradOutpu
             "-> Tensor[]" % _CORR_ARGS)
 _def.define("correlation_leaky(Tensor input1, Tensor input2, %s, float negative_slope) "
             "-> Tensor" % _CORR_ARGS)
+_def.define("correlation_leaky_into(Tensor(a!) buffer, Tensor input1, Tensor input2, int channel_offset, "
+            "%s, float negative_slope) -> ()" % _CORR_ARGS)
 _def.define("flow_warp(Tensor image, Tensor flow, int pad_mode, int interp_mode) -> Tensor")
 _def.define("flow_warp_ctx(Tensor image, Tensor flow, int pad_mode, int interp_mode) -> "
             "(Tensor, Tensor)")
@@ -128,6 +130,38 @@ def _correlation_leaky_cuda(input1, input2, pad_size, kernel_size, max_displacem
     return _correlation_impl(input1, input2, pad_size, kernel_size, max_displacement, stride1,
                              stride2, corr_type_multiply, float(negative_slope),
                              "cerberus::correlation_leaky")
+
+
+def _correlation_leaky_into_cuda(buffer, input1, input2, channel_offset, pad_size, kernel_size,
+                                 max_displacement, stride1, stride2, corr_type_multiply,
+                                 negative_slope):
+    """The cost volume (with the fused LeakyReLU) written straight into channels
+    [channel_offset, channel_offset + oC) of a wider, caller-owned NCHW buffer: the
+    ``torch.cat([out_corr, im1_1by1, flow])`` of pwcnet_sfd.py:186-187 without the pass that
+    re-reads and re-writes the 81-channel volume."""
+    what = "cerberus::correlation_leaky_into"
+    _check_pair(input1, input2, what)
+    code = _dtype_code(input1, what)
+    x1, x2 = input1.contiguous(), input2.contiguous()
+    B, C, H, W = x1.shape
+    oc, oh, ow = _corr_out_shape(H, W, pad_size, kernel_size, max_displacement, stride1, stride2)
+    if (buffer.dim() != 4 or not buffer.is_contiguous() or buffer.dtype != x1.dtype or
+            buffer.device != x1.device or buffer.shape[0] != B or
+            tuple(buffer.shape[2:]) != (oh, ow) or channel_offset < 0 or
+            channel_offset + oc > buffer.shape[1]):
+        raise RuntimeError("%s: buffer %s (%s, contiguous=%s) cannot hold channels [%d, %d) of a "
+                           "(%d, %d, %d, %d) %s cost volume"
+                           % (what, tuple(buffer.shape), buffer.dtype, buffer.is_contiguous(),
+                              channel_offset, channel_offset + oc, B, oc, oh, ow, x1.dtype))
+    if B * oc * oh * ow == 0:
+        return
+    first = buffer[:, channel_offset]          # address of (0, channel_offset, 0, 0)
+    with torch.cuda.device(x1.device):
+        rc = _lib.get().cerberus_correlation_forward_ex(
+            x1.data_ptr(), x2.data_ptr(), first.data_ptr(), B, C, H, W, pad_size, kernel_size,
+            max_displacement, stride1, stride2, ctypes.c_float(float(negative_slope)),
+            buffer.stride(0), code, _stream_ptr(x1))
+    _lib.check(rc, what)
 
 
 def _correlation_meta(input1, input2, pad_size, kernel_size, max_displacement, stride1,
@@ -307,6 +341,9 @@ _def.impl("correlation", _no_cpu("correlation"), "CPU")
 _def.impl("correlation_leaky", _correlation_leaky_cuda, "CUDA")
 _def.impl("correlation_leaky", _correlation_meta, "Meta")
 _def.impl("correlation_leaky", _no_cpu("correlation_leaky"), "CPU")
+_def.impl("correlation_leaky_into", _correlation_leaky_into_cuda, "CUDA")
+_def.impl("correlation_leaky_into", lambda *a: None, "Meta")
+_def.impl("correlation_leaky_into", _no_cpu("correlation_leaky_into"), "CPU")
 _def.impl("correlation_backward", _correlation_backward_cuda, "CUDA")
 _def.impl("correlation_backward", _correlation_backward_meta, "Meta")
 _def.impl("correlation_backward", _no_cpu("correlation_backward"), "CPU")

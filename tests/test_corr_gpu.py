@@ -470,7 +470,7 @@ def test_dma_pipelines_with_fewer_chunks_than_ring_buffers(C, hw):
     out = run_fwd(x1, x2, (4, 1, 4, 1, 1))
     assert "dma" in _lib.last_kernel(0), _lib.last_kernel(0)
     g1, g2 = run_bwd(x1, x2, go, (4, 1, 4, 1, 1))
-    assert "dma" in _lib.last_kernel(1) or "g3" in _lib.last_kernel(1), _lib.last_kernel(1)
+    assert any(k in _lib.last_kernel(1) for k in ("dma", "g3", "rows")), _lib.last_kernel(1)
     ref = oracle.corr_forward_ref(x1, x2, 4, 1, 4, 1, 1)
     r1, r2 = oracle.corr_backward_ref(x1, x2, go, 4, 1, 4, 1, 1)
     assert rel_err(out, ref) < TOL
@@ -555,3 +555,44 @@ def test_row_streaming_backward_keeps_nonfinite_gradients_local():
     ok1, ok2 = np.isfinite(r1), np.isfinite(r2)
     assert rel_err(np.where(ok1, g1, 0), np.where(ok1, r1, 0)) < TOL
     assert rel_err(np.where(ok2, g2, 0), np.where(ok2, r2, 0)) < TOL
+
+
+@pytest.mark.parametrize("shape,total,off", [((2, 32, 13, 72), 115, 0), ((1, 16, 9, 64), 100, 7),
+                                             ((2, 7, 11, 132), 83, 2), ((4, 32, 128, 256), 115, 0),
+                                             ((1, 10, 20, 33), 90, 4)])
+def test_concat_buffer_output_against_the_oracle(shape, total, off):
+    """the cost volume (fused LeakyReLU) lands in channels [off, off+81) of a
+    wider buffer (batch stride = total*H*W); every other channel of the buffer stays
+    untouched.  Vector, scalar (W % 4 != 0) and unaligned-offset paths, against the C oracle."""
+    B, C, H, W = shape
+    x1, x2 = hash_uniform(shape, 161), hash_uniform(shape, 162)
+    ref = oracle.corr_forward_ref(x1, x2, 4, 1, 4, 1, 1)
+    ref = np.where(ref > 0, ref, ref * np.float32(0.1))
+    buf = torch.full((B, total, H, W), 7.5, device=DEV)
+    torch.ops.cerberus.correlation_leaky_into(buf, dev(x1), dev(x2), off, 4, 1, 4, 1, 1, 1, 0.1)
+    got = buf.cpu().numpy()
+    assert rel_err(got[:, off:off + 81], ref) < TOL
+    rest = np.delete(got, np.s_[off:off + 81], axis=1)
+    assert np.all(rest == 7.5)
+    with pytest.raises(RuntimeError, match="cannot hold"):
+        torch.ops.cerberus.correlation_leaky_into(buf, dev(x1), dev(x2), total - 80, 4, 1, 4, 1, 1, 1, 0.1)
+    with pytest.raises(RuntimeError, match="cannot hold"):
+        torch.ops.cerberus.correlation_leaky_into(buf[:, :, :, :-1], dev(x1), dev(x2), 0, 4, 1, 4, 1, 1, 1, 0.1)
+
+
+def test_concat_function_equals_cat_of_the_separate_ops():
+    """CostVolumeConcat (forward values and every gradient) against
+    torch.cat([correlation_leaky(...), a, b]) built from the separate ops."""
+    from cerberusnet_amd.correlation_package.correlation import cost_volume_concat
+    shape = (2, 16, 24, 64)
+    mk = lambda s, seed: dev(hash_uniform(s, seed)).requires_grad_(True)
+    x1, x2, a, b = mk(shape, 171), mk(shape, 172), mk((2, 32, 24, 64), 173), mk((2, 2, 24, 64), 174)
+    w = dev(hash_uniform((2, 81 + 34, 24, 64), 175))
+    hyper = (4, 1, 4, 1, 1, 1)
+    fused = cost_volume_concat(x1, x2, [a, b], hyper, 0.1)
+    gf = torch.autograd.grad((fused * w).sum(), (x1, x2, a, b))
+    sep = torch.cat([torch.ops.cerberus.correlation_leaky(x1, x2, *hyper, 0.1), a, b], dim=1)
+    gs = torch.autograd.grad((sep * w).sum(), (x1, x2, a, b))
+    assert torch.equal(fused, sep)
+    for u, v in zip(gf, gs):
+        assert torch.equal(u, v)

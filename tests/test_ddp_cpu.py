@@ -89,3 +89,33 @@ def test_shard_pairs_partitions_the_batch():
         seen = sorted(i for r in range(world) for i in cdist.shard_pairs(11, r, world))
         assert seen == list(range(11))
     assert cdist.init_from_env() == (0, 1)  # no env -> single process, no group
+
+
+def _exchange_worker(rank, world, port, out):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    assert cdist.init_from_env("gloo") == (rank, world)
+    ex = cdist.GradientExchange(10_000, torch.device("cpu"), bucket_mb=0.01)
+    assert len(ex.buckets) == 4 and ex.nbytes == 40_000          # 2621 floats per bucket
+    ex.flat.copy_(torch.from_numpy(hash_uniform((10_000,), 900 + rank)))
+    ex.start()
+    ex.finish()
+    if rank == 0:
+        torch.save(ex.flat.clone(), out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradient_exchange_averages_buckets_over_ranks(tmp_path):
+    """The stand-alone bucketed exchange bench.py puts in its timed loop (gloo, world 2): every
+    bucket ends up holding the mean over ranks."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "flat.pt")
+    mp.spawn(_exchange_worker, args=(2, port, out), nprocs=2, join=True)
+    got = torch.load(out)
+    want = (torch.from_numpy(hash_uniform((10_000,), 900)) +
+            torch.from_numpy(hash_uniform((10_000,), 901))) / 2
+    assert torch.equal(got, want)
+    assert cdist.GradientExchange.bus_bandwidth(100, 1.0, 8) == 175.0

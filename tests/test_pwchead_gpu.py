@@ -15,10 +15,13 @@ DEV = "cuda:0"
 
 
 @pytest.mark.parametrize("est,tag", [("FlowEstimatorLite", "lite"), ("FlowEstimatorDense", "dense")])
-@pytest.mark.parametrize("fuse", [True, False])
+@pytest.mark.parametrize("fuse", ["concat", "leaky", "none"])
 def test_hip_head_matches_reference_goldens(golden, est, tag, fuse):
+    """fuse: 'concat' = the correlation kernel writes LeakyReLU(corr) straight into the
+    estimator's concatenation buffer (the default), 'leaky' = fused LeakyReLU
+    + torch.cat, 'none' = the reference's three passes.  All against the REFERENCE head."""
     g = golden("pwchead_" + tag)
-    head = build(est, fuse_leaky=fuse).to(DEV)
+    head = build(est, fuse_leaky=fuse != "none", fuse_concat=fuse == "concat").to(DEV)
     p1, p2 = pyramids(g, DEV)
     flows = head((None, p1), (None, p2))
     for i, f in enumerate(flows):
@@ -78,7 +81,15 @@ def test_graphed_flow_step_equals_eager():
     level's input gradient by up to 1.7e-3 in l2 (0.5 % of its elements) -- which is what made
     the round-1 form of this test (l2 < 1e-3, default algorithms) flaky.  With deterministic
     algorithms eager == eager == graph replay, to the last bit, for every tensor: every kernel
-    of this package is bit-reproducible, so that is the honest bar."""
+    of this package is bit-reproducible, so that is the honest bar.
+
+    The loss reduces in two block-level stages (rows of 4096, then <= 512 values).  A single
+    ``f.abs().mean()`` over the 524288 elements of a full-resolution flow is one of PyTorch's
+    multi-block reductions (staging buffer + semaphores); replayed from a hipGraph with eager
+    work interleaved between replays, THAT scalar came back wrong (off by a constant, often
+    about half) while every flow and every gradient of the same replay stayed bit-exact --
+    measured with tools/diag_graph_order.py ('blockloss' vs default), independent of this
+    package's kernels.  GraphedFlowStep's docstring carries the caveat."""
     from cerberusnet_amd.graphs import GraphedFlowStep
     det = torch.backends.cudnn.deterministic
     torch.backends.cudnn.deterministic = True
@@ -87,7 +98,7 @@ def test_graphed_flow_step_equals_eager():
         head = build("FlowEstimatorLite").to(DEV)
         shapes = [(2, c, 8 * 2 ** l, 16 * 2 ** l) for l, c in enumerate(reversed(CHANS))]
         mk = lambda: [torch.randn(s, device=DEV) for s in shapes]
-        loss_fn = lambda flows: sum(f.abs().mean() for f in flows)
+        loss_fn = lambda flows: sum(f.abs().reshape(-1, 4096).mean(1).mean() for f in flows)
 
         def eager(p1, p2):
             for p in head.parameters():

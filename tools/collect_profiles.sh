@@ -1,25 +1,49 @@
 #!/bin/bash
-# Run ON THE GPU BOX (via gpurun): rocprofv3 kernel statistics of the default bench
-# command + the HBM-traffic PMC passes for the level-3 kernels.  Writes gpurun_out/profiles/.
+# Run ON THE GPU BOX (via gpurun): rocprofv3 evidence for profiles/.  Writes gpurun_out/profiles/.
+#   tools/collect_profiles.sh r02 <git commit of the sources>
 # Counters are collected in their own passes with --kernel-trace only (FETCH_SIZE and
 # WRITE_SIZE do not fit one pass on gfx950: MI355X_MICROARCH.md, rocprofv3 PMC slots).
 set -u
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-TAG=${1:-r01}
+TAG=${1:-r02}
+COMMIT=${2:-unknown}
 OUT=gpurun_out/profiles
 mkdir -p $OUT
+# 1. the default bench command under the profiler: per kernel symbol and per (kernel, grid)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/_stats -- python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline > $OUT/${TAG}_bench_under_rocprof.json 2> $OUT/_stats.err
 cp "$(find $OUT/_stats -name '*kernel_stats.csv' | head -1)" $OUT/${TAG}_kernel_stats.csv
-# one kernel symbol serves several pyramid levels: break the trace down by launch geometry
 python3 tools/trace_by_grid.py "$(find $OUT/_stats -name '*kernel_trace.csv' | head -1)" > $OUT/${TAG}_kernel_trace_by_grid.csv
-# level-3 kernels alone (the same symbols serve levels 1-3 with the same grid size, so the
-# whole-step statistics above average over levels): kernel stats of the roofline kernels
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/_l3 -- python3 tools/prof_kernels.py --levels 3 --warp --reps 20 > /dev/null 2> $OUT/_l3.err
-cp "$(find $OUT/_l3 -name '*kernel_stats.csv' | head -1)" $OUT/${TAG}_kernel_stats_level3.csv
-for pass in "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT"; do
-  name=$(echo $pass | cut -d' ' -f1)
-  rocprofv3 --kernel-trace --pmc $pass --output-format csv -d $OUT/_pmc_$name -- python3 tools/prof_kernels.py --levels 3 --warp --reps 5 > /dev/null 2> $OUT/_pmc_$name.err
+# 2. every pyramid level on its own (one symbol serves several levels with different grids)
+for L in 0 1 2 3; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/_l$L -- python3 tools/prof_kernels.py --levels $L --warp --reps 20 > /dev/null 2> $OUT/_l$L.err
+  cp "$(find $OUT/_l$L -name '*kernel_stats.csv' | head -1)" $OUT/${TAG}_kernel_stats_level$L.csv
 done
-python3 tools/pmc_to_traffic.py $OUT $TAG
-rm -rf $OUT/_stats $OUT/_l3 $OUT/_pmc_* $OUT/*.err
+# 3. PMC passes per level (traffic at the fabric + SQ/LDS counters)
+for L in 0 1 2 3; do
+  for pass in "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT" "SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES"; do
+    name=$(echo $pass | cut -d' ' -f1)
+    rocprofv3 --kernel-trace --pmc $pass --output-format csv -d $OUT/_pmc_L${L}_$name -- python3 tools/prof_kernels.py --levels $L --warp --reps 5 > /dev/null 2> $OUT/_pmc_L${L}_$name.err
+  done
+done
+python3 tools/pmc_to_traffic.py $OUT $TAG $COMMIT
+# 4. FETCH_SIZE calibration for the access widths of the warp gathers (known 1 GiB reads)
+if [ -x tools/ubench/fetch_calib ]; then
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/_calib -- ./tools/ubench/fetch_calib > $OUT/_calib.out 2> $OUT/_calib.err
+  python3 - "$OUT" "$TAG" <<'PY'
+import csv, glob, sys, json, collections
+out, tag = sys.argv[1], sys.argv[2]
+acc = collections.defaultdict(list)
+for p in glob.glob(out + "/_calib/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(p)):
+        if r["Counter_Name"] == "FETCH_SIZE":
+            acc[r["Kernel_Name"].split("(")[0]].append(float(r["Counter_Value"]))
+res = {"_note": "FETCH_SIZE (KiB) of kernels that read a known 1 GiB once; factor = true bytes / (FETCH_SIZE*1024)"}
+for k, v in acc.items():
+    m = sum(v) / len(v)
+    res[k] = {"FETCH_SIZE_KiB": m, "factor": (1 << 30) / (m * 1024.0) if m else None}
+json.dump(res, open("%s/%s_fetch_size_calibration.json" % (out, tag), "w"), indent=1)
+print(json.dumps(res, indent=1))
+PY
+fi
+rm -rf $OUT/_stats $OUT/_l? $OUT/_pmc_* $OUT/_calib $OUT/*.err $OUT/_calib.out
 ls -la $OUT
