@@ -176,3 +176,59 @@ def test_warp_numpy_fp64_agrees_with_torch_fp64():
                                 "reflection")
     assert rel_err(oracle.flow_warp_numpy(img, flo, "reflection"),
                    refl.numpy()) < 1e-13
+
+
+def test_c_oracle_is_clean_under_address_and_ub_sanitizers(tmp_path):
+    """The parity checker itself must not read or write out of bounds (GPU sanitizers are not
+    available on this pool, so the CPU restatement is where index arithmetic gets its
+    sanitizer run): `make asan` + a sweep of general (pad, k, d, s1, s2) incl. pad < d (Q5/Q7)
+    in a child process with libasan preloaded."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(oracle.__file__))
+    subprocess.run(["make", "-s", "-C", here, "asan"], check=True)
+    so = os.path.join(here, "_build", "libcorr_oracle_asan.so")
+    libasan = subprocess.run(["gcc", "-print-file-name=libasan.so"], capture_output=True,
+                             text=True, check=True).stdout.strip()
+    if not os.path.isabs(libasan) or not os.path.exists(libasan):
+        pytest.skip("gcc has no libasan.so in this image")
+    code = r'''
+import ctypes, sys
+import numpy as np
+lib = ctypes.CDLL(sys.argv[1])
+i, p = ctypes.c_int, ctypes.c_void_p
+lib.corr_oracle_out_shape.argtypes = [i] * 9 + [ctypes.POINTER(i)] * 3
+lib.corr_oracle_forward_f32.argtypes = [p, p, p] + [i] * 9
+lib.corr_oracle_backward_f32.argtypes = [p, p, p, p, p] + [i] * 9
+rng = np.random.RandomState(5)
+n = 0
+for (pad, k, d, s1, s2) in [(4, 1, 4, 1, 1), (3, 3, 6, 1, 2), (0, 1, 2, 1, 1), (2, 1, 4, 1, 1),
+                            (4, 1, 10, 1, 2), (5, 3, 4, 2, 1), (1, 5, 3, 1, 3)]:
+    for (B, C, H, W) in [(1, 1, 9, 11), (2, 5, 16, 13), (1, 3, 30, 7)]:
+        oc, oh, ow = i(), i(), i()
+        if lib.corr_oracle_out_shape(B, C, H, W, pad, k, d, s1, s2, ctypes.byref(oc),
+                                     ctypes.byref(oh), ctypes.byref(ow)):
+            continue
+        x1 = rng.rand(B, C, H, W).astype(np.float32)
+        x2 = rng.rand(B, C, H, W).astype(np.float32)
+        out = np.zeros((B, oc.value, oh.value, ow.value), np.float32)
+        assert lib.corr_oracle_forward_f32(x1.ctypes.data, x2.ctypes.data, out.ctypes.data,
+                                           B, C, H, W, pad, k, d, s1, s2) == 0
+        if s1 == 1:
+            g1, g2 = np.zeros_like(x1), np.zeros_like(x2)
+            go = rng.rand(*out.shape).astype(np.float32)
+            assert lib.corr_oracle_backward_f32(x1.ctypes.data, x2.ctypes.data, go.ctypes.data,
+                                                g1.ctypes.data, g2.ctypes.data, B, C, H, W,
+                                                pad, k, d, s1, s2) == 0
+        n += 1
+assert n >= 12, n
+print("sanitized calls:", n)
+'''
+    env = dict(os.environ, LD_PRELOAD=libasan, ASAN_OPTIONS="detect_leaks=0:halt_on_error=1",
+               UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
+    res = subprocess.run([sys.executable, "-c", code, so], env=env, capture_output=True, text=True,
+                         timeout=300)
+    assert res.returncode == 0, res.stderr[-2000:]
+    assert "sanitized calls" in res.stdout
+    assert "AddressSanitizer" not in res.stderr and "runtime error" not in res.stderr, res.stderr[-2000:]

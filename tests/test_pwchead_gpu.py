@@ -130,3 +130,35 @@ def test_graphed_flow_step_equals_eager():
             step([t[:1] for t in p1], p2)
     finally:
         torch.backends.cudnn.deterministic = det
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+def test_head_under_autocast_runs_the_16bit_kernels(golden, dt):
+    """AMP (BASELINE config 5): under torch.autocast the convolutions hand 16-bit features to the
+    hot-path ops, which must run in that dtype (CorrelationFunction has custom_fwd without
+    cast_inputs, correlation.py:30; the warp follows its image) and stay close to the fp32 run:
+    flows within a few percent (16-bit feature storage), finite gradients for every input
+    and parameter, 16-bit tiled warp backward (no global-atomic CAS loop)."""
+    from cerberusnet_amd import _lib
+    g = golden("pwchead_lite")
+    head = build("FlowEstimatorLite").to(DEV)
+    p1, p2 = pyramids(g, DEV)
+    ref = [f.detach() for f in head((None, p1), (None, p2))]
+    seen = []
+    with torch.autocast("cuda", dtype=dt):
+        h1 = [t.to(dt) for t in p1]
+        h2 = [t.to(dt) for t in p2]
+        for t in h1 + h2:
+            t.retain_grad()
+        flows = head((None, h1), (None, h2))
+        seen.append(_lib.last_kernel(0))
+        loss = sum((f.float() ** 2).mean() for f in flows)
+    loss.backward()
+    # the 16-bit correlation takes the register-staged tuned kernels (the LDS-DMA ones are fp32)
+    assert "corr_fwd_d4" in seen[0] and "dma" not in seen[0], seen
+    tol = 0.05 if dt == torch.float16 else 0.25
+    for f, r in zip(flows, ref):
+        assert rel_err(f.detach().float().cpu().numpy(), r.cpu().numpy()) < tol
+    for t in h1 + h2:
+        assert t.grad is not None and t.grad.dtype == dt and torch.isfinite(t.grad.float()).all()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in head.parameters())
