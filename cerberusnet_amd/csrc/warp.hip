@@ -97,15 +97,35 @@ template <typename T>
 __device__ __forceinline__ const T *tap_ptr(const T *real, bool ok) {
     return ok ? real : reinterpret_cast<const T *>(g_warp_zero);
 }
-// Variant: the two horizontal taps as ONE dword-aligned 8-byte load when both are inside
-// (fp32), separate guarded loads at the border.  Fewer gather instructions, but a branch.
+// Variant: the two horizontal taps as ONE load when both are inside -- 8 bytes at 4-byte
+// alignment (fp32) or 4 bytes at 2-byte alignment (fp16 / bf16; global memory takes unaligned
+// addresses) --, separate guarded loads at the border.  Half the gather instructions, but a
+// branch.
 struct __attribute__((packed, aligned(4))) f32x2_u { float a, b; };
+struct __attribute__((packed, aligned(2))) u16x2_u { unsigned short a, b; };
+template <typename T> __device__ __forceinline__ float widen16(unsigned short bits);
+template <> __device__ __forceinline__ float widen16<__half>(unsigned short bits) {
+    __half h;
+    __builtin_memcpy(&h, &bits, 2);
+    return __half2float(h);
+}
+template <> __device__ __forceinline__ float widen16<hip_bfloat16>(unsigned short bits) {
+    return __uint_as_float(static_cast<unsigned int>(bits) << 16);
+}
 template <bool PAIR, typename T, typename A>
 __device__ __forceinline__ void load_taps(const T *q, bool ok0, bool ok1, A &v0, A &v1) {
     if constexpr (PAIR && sizeof(T) == 4 && sizeof(A) == 4) {
         if (ok0 && ok1) {
             const f32x2_u t = *reinterpret_cast<const f32x2_u *>(q);
             v0 = t.a; v1 = t.b;
+        } else {
+            v0 = ok0 ? ld(q) : A(0);
+            v1 = ok1 ? ld(q + 1) : A(0);
+        }
+    } else if constexpr (PAIR && sizeof(T) == 2 && sizeof(A) == 4) {
+        if (ok0 && ok1) {
+            const u16x2_u t = *reinterpret_cast<const u16x2_u *>(q);
+            v0 = widen16<T>(t.a); v1 = widen16<T>(t.b);
         } else {
             v0 = ok0 ? ld(q) : A(0);
             v1 = ok1 ? ld(q + 1) : A(0);
@@ -492,6 +512,7 @@ __global__ __launch_bounds__(256, 4) void warp_bwd_tile_kernel(
                 const int64_t cp = static_cast<int64_t>(on ? cc : c) * plane;
                 g[u] = ld(tap_ptr(gob + cp + pc, on));
                 const T *qd = im + cp + o00;
+                // (unpaired: pairing the taps here measured no gain for fp32 and a loss for fp16)
                 load_taps<false, T, float>(qd, oky0 && okx0, oky0 && okx1, vnw[u], vne[u]);
                 load_taps<false, T, float>(qd + W, oky1 && okx0, oky1 && okx1, vsw[u], vse[u]);
             }
