@@ -183,6 +183,27 @@ int cerberus_flow_warp_backward(const void *image, const void *flow, const void 
                          flow_dtype, static_cast<hipStream_t>(stream));
 }
 
+static int upsample_entry(bool fwd, const void *src, void *dst, int64_t planes, int H, int W, int factor,
+                          int dtype, void *stream) {
+    if (!dtype_ok(dtype)) return CERB_EDTYPE;
+    if (planes < 0 || H <= 0 || W <= 0 || factor < 1) return CERB_EINVAL;
+    if (planes == 0) return CERB_OK;
+    if (!src || !dst) return CERB_EINVAL;
+    if (static_cast<int64_t>(H) * factor > 0x7fffffff || static_cast<int64_t>(W) * factor > 0x7fffffff)
+        return CERB_ETOOLARGE;
+    return flow_upsample(fwd, src, dst, planes, H, W, factor, dtype, static_cast<hipStream_t>(stream));
+}
+
+int cerberus_flow_upsample_forward(const void *src, void *dst, int64_t planes, int H, int W, int factor,
+                                   int dtype, void *stream) {
+    return upsample_entry(true, src, dst, planes, H, W, factor, dtype, stream);
+}
+
+int cerberus_flow_upsample_backward(const void *grad_out, void *grad_in, int64_t planes, int H, int W,
+                                    int factor, int dtype, void *stream) {
+    return upsample_entry(false, grad_out, grad_in, planes, H, W, factor, dtype, stream);
+}
+
 int cerberus_set_option(const char *key, int value) {
     if (!key) return CERB_EINVAL;
     const int i = find_option(key);

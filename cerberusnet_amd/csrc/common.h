@@ -4,6 +4,7 @@
 #include <hip/hip_fp16.h>
 #include <hip/hip_bfloat16.h>
 #include <stdint.h>
+#include <algorithm>
 
 #include "../../include/cerberus_hip.h"
 
@@ -124,6 +125,10 @@ int warp_backward(const void *image, const void *flow, const void *gout, void *g
                   void *gflow, const void *ctx, int64_t ctx_size, void *workspace,
                   int64_t workspace_bytes, int B, int C, int H, int W, int pad_mode, int interp,
                   int dtype, int flow_dtype, hipStream_t s);
+
+// upsample.hip: flow * factor -> bilinear x factor, align_corners = true (forward) / its adjoint
+int flow_upsample(bool forward, const void *src, void *dst, int64_t planes, int H, int W, int factor,
+                  int dtype, hipStream_t s);
 
 static inline int launch_status() {
     hipError_t e = hipGetLastError();

@@ -21,6 +21,10 @@ except where noted):
     writes its 81 channels straight into the ``torch.cat([out_corr, im1_1by1, flow])`` buffer
     (:186-187) -- ``CostVolumeConcat``; same values, the 81-channel volume is not re-read and
     re-written by a concatenation pass.
+  * ``fuse_upsample=True`` (default, HIP backend): ``F.interpolate(flow * k, scale_factor=k,
+    mode='bilinear', align_corners=True)`` (:176 with k = 2, :199-201 with k = 4) runs as ONE
+    launch (``cerberus::flow_upsample``) with a deterministic gather backward instead of a
+    multiply + ATen's upsample and its float-atomic backward.
   * ``correlation_backend``: ``"hip"`` (default; no fallback: CPU tensors raise) or
     ``"torch"`` -- the reference's own pure-PyTorch ``CorrelationTorch`` + ``grid_sample``,
     for CPU-side wiring tests (DDP over gloo) only; never selected automatically.
@@ -55,6 +59,7 @@ class PWCNetHead(nn.Module):
         self.output_level = kwargs.get("output_level", 4)
         self.fuse_leaky = bool(kwargs.get("fuse_leaky", True))
         self.fuse_concat = bool(kwargs.get("fuse_concat", True))
+        self.fuse_upsample = bool(kwargs.get("fuse_upsample", True))
         self.correlation_backend = kwargs.get("correlation_backend", "hip")
         if self.correlation_backend not in ("hip", "torch"):
             raise ValueError("correlation_backend must be 'hip' or 'torch'")
@@ -86,6 +91,11 @@ class PWCNetHead(nn.Module):
             return _torch_flow_warp(feat, flow)
         return flow_warp(feat, flow)
 
+    def _upsample(self, flow, factor):
+        if self.correlation_backend == "hip" and self.fuse_upsample:
+            return torch.ops.cerberus.flow_upsample(flow, factor)
+        return F.interpolate(flow * factor, scale_factor=factor, mode="bilinear", align_corners=True)
+
     def _cost_volume(self, im1, im2_warp):
         c = self.corr
         if self.correlation_backend == "torch":
@@ -109,7 +119,7 @@ class PWCNetHead(nn.Module):
             if level == 0:
                 im2_warp = im2
             else:
-                flow = F.interpolate(flow * 2, scale_factor=2, mode="bilinear", align_corners=True)
+                flow = self._upsample(flow, 2)
                 im2_warp = self._warp(im2, flow).type(im1.dtype)
             if self.correlation_backend == "hip" and self.fuse_leaky and self.fuse_concat:
                 c = self.corr
@@ -127,6 +137,5 @@ class PWCNetHead(nn.Module):
             if level == self.output_level:
                 break
         if self.upsample:
-            flows = [F.interpolate(f * 4, scale_factor=4, mode="bilinear", align_corners=True)
-                     for f in flows]
+            flows = [self._upsample(f, 4) for f in flows]
         return flows[::-1]

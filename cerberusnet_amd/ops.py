@@ -43,6 +43,8 @@ _def.define("correlation_leaky(Tensor input1, Tensor input2, %s, float negative_
             "-> Tensor" % _CORR_ARGS)
 _def.define("correlation_leaky_into(Tensor(a!) buffer, Tensor input1, Tensor input2, int channel_offset, "
             "%s, float negative_slope) -> ()" % _CORR_ARGS)
+_def.define("flow_upsample(Tensor flow, int factor) -> Tensor")
+_def.define("flow_upsample_backward(Tensor grad_out, int factor) -> Tensor")
 _def.define("flow_warp(Tensor image, Tensor flow, int pad_mode, int interp_mode) -> Tensor")
 _def.define("flow_warp_ctx(Tensor image, Tensor flow, int pad_mode, int interp_mode) -> "
             "(Tensor, Tensor)")
@@ -328,6 +330,45 @@ def _flow_warp_backward_ctx_cuda(image, flow, context, grad_out, pad_mode, inter
                                    need_image, need_flow, "cerberus::flow_warp_backward_ctx")
 
 
+# ----------------------------------------------------------------------------
+# flow upsample (pwcnet_sfd.py:176, :199-201)
+# ----------------------------------------------------------------------------
+def _flow_upsample_run(t, factor, forward, what):
+    if t.dim() != 4:
+        raise RuntimeError("%s: expected a 4-D NCHW tensor, got %s" % (what, tuple(t.shape)))
+    if factor < 1:
+        raise RuntimeError("%s: factor must be >= 1" % what)
+    code = _dtype_code(t, what)
+    if code == 3:
+        raise RuntimeError("%s: float64 is not supported" % what)
+    x = t.contiguous()
+    B, C, H, W = x.shape
+    if forward:
+        h, w = H, W
+        out = x.new_empty((B, C, H * factor, W * factor))
+    else:
+        if H % factor or W % factor:
+            raise RuntimeError("%s: grad shape %s is not a multiple of the factor %d"
+                               % (what, tuple(x.shape), factor))
+        h, w = H // factor, W // factor
+        out = x.new_empty((B, C, h, w))
+    if out.numel() == 0 or x.numel() == 0:
+        return out
+    fn = _lib.get().cerberus_flow_upsample_forward if forward else _lib.get().cerberus_flow_upsample_backward
+    with torch.cuda.device(x.device):
+        rc = fn(x.data_ptr(), out.data_ptr(), B * C, h, w, factor, code, _stream_ptr(x))
+    _lib.check(rc, what)
+    return out
+
+
+def _flow_upsample_cuda(flow, factor):
+    return _flow_upsample_run(flow, factor, True, "cerberus::flow_upsample")
+
+
+def _flow_upsample_backward_cuda(grad_out, factor):
+    return _flow_upsample_run(grad_out, factor, False, "cerberus::flow_upsample_backward")
+
+
 def _no_cpu(name):
     def _raise(*_a, **_k):
         raise RuntimeError("cerberus::%s has no CPU implementation: this build is the "
@@ -347,6 +388,13 @@ _def.impl("correlation_leaky_into", _no_cpu("correlation_leaky_into"), "CPU")
 _def.impl("correlation_backward", _correlation_backward_cuda, "CUDA")
 _def.impl("correlation_backward", _correlation_backward_meta, "Meta")
 _def.impl("correlation_backward", _no_cpu("correlation_backward"), "CPU")
+_def.impl("flow_upsample", _flow_upsample_cuda, "CUDA")
+_def.impl("flow_upsample", lambda f, k: f.new_empty((f.shape[0], f.shape[1], f.shape[2] * k, f.shape[3] * k)), "Meta")
+_def.impl("flow_upsample", _no_cpu("flow_upsample"), "CPU")
+_def.impl("flow_upsample_backward", _flow_upsample_backward_cuda, "CUDA")
+_def.impl("flow_upsample_backward",
+          lambda g, k: g.new_empty((g.shape[0], g.shape[1], g.shape[2] // k, g.shape[3] // k)), "Meta")
+_def.impl("flow_upsample_backward", _no_cpu("flow_upsample_backward"), "CPU")
 _def.impl("flow_warp", _flow_warp_cuda, "CUDA")
 _def.impl("flow_warp", lambda image, flow, p, m: torch.empty_like(image), "Meta")
 _def.impl("flow_warp", _no_cpu("flow_warp"), "CPU")
@@ -437,6 +485,27 @@ def _warp_ctx_backward(ctx, grad, _grad_context):
     return (gi if need_image else None, gf.to(flow.dtype) if need_flow else None, None, None)
 
 
+def _upsample_setup(ctx, inputs, output):
+    ctx.factor = inputs[1]
+
+
+def _upsample_backward(ctx, grad):
+    return torch.ops.cerberus.flow_upsample_backward(grad, ctx.factor), None
+
+
+def _upsample_bwd_setup(ctx, inputs, output):
+    ctx.factor = inputs[1]
+
+
+def _upsample_bwd_backward(ctx, grad):
+    # the adjoint of the adjoint is the forward (the op is linear)
+    return torch.ops.cerberus.flow_upsample(grad, ctx.factor), None
+
+
+torch.library.register_autograd("cerberus::flow_upsample", _upsample_backward,
+                                setup_context=_upsample_setup)
+torch.library.register_autograd("cerberus::flow_upsample_backward", _upsample_bwd_backward,
+                                setup_context=_upsample_bwd_setup)
 torch.library.register_autograd("cerberus::flow_warp", _warp_backward,
                                 setup_context=_warp_setup)
 torch.library.register_autograd("cerberus::flow_warp_ctx", _warp_ctx_backward,

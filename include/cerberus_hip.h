@@ -157,6 +157,19 @@ int cerberus_flow_warp_backward(const void *image, const void *flow,
                                 int pad_mode, int interp_mode, int dtype,
                                 int flow_dtype, void *stream);
 
+/* The flow pyramid's upsampling step, fused.  Replaces
+ *   F.interpolate(flow * factor, scale_factor=factor, mode='bilinear', align_corners=True)
+ * (nnet_training/nnet_models/pwcnet_sfd.py:176 with factor 2, :199-201 with factor 4): one launch
+ * instead of a multiply + ATen upsample_bilinear2d; the backward is a deterministic gather
+ * instead of ATen's float-atomic scatter.
+ *   forward : src (planes, H, W) -> dst (planes, H*factor, W*factor)
+ *   backward: src = grad of the upsampled tensor (planes, H*factor, W*factor) -> dst (planes, H, W)
+ * planes = B * channels of the contiguous NCHW tensor; factor >= 1; fp32 / fp16 / bf16. */
+int cerberus_flow_upsample_forward(const void *src, void *dst, int64_t planes, int H, int W,
+                                   int factor, int dtype, void *stream);
+int cerberus_flow_upsample_backward(const void *grad_out, void *grad_in, int64_t planes, int H,
+                                    int W, int factor, int dtype, void *stream);
+
 /* Diagnostics / tuning knobs (process-wide, read at launch time, default 0):
  *   "corr_force_generic" : 1 = always use the generic kernels (testing)
  *   "corr_fwd_variant"   : 0 = auto, 1..8 = force one register-staged forward variant,

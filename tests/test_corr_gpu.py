@@ -91,6 +91,26 @@ def test_general_parameters_against_c_oracle(p):
     assert rel_err(g2, r2) < TOL
 
 
+def test_reference_main_benchmark_point_at_its_own_size():
+    """The reference's only in-tree exercise of the op besides the models: ``correlation.py:82-113``
+    (``__main__``): pad 4 < d 10, k 1, strides 1 (output shrinks: Q5) on (16, 128|256, 128|256,
+    64|128) tensors.  One batch item of its smallest draw, forward and both gradients, against
+    the C restatement of the CUDA kernels (441 displacements x 128 channels)."""
+    p = (4, 1, 10, 1, 1)
+    shape = (1, 128, 128, 64)
+    x1, x2 = hash_uniform(shape, 21), hash_uniform(shape, 22)
+    ref = oracle.corr_forward_ref(x1, x2, *p)
+    assert ref.shape == (1, 441, 116, 52)
+    out = run_fwd(x1, x2, p)
+    assert _lib.last_kernel(0) == "corr_fwd_generic"
+    assert rel_err(out, ref) < TOL
+    go = hash_uniform(ref.shape, 23)
+    r1, r2 = oracle.corr_backward_ref(x1, x2, go, *p)
+    g1, g2 = run_bwd(x1, x2, go, p)
+    assert rel_err(g1, r1) < TOL
+    assert rel_err(g2, r2) < TOL
+
+
 def test_forward_stride1_gt_1_and_backward_rejects_it():
     x1 = hash_uniform((1, 4, 10, 12), 5)
     x2 = hash_uniform((1, 4, 10, 12), 6)

@@ -21,7 +21,8 @@ def test_hip_head_matches_reference_goldens(golden, est, tag, fuse):
     estimator's concatenation buffer (the default), 'leaky' = fused LeakyReLU
     + torch.cat, 'none' = the reference's three passes.  All against the REFERENCE head."""
     g = golden("pwchead_" + tag)
-    head = build(est, fuse_leaky=fuse != "none", fuse_concat=fuse == "concat").to(DEV)
+    head = build(est, fuse_leaky=fuse != "none", fuse_concat=fuse == "concat",
+                 fuse_upsample=fuse != "none").to(DEV)
     p1, p2 = pyramids(g, DEV)
     flows = head((None, p1), (None, p2))
     for i, f in enumerate(flows):

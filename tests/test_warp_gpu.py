@@ -399,3 +399,42 @@ def test_tile_shapes_and_channel_ranges_agree_bit_for_bit(th, ranges):
         # boundaries see the same groups, so only the tile height may change the scale
         if th == 16:
             assert torch.equal(got[0], base[0]) or H * W * B <= 64 * 128 * 4, name
+
+
+@pytest.mark.parametrize("factor", [2, 4])
+@pytest.mark.parametrize("shape", [(2, 2, 8, 16), (1, 2, 1, 1), (3, 2, 17, 5), (1, 2, 64, 128), (2, 3, 1, 9)])
+def test_flow_upsample_against_torch_interpolate(shape, factor):
+    """flow_upsample(flow, k) == F.interpolate(flow * k, scale_factor=k, 'bilinear',
+    align_corners=True) (pwcnet_sfd.py:176, :199-201) and its gradient (a deterministic gather
+    here, ATen's atomic scatter there), against torch on the CPU; single rows / columns / pixels
+    (scale 0 paths) included."""
+    import torch.nn.functional as F
+    x = torch.from_numpy(hash_uniform(shape, 181, -8.0, 8.0)).requires_grad_(True)
+    ref = F.interpolate(x * factor, scale_factor=factor, mode="bilinear", align_corners=True)
+    go = torch.from_numpy(hash_uniform(tuple(ref.shape), 182))
+    (rg,) = torch.autograd.grad(ref, x, go)
+    xd = x.detach().to(DEV).requires_grad_(True)
+    out = torch.ops.cerberus.flow_upsample(xd, factor)
+    (g,) = torch.autograd.grad(out, xd, go.to(DEV))
+    (g2,) = torch.autograd.grad(torch.ops.cerberus.flow_upsample(xd, factor), xd, go.to(DEV))
+    assert out.shape == ref.shape
+    assert rel_err(out.detach().cpu().numpy(), ref.detach().numpy()) < 1e-6
+    assert rel_err(g.cpu().numpy(), rg.numpy()) < 1e-6
+    assert torch.equal(g, g2)
+
+
+def test_flow_upsample_half_and_errors():
+    import torch.nn.functional as F
+    x = torch.from_numpy(hash_uniform((2, 2, 12, 20), 183, -4.0, 4.0))
+    ref = F.interpolate(x * 2, scale_factor=2, mode="bilinear", align_corners=True)
+    for dt, tol in ((torch.float16, 2e-3), (torch.bfloat16, 1.6e-2)):
+        out = torch.ops.cerberus.flow_upsample(x.to(DEV).to(dt), 2)
+        assert out.dtype == dt
+        assert rel_err(out.float().cpu().numpy(), F.interpolate(x.to(dt).float() * 2, scale_factor=2, mode="bilinear",
+                                                              align_corners=True).numpy()) < tol
+    with pytest.raises(RuntimeError, match="factor"):
+        torch.ops.cerberus.flow_upsample(x.to(DEV), 0)
+    with pytest.raises(RuntimeError, match="multiple"):
+        torch.ops.cerberus.flow_upsample_backward(x.to(DEV), 8)
+    with pytest.raises(RuntimeError, match="no CPU"):
+        torch.ops.cerberus.flow_upsample(x, 2)
