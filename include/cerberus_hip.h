@@ -177,7 +177,8 @@ int cerberus_flow_upsample_backward(const void *grad_out, void *grad_in, int64_t
  *                          16 channel groups
  *   "corr_bwd_variant"   : 0 = auto, 1 = all 81 displacements per lane (register-staged),
  *                          2/3 = three displacement groups, 4 / 5 = LDS-DMA with the 8x64 /
- *                          16x32 tile (fp32, W % 4 == 0), 6 = displacement-row streaming
+ *                          16x32 tile (fp32, W % 4 == 0), 6..9 = displacement-row streaming
+ *                          (4 configurations), 10 = the same walking down a column of tiles
  *   "corr_bwd_cslice"    : 0 = auto, else channels per backward workgroup
  *   "warp_pair_taps"     : warp gather variant (0 default, 1 paired everywhere, 2 unpaired)
  *   "warp_tile_ranges"   : channel ranges per warp-backward tile (0 auto)
