@@ -15,7 +15,7 @@ from typing import Callable, List, Optional, Sequence
 
 import torch
 
-__all__ = ["GraphedFlowStep"]
+__all__ = ["GraphedFlowStep", "GraphedFlowInference"]
 
 
 class GraphedFlowStep:
@@ -113,3 +113,53 @@ class GraphedFlowStep:
     def input_gradients(self):
         """Static gradients of the input pyramids (``input_grads=True`` at construction)."""
         return self.input_grads1, self.input_grads2
+
+
+class GraphedFlowInference:
+    """The forward of the flow head alone, captured once and replayed: the low-latency inference
+    path (what the reference gets from its TensorRT engine + correlation / grid-sampler plugins,
+    ``runtime/cerberus_net/trt_plugins``; SURVEY.md section 8(f)-4 names MIGraphX custom ops for
+    it, which this image does not ship -- a hipGraph of the PyTorch-ROCm forward with the HIP ops
+    needs no exporter and no plugin ABI).
+
+    The head runs in ``eval()`` mode under ``torch.inference_mode``: ``Correlation.forward`` then
+    calls the raw op (``correlation.py:78-80``), the warp saves no backward context, nothing is
+    kept for autograd.  ``bidirectional=True`` also captures the 2 -> 1 direction.
+    Call with new pyramids of the captured shapes; returns the static flow lists."""
+
+    def __init__(self, head: torch.nn.Module, pyr1: Sequence[torch.Tensor],
+                 pyr2: Sequence[torch.Tensor], bidirectional: bool = False, warmup: int = 3):
+        if not pyr1[0].is_cuda:
+            raise RuntimeError("GraphedFlowInference needs the pyramids on the GPU (there is no CPU "
+                               "path for the HIP ops)")
+        self.head = head.eval()
+        self.bidirectional = bidirectional
+        self.static1 = [t.detach().clone() for t in pyr1]
+        self.static2 = [t.detach().clone() for t in pyr2]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side), torch.inference_mode():
+            for _ in range(max(1, warmup)):
+                self._forward()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.inference_mode(), torch.cuda.graph(self.graph):
+            self.flows_fw, self.flows_bw = self._forward()
+
+    def _forward(self):
+        fw = self.head((None, self.static1), (None, self.static2))
+        bw = self.head((None, self.static2), (None, self.static1)) if self.bidirectional else []
+        return list(fw), list(bw)
+
+    def __call__(self, pyr1: Sequence[torch.Tensor], pyr2: Sequence[torch.Tensor]):
+        if len(pyr1) != len(self.static1) or len(pyr2) != len(self.static2):
+            raise RuntimeError("GraphedFlowInference: pyramid depth differs from the captured one")
+        with torch.inference_mode():
+            for dst, src in zip(self.static1 + self.static2, list(pyr1) + list(pyr2)):
+                if dst.shape != src.shape:
+                    raise RuntimeError("GraphedFlowInference: shape %s differs from the captured %s"
+                                       % (tuple(src.shape), tuple(dst.shape)))
+                dst.copy_(src)
+        self.graph.replay()
+        return (self.flows_fw, self.flows_bw) if self.bidirectional else self.flows_fw

@@ -163,3 +163,31 @@ def test_head_under_autocast_runs_the_16bit_kernels(golden, dt):
     for t in h1 + h2:
         assert t.grad is not None and t.grad.dtype == dt and torch.isfinite(t.grad.float()).all()
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in head.parameters())
+
+
+def test_graphed_inference_equals_eager_eval():
+    """The captured forward-only (eval, inference_mode) head replays the eager eval forward
+    bit for bit, for the captured inputs and for new ones; wrong shapes are rejected."""
+    from cerberusnet_amd.graphs import GraphedFlowInference
+    det = torch.backends.cudnn.deterministic
+    torch.backends.cudnn.deterministic = True
+    try:
+        torch.manual_seed(5)
+        head = build("FlowEstimatorLite").to(DEV).eval()
+        shapes = [(1, c, 8 * 2 ** l, 16 * 2 ** l) for l, c in enumerate(reversed(CHANS))]
+        mk = lambda: [torch.randn(s, device=DEV) for s in shapes]
+        p1, p2 = mk(), mk()
+        run = GraphedFlowInference(head, p1, p2, bidirectional=True)
+        for trial in range(3):
+            if trial:
+                p1, p2 = mk(), mk()
+            fw, bw = run(p1, p2)
+            got = [f.clone() for f in fw + bw]
+            with torch.inference_mode():
+                want = list(head((None, p1), (None, p2))) + list(head((None, p2), (None, p1)))
+            for a, b in zip(got, want):
+                assert torch.equal(a, b)
+        with pytest.raises(RuntimeError, match="shape"):
+            run([t[:, :1] for t in p1], p2)
+    finally:
+        torch.backends.cudnn.deterministic = det

@@ -10,7 +10,7 @@ import time
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from cerberusnet_amd.graphs import GraphedFlowStep
+from cerberusnet_amd.graphs import GraphedFlowInference, GraphedFlowStep
 from cerberusnet_amd.nnet_models import PWCNetHead
 from cerberusnet_amd.synth import W32_PYRAMID_1024x512, fill_parameters, hash_uniform
 
@@ -55,4 +55,15 @@ for backend in ("hip", "torch"):
             t_graph = timed(lambda: step.graph.replay(), 20)
             row.update(graph_ms=round(t_graph * 1e3, 3), pairs_per_s_graph=round(B / t_graph, 1))
         row["pairs_per_s_eager"] = round(B / t_eager, 1)
+        if backend == "hip":
+            # inference (eval, forward only, one direction): eager vs the captured forward
+            head.eval()
+            def infer():
+                with torch.inference_mode():
+                    head((None, p1), (None, p2))
+            t_inf = timed(infer, 20)
+            run = GraphedFlowInference(head, p1, p2)
+            t_ginf = timed(lambda: run.graph.replay(), 50)
+            row.update(infer_eager_ms=round(t_inf * 1e3, 3), infer_graph_ms=round(t_ginf * 1e3, 3))
+            head.train()
         print(json.dumps(row), flush=True)
