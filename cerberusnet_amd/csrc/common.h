@@ -73,6 +73,7 @@ enum OptId {
     OPT_WARP_TILE_RANGES,
     OPT_WARP_TILE_H,
     OPT_WARP_FORCE_SCATTER,
+    OPT_WARP_STAGED,
 #ifdef CERB_ABLATE
     OPT_DEBUG_ABLATE,   // timing-ablation mask: exists in -DCERB_ABLATE builds only
 #endif
@@ -100,6 +101,19 @@ __device__ __forceinline__ int xcd_chunk(int bid, int nblocks) {
     const int q = nblocks / kXcd, rem = nblocks % kXcd;
     return x * q + min(x, rem) + idx;
 }
+
+#if defined(__HIP_DEVICE_COMPILE__)
+// Buffer resource over [p, p+bytes) with the pointer pinned to SGPRs (64-bit address
+// arithmetic runs on the VALU; a resource left in VGPRs costs a waterfall loop per use).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const void *p, int bytes) {
+    const uint64_t a = reinterpret_cast<uint64_t>(p);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(a));
+    const uint32_t hi = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(a >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<void *>((static_cast<uint64_t>(hi) << 32) | lo), 0,
+        __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+}
+#endif
 
 // ---- launchers implemented in the kernel translation units ------------------
 // all return hipError_t (as int) of the launch, or a negative CERB_E* code.

@@ -456,19 +456,6 @@ struct FwdDmaCfg {
 typedef __attribute__((address_space(3))) void *lds_void_ptr;
 typedef const __attribute__((address_space(1))) void *gbl_void_ptr;
 
-#if defined(__HIP_DEVICE_COMPILE__)
-// Buffer resource over [p, p+bytes) with the pointer pinned to SGPRs (64-bit address
-// arithmetic runs on the VALU; a resource left in VGPRs costs a waterfall loop per use).
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const void *p, int bytes) {
-    const uint64_t a = reinterpret_cast<uint64_t>(p);
-    const uint32_t lo = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(a));
-    const uint32_t hi = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(a >> 32));
-    return __builtin_amdgcn_make_buffer_rsrc(
-        reinterpret_cast<void *>((static_cast<uint64_t>(hi) << 32) | lo), 0,
-        __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
-}
-#endif
-
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }

@@ -144,21 +144,21 @@ __device__ __forceinline__ void load_taps(const T *q, bool ok0, bool ok1, A &v0,
 // by (the tile grown by |flow|) -- 1.1x instead of 2.3x the tile at +-6 px.
 // Saved by the forward (cerberus_flow_warp_forward_ctx) the backward is one launch with no
 // pre-pass; without it the backward first runs warp_context_kernel over the flow.
-//   int4  ext[kCtxPartials]     {dx_lo, dx_hi, dy_lo, dy_hi} per producer workgroup (strips
-//                               j, j+npart, ... fold into partial j); empty: lo > hi.  The first
-//                               min(B*ceil(HW/64), kCtxPartials) slots are written and read
+//   int4  ext[B * strips]       {dx_lo, dx_hi, dy_lo, dy_hi} of every 2 x 32 strip (image-major,
+//                               then row-major over the strips of an image); empty: lo > hi
 //   float pos[B][2][H][W]       sample positions (x plane, y plane)
-constexpr int kCtxPartials = 2048;
 constexpr int kExtEmptyLo = 0x3fffffff, kExtEmptyHi = -0x3fffffff;
+__host__ __device__ inline int64_t ctx_header_bytes(int B, int H, int W) {
+    return static_cast<int64_t>(B) * Strips(H, W).per_image() * 4 * sizeof(int);
+}
 __host__ __device__ inline int64_t ctx_bytes(int B, int H, int W) {
-    return static_cast<int64_t>(kCtxPartials) * 4 * sizeof(int) +
-           static_cast<int64_t>(B) * 2 * H * W * sizeof(float);
+    return ctx_header_bytes(B, H, W) + static_cast<int64_t>(B) * 2 * H * W * sizeof(float);
 }
-__host__ __device__ __forceinline__ float *ctx_pos(void *ctx) {
-    return reinterpret_cast<float *>(static_cast<int *>(ctx) + 4 * kCtxPartials);
+__host__ __device__ __forceinline__ float *ctx_pos(void *ctx, int B, int H, int W) {
+    return reinterpret_cast<float *>(static_cast<char *>(ctx) + ctx_header_bytes(B, H, W));
 }
-__host__ __device__ __forceinline__ const float *ctx_pos(const void *ctx) {
-    return reinterpret_cast<const float *>(static_cast<const int *>(ctx) + 4 * kCtxPartials);
+__host__ __device__ __forceinline__ const float *ctx_pos(const void *ctx, int B, int H, int W) {
+    return reinterpret_cast<const float *>(static_cast<const char *>(ctx) + ctx_header_bytes(B, H, W));
 }
 
 struct TapRange {
@@ -189,8 +189,8 @@ __device__ __forceinline__ int tap_index(float f) {
     return min(max(static_cast<int>(f), -(1 << 24)), 1 << 24);
 }
 
-// Grid: 1-D over the B * ceil(HW/64) pixel strips (grid-stride when a context caps the
-// number of workgroups at kCtxPartials).  T: image / output storage type, F: flow type
+// Grid: 1-D over the B * strips-per-image pixel strips, one per workgroup.  T: image / output
+// storage type, F: flow type
 // (F = float with a 16-bit image keeps full flow precision: the reference's grid_sample runs
 // in fp32 under autocast with whatever precision the flow arrives in).
 template <typename T, typename F, bool PAIR, int kCg>
@@ -235,7 +235,7 @@ __global__ __launch_bounds__(kPix * kCg) void warp_fwd_kernel(
         const bool oky0 = y0 >= 0 && y0 < H, oky1 = y0 + 1 >= 0 && y0 + 1 < H;
         const int64_t o00 = static_cast<int64_t>(y0) * W + x0;
         if (ctx && cg == 0) {
-            float *pos = ctx_pos(ctx) + static_cast<int64_t>(b) * 2 * plane + p;
+            float *pos = ctx_pos(ctx, B, H, W) + static_cast<int64_t>(b) * 2 * plane + p;
             pos[0] = static_cast<float>(cx.pos);
             pos[plane] = static_cast<float>(cy.pos);
             range.add(x, y, x0, y0, W, H);
@@ -267,6 +267,237 @@ __global__ __launch_bounds__(kPix * kCg) void warp_fwd_kernel(
     if (ctx && cg == 0) range.publish(ctx, first, lane);
 }
 
+// ---- forward, LDS-staged window -------------------------------------------------------
+// The direct gather above moves every 128-byte line a wave's taps touch from L2 to the CU
+// (measured at the 32x128x256 level: 0.93 M line reads = 119 MB for a 16.8 MB image, PMC
+// TCC_HIT + TCC_MISS in profiles/r02_pmc_counters.csv) and spends most of its instructions on
+// per-tap address arithmetic and selects.  Here a workgroup owns an 8 x 32 pixel tile (4
+// strips, one per wave) for a range of channels.  It finds the bounding box of the tile's
+// taps (under a smooth flow: the tile shifted by the flow, ~11 x 36), copies that window --
+// plus a one-pixel apron of zeros where it leaves the image -- into LDS with coalesced
+// 16-byte buffer loads whose channel advance is a scalar offset, and takes the four taps of a
+// channel from LDS with two ds_read2.  Same arithmetic in the same order as warp_fwd_kernel:
+// results are bit-identical.
+// A window that does not fit kStageCap floats x the channel count is walked in smaller
+// channel groups; one that does not fit for a single channel (a diverged flow) falls back to
+// the direct gather for that workgroup.
+[[maybe_unused]] constexpr int kStageCap = 8192;   // floats of LDS window per workgroup
+[[maybe_unused]] constexpr int kStageMaxArea = 4096;   // largest window of ONE channel (1024 16-byte cells)
+constexpr int kStageRows = 4;     // strips (waves) per workgroup, stacked vertically
+[[maybe_unused]] constexpr int kDeadOffset = static_cast<int>(0x80000000u);   // buffer offset that reads 0 / drops a store
+
+// Wave-wide min / max through DPP row shifts and row broadcasts: 6 VALU instructions and no
+// LDS crossbar traffic (__shfl_xor is a ds_bpermute_b32 each); the result is wave-uniform.
+template <bool MAX> __device__ __forceinline__ int wave_minmax(int v) {
+#define CERB_DPP_STEP(ctrl, rows)                                                     \
+    {                                                                                 \
+        const int o = __builtin_amdgcn_update_dpp(v, v, ctrl, rows, 0xf, false);      \
+        v = MAX ? max(v, o) : min(v, o);                                              \
+    }
+    CERB_DPP_STEP(0x111, 0xf)   // row_shr:1
+    CERB_DPP_STEP(0x112, 0xf)   // row_shr:2
+    CERB_DPP_STEP(0x114, 0xf)   // row_shr:4
+    CERB_DPP_STEP(0x118, 0xf)   // row_shr:8  -> lane 15 of every row holds the row's result
+    CERB_DPP_STEP(0x142, 0xa)   // row_bcast:15 into rows 1 and 3
+    CERB_DPP_STEP(0x143, 0xc)   // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave's
+#undef CERB_DPP_STEP
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
+// 4 consecutive pixels of storage type T through a buffer resource, widened to fp32
+template <typename T>
+__device__ __forceinline__ float4 buffer_load_px4(__amdgpu_buffer_rsrc_t rsrc, int voff, int soff) {
+    typedef unsigned u4v __attribute__((ext_vector_type(4)));
+    typedef unsigned u2v __attribute__((ext_vector_type(2)));
+    if constexpr (sizeof(T) == 4) {
+        const u4v r = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0);
+        return make_float4(__uint_as_float(r.x), __uint_as_float(r.y), __uint_as_float(r.z),
+                           __uint_as_float(r.w));
+    } else {
+        const u2v r = __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff, soff, 0);
+        return make_float4(widen16<T>(r.x & 0xFFFFu), widen16<T>(r.x >> 16),
+                           widen16<T>(r.y & 0xFFFFu), widen16<T>(r.y >> 16));
+    }
+}
+template <typename T>
+__device__ __forceinline__ void buffer_store_px(__amdgpu_buffer_rsrc_t rsrc, int voff, int soff, float v) {
+    if constexpr (sizeof(T) == 4) {
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsrc, voff, soff, 0);
+    } else {
+        T t;
+        st(&t, v);
+        unsigned short bits;
+        __builtin_memcpy(&bits, &t, 2);
+        __builtin_amdgcn_raw_buffer_store_b16(bits, rsrc, voff, soff, 0);
+    }
+}
+
+template <typename T, typename F>
+__global__ __launch_bounds__(256) void warp_fwd_staged_kernel(
+    const T *__restrict__ image, const F *__restrict__ flow, T *__restrict__ out,
+    void *__restrict__ ctx, int B, int C, int H, int W, int pad_mode, int crange, int nrange) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __shared__ __attribute__((aligned(16))) float win[kStageCap];
+    __shared__ int4 boxes[kStageRows];
+    constexpr int esz = sizeof(T);
+    const int plane = H * W;   // the launcher guarantees C * plane * esz < 2^31
+    const int tid = threadIdx.x;
+    const int lane = tid & (kPix - 1), wave = __builtin_amdgcn_readfirstlane(tid / kPix);
+    const Strips strips(H, W);
+    const int tyn = (strips.ny + kStageRows - 1) / kStageRows;
+    int id = xcd_chunk(blockIdx.x, gridDim.x);
+    const int r = __builtin_amdgcn_readfirstlane(id % nrange); id /= nrange;
+    const int tx = __builtin_amdgcn_readfirstlane(id % strips.nx); id /= strips.nx;
+    const int ty = __builtin_amdgcn_readfirstlane(id % tyn);
+    const int b = __builtin_amdgcn_readfirstlane(id / tyn);
+    const int jy = ty * kStageRows + wave;
+    int x = 0, y = 0;
+    const bool live = jy < strips.ny && strips.pixel(jy * strips.nx + tx, lane, H, W, x, y);
+    const int p = y * W + x;
+    float wnw = 0.f, wne = 0.f, wsw = 0.f, wse = 0.f;
+    int x0 = -2, y0 = -2;   // a lane outside the image has no in-image tap
+    TapRange range;
+    if (live) {
+        const F *fl = flow + static_cast<int64_t>(b) * 2 * plane + p;
+        const Coord<float> cx = source_coord<float>(x, static_cast<float>(ld(fl)), W, pad_mode);
+        const Coord<float> cy = source_coord<float>(y, static_cast<float>(ld(fl + plane)), H, pad_mode);
+        const float x0f = floorf(cx.pos), y0f = floorf(cy.pos);
+        const float x1f = x0f + 1.f, y1f = y0f + 1.f;
+        wnw = (x1f - cx.pos) * (y1f - cy.pos);
+        wne = (cx.pos - x0f) * (y1f - cy.pos);
+        wsw = (x1f - cx.pos) * (cy.pos - y0f);
+        wse = (cx.pos - x0f) * (cy.pos - y0f);
+        x0 = tap_index(x0f); y0 = tap_index(y0f);
+        if (ctx && r == 0) {
+            float *pos = ctx_pos(ctx, B, H, W) + static_cast<int64_t>(b) * 2 * plane + p;
+            pos[0] = cx.pos;
+            pos[plane] = cy.pos;
+            range.add(x, y, x0, y0, W, H);
+        }
+    }
+    if (ctx && r == 0 && jy < strips.ny) {
+        const int xl = wave_minmax<false>(range.xlo), xh = wave_minmax<true>(range.xhi);
+        const int yl = wave_minmax<false>(range.ylo), yh = wave_minmax<true>(range.yhi);
+        if (lane == 0)
+            static_cast<int4 *>(ctx)[b * strips.per_image() + jy * strips.nx + tx] = make_int4(xl, xh, yl, yh);
+    }
+    // A lane is dead when no tap of it is inside the image (its output is the same sum of
+    // zero products for every channel); the others have x0 in [-1, W-1], y0 in [-1, H-1].
+    const bool dead = !(x0 >= -1 && x0 <= W - 1 && y0 >= -1 && y0 <= H - 1);
+    const float zsum = [&] { float a = 0.f * wnw; a += 0.f * wne; a += 0.f * wsw; a += 0.f * wse; return a; }();
+    // bounding box of the taps, apron included, over the workgroup
+    int bxl = wave_minmax<false>(dead ? kExtEmptyLo : x0), bxh = wave_minmax<true>(dead ? kExtEmptyHi : x0 + 1);
+    int byl = wave_minmax<false>(dead ? kExtEmptyLo : y0), byh = wave_minmax<true>(dead ? kExtEmptyHi : y0 + 1);
+    if (lane == 0) boxes[wave] = make_int4(bxl, bxh, byl, byh);
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kStageRows; ++k) {
+        const int4 e = boxes[k];
+        bxl = min(bxl, e.x); bxh = max(bxh, e.y); byl = min(byl, e.z); byh = max(byh, e.w);
+    }
+    bxl = __builtin_amdgcn_readfirstlane(bxl); bxh = __builtin_amdgcn_readfirstlane(bxh);
+    byl = __builtin_amdgcn_readfirstlane(byl); byh = __builtin_amdgcn_readfirstlane(byh);
+
+    const int c_begin = r * crange, c_end = min(C, c_begin + crange);
+    const T *img = image + static_cast<int64_t>(b) * C * plane;
+    const __amdgpu_buffer_rsrc_t rsrc_img = uniform_rsrc(img, C * plane * esz);
+    const __amdgpu_buffer_rsrc_t rsrc_out =
+        uniform_rsrc(out + static_cast<int64_t>(b) * C * plane, C * plane * esz);
+    const int out_voff = live ? p * esz : kDeadOffset;
+    if (bxl > bxh) {   // no tap of the tile is inside the image
+        for (int c = c_begin; c < c_end; ++c) buffer_store_px<T>(rsrc_out, out_voff, c * plane * esz, zsum);
+        return;
+    }
+    // window: columns from a multiple of 4 (16-byte loads), pitch a multiple of 4
+    const int wx0 = bxl & ~3, wy0 = byl;
+    const int pitch = (bxh - wx0 + 4) & ~3, rows = byh - byl + 1;
+    const int64_t area64 = static_cast<int64_t>(pitch) * rows;
+    if (area64 > kStageMaxArea) {
+        // diverged flow: direct gather, four channels in flight
+        if (!live) return;
+        const bool okx0 = x0 >= 0 && x0 < W, okx1 = x0 + 1 >= 0 && x0 + 1 < W;
+        const bool oky0 = y0 >= 0 && y0 < H, oky1 = y0 + 1 >= 0 && y0 + 1 < H;
+        const int64_t o00 = static_cast<int64_t>(y0) * W + x0;
+        T *dst = out + static_cast<int64_t>(b) * C * plane + p;
+        for (int c = c_begin; c < c_end; c += 4) {
+            float v[4][4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const T *q = img + static_cast<int64_t>(min(c + u, c_end - 1)) * plane + o00;
+                load_taps<true, T, float>(q, oky0 && okx0, oky0 && okx1, v[u][0], v[u][1]);
+                load_taps<true, T, float>(q + W, oky1 && okx0, oky1 && okx1, v[u][2], v[u][3]);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (c + u >= c_end) break;
+                float acc = v[u][0] * wnw;
+                acc += v[u][1] * wne;
+                acc += v[u][2] * wsw;
+                acc += v[u][3] * wse;
+                st(dst + static_cast<int64_t>(c + u) * plane, acc);
+            }
+        }
+        return;
+    }
+    const int area = static_cast<int>(area64);
+    const int cch = min(crange, kStageCap / area);
+    // The 16-byte cells of one channel's window this thread copies: cell = tid + 256 j (a
+    // smooth flow has ~100 cells: one per thread of the first two waves).  Cell -> (row,
+    // column) once; the channel is the scalar offset of the load.  it / d for it < 1024,
+    // d <= 1024 as (it * ceil(2^20 / d)) >> 20: exact.
+    const int p4 = pitch >> 2, cells = rows * p4;
+    const int ncell = (cells + 255) >> 8;   // <= 4
+    const unsigned m_row = static_cast<unsigned>(ceilf(1048576.f / static_cast<float>(p4)));
+    int cell_voff[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int cell = tid + 256 * j;
+        const int row = static_cast<int>((cell * m_row) >> 20), q = cell - row * p4;
+        const int gx = wx0 + 4 * q, gy = wy0 + row;
+        cell_voff[j] = (cell < cells && gx >= 0 && gx < W && gy >= 0 && gy < H) ? (gy * W + gx) * esz
+                                                                                 : kDeadOffset;
+    }
+    const bool mine = tid < cells;
+    const float *tap = win + (dead ? 0 : (y0 - wy0) * pitch + (x0 - wx0));
+    for (int c = c_begin; c < c_end; c += cch) {
+        const int n = min(cch, c_end - c);
+        if (c != c_begin) __syncthreads();   // the previous group's taps have been read
+        if (ncell == 1) {
+            // eight channels' loads in flight per thread, all issued before the first LDS store
+            for (int h = 0; h < n; h += 8) {
+                float4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    v[u] = buffer_load_px4<T>(rsrc_img, h + u < n ? cell_voff[0] : kDeadOffset,
+                                              (c + min(h + u, n - 1)) * plane * esz);
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (mine && h + u < n) *reinterpret_cast<float4 *>(win + (h + u) * area + 4 * tid) = v[u];
+            }
+        } else {
+            for (int h = 0; h < n; ++h) {
+                float4 v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = buffer_load_px4<T>(rsrc_img, cell_voff[j], (c + h) * plane * esz);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (tid + 256 * j < cells) *reinterpret_cast<float4 *>(win + h * area + 4 * (tid + 256 * j)) = v[j];
+            }
+        }
+        __syncthreads();
+        for (int h = 0; h < n; ++h) {
+            const float *wc = tap + h * area;
+            const float v0 = wc[0], v1 = wc[1], v2 = wc[pitch], v3 = wc[pitch + 1];
+            float acc = v0 * wnw;
+            acc += v1 * wne;
+            acc += v2 * wsw;
+            acc += v3 * wse;
+            buffer_store_px<T>(rsrc_out, out_voff, (c + h) * plane * esz, dead ? zsum : acc);
+        }
+    }
+#endif
+}
+
 // Context from the flow alone (backward called without a forward context): same strip ->
 // workgroup mapping as the forward, one wavefront per workgroup.
 template <typename F>
@@ -288,7 +519,7 @@ __global__ __launch_bounds__(kPix) void warp_context_kernel(const F *__restrict_
         const F *fl = flow + static_cast<int64_t>(b) * 2 * plane + p;
         const Coord<float> cx = source_coord<float>(x, static_cast<float>(ld(fl)), W, pad_mode);
         const Coord<float> cy = source_coord<float>(y, static_cast<float>(ld(fl + plane)), H, pad_mode);
-        float *pos = ctx_pos(ctx) + static_cast<int64_t>(b) * 2 * plane + p;
+        float *pos = ctx_pos(ctx, B, H, W) + static_cast<int64_t>(b) * 2 * plane + p;
         pos[0] = cx.pos;
         pos[plane] = cy.pos;
         range.add(x, y, tap_index(floorf(cx.pos)), tap_index(floorf(cy.pos)), W, H);
@@ -469,7 +700,7 @@ template <int TH> struct TileGeom {
 template <typename T, typename F, int TH, int CW, int NS>
 __global__ __launch_bounds__(256, 4) void warp_bwd_tile_kernel(
     const T *__restrict__ image, const T *__restrict__ gout, const void *__restrict__ ctx,
-    int npart, T *__restrict__ gimage, F *__restrict__ gflow, int B, int C, int H, int W,
+    T *__restrict__ gimage, F *__restrict__ gflow, int B, int C, int H, int W,
     int tiles_x, int tiles_y, int nrange, int crange, int ntile_blocks, int pad_mode) {
     constexpr int TW = kTileW, PW = TileGeom<TH>::PW, PS = TileGeom<TH>::PS;
     constexpr int NP = CW / 2;                       // channel pairs = planes of 64-bit slots
@@ -491,7 +722,7 @@ __global__ __launch_bounds__(256, 4) void warp_bwd_tile_kernel(
         const bool live = strips.pixel(strip % spp, lane, H, W, x, y);
         const int p = y * W + x;
         const int pc = live ? p : 0;
-        const float *pos = ctx_pos(ctx) + static_cast<int64_t>(b) * 2 * plane;
+        const float *pos = ctx_pos(ctx, B, H, W) + static_cast<int64_t>(b) * 2 * plane;
         const float ixp = pos[pc], iyp = pos[plane + pc];
         const float x0f = floorf(ixp), y0f = floorf(iyp);
         const float x1f = x0f + 1.f, y1f = y0f + 1.f;
@@ -556,7 +787,7 @@ __global__ __launch_bounds__(256, 4) void warp_bwd_tile_kernel(
     const int tx0 = tx * TW, ty0 = ty * TH;
     const int tx1 = min(tx0 + TW, W) - 1, ty1 = min(ty0 + TH, H) - 1;   // last pixel of the tile
     const int c_begin = range * crange, c_end = min(C, c_begin + crange);
-    const float *pos = ctx_pos(ctx) + static_cast<int64_t>(b) * 2 * plane;
+    const float *pos = ctx_pos(ctx, B, H, W) + static_cast<int64_t>(b) * 2 * plane;
     (void)nrange;
 
     CERB_STAMP_AT(0);
@@ -575,10 +806,9 @@ __global__ __launch_bounds__(256, 4) void warp_bwd_tile_kernel(
         // strip j = tid + 256 k as (jy, jx), advanced without divisions in the loop
         int jy = tid / strips.nx, jx = tid % strips.nx;
         const int qy = 256 / strips.nx, qx = 256 % strips.nx;
-        const bool folded = static_cast<int64_t>(B) * spp > npart;   // strips share partials
         for (int j = tid; j < spp; j += 256) {
             const int slot = b * spp + j;
-            const int4 e = ext[folded ? slot % npart : slot];
+            const int4 e = ext[slot];
             const int sy0 = jy * kStripH, sy1 = min(sy0 + kStripH, H) - 1;
             const int sx0 = jx * kStripW, sx1 = min(sx0 + kStripW, W) - 1;
             const bool hit = e.x <= e.y && sx0 + e.x <= tx1 && sx1 + e.y >= tx0 &&
@@ -972,10 +1202,9 @@ extern "C" int cerberus_debug_stamps(void *dst, int bytes) {
 }
 #endif
 
-// number of extent partials a context of this shape holds (= workgroups of its producer)
+// strips (= tap-range slots of a context) of this shape
 static int ctx_partials(int B, int H, int W) {
-    const int64_t nstrips = static_cast<int64_t>(B) * Strips(H, W).per_image();
-    return static_cast<int>(std::min<int64_t>(nstrips, kCtxPartials));
+    return static_cast<int>(static_cast<int64_t>(B) * Strips(H, W).per_image());
 }
 
 // workspace of the tiled backward: 16 reserved bytes + room for a context in case the caller
@@ -998,9 +1227,35 @@ int warp_forward(const void *image, const void *flow, void *out, void *ctx, int6
         return CERB_EINVAL;
     const int64_t nstrips = static_cast<int64_t>(B) * Strips(H, W).per_image();
     if (nstrips > 0x7fffffff) return CERB_ETOOLARGE;
-    // with a context the grid is capped: one extent partial per workgroup (ctx_partials of them)
-    const unsigned blocks = static_cast<unsigned>(ctx ? ctx_partials(B, H, W) : nstrips);
-    const dim3 grid(blocks);
+    const int staged_opt = option(OPT_WARP_STAGED);
+    // LDS-staged window: bilinear, 16-byte-aligned rows, 32-bit byte offsets.  Channels per
+    // workgroup: as few as keep the launch at <= 1024 workgroups (the per-workgroup box
+    // reduction and window set-up amortise over the channels), between 8 and 32.  Measured, 4
+    // pairs, smooth flow, fwd + context, us direct / staged: 64x64x128 9.4 / 8.6, 32x128x256
+    // 14.8 / 13.5, 64x128x256 23.8 / 21.2, 32x256x512 44.6 / 37.6 in fp32 and 12.9 / 8.3,
+    // 15.5 / 12.0, 28.6 / 19.3, 50.1 / 34.4 in fp16.
+    const bool staged = interp == CERB_INTERP_BILINEAR && dtype != CERB_F64 && W % 4 == 0 &&
+                        (reinterpret_cast<uintptr_t>(image) & 15) == 0 && staged_opt != 2 &&
+                        static_cast<int64_t>(C) * H * W * 4 < 0x7fffffff;
+    if (staged) {
+        const Strips strips(H, W);
+        const int64_t tiles = static_cast<int64_t>(B) * ((strips.ny + kStageRows - 1) / kStageRows) * strips.nx;
+        int crange = 8;
+        while (crange < 32 && tiles * ((C + crange - 1) / crange) > 1024) crange *= 2;
+        if (staged_opt >= 4) crange = staged_opt;
+        crange = std::max(1, std::min(C, crange));
+        const int nrange = (C + crange - 1) / crange;
+        const int64_t blocks = static_cast<int64_t>(B) * ((strips.ny + kStageRows - 1) / kStageRows) *
+                               strips.nx * nrange;
+        if (blocks > 0x7fffffff) return CERB_ETOOLARGE;
+        CERB_DISPATCH2(dtype, flow_dtype, if constexpr (!std::is_same<T, double>::value)
+            hipLaunchKernelGGL((warp_fwd_staged_kernel<T, F>), dim3(static_cast<unsigned>(blocks)),
+                               dim3(256), 0, s, static_cast<const T *>(image),
+                               static_cast<const F *>(flow), static_cast<T *>(out), ctx, B, C, H, W,
+                               pad_mode, crange, nrange))
+        return launch_status();
+    }
+    const dim3 grid(static_cast<unsigned>(nstrips));
     if (option(OPT_WARP_PAIR_TAPS) != 2) {  // default: paired taps in the forward gather
         CERB_PICK_CG(C, CERB_DISPATCH2(dtype, flow_dtype, hipLaunchKernelGGL(
             (warp_fwd_kernel<T, F, true, CG>), grid, dim3(kPix * CG), 0, s,
@@ -1036,7 +1291,7 @@ static int launch_tiles(const void *image, const void *gout, const void *ctx, vo
     hipLaunchKernelGGL((warp_bwd_tile_kernel<T, F, TH, CW, NS>),
                        dim3(static_cast<unsigned>(tile_blocks + flow_blocks)), dim3(256), 0, s,
                        static_cast<const T *>(image), static_cast<const T *>(gout), ctx,
-                       ctx_partials(B, H, W), static_cast<T *>(gimage), static_cast<F *>(gflow), B,
+                       static_cast<T *>(gimage), static_cast<F *>(gflow), B,
                        C, H, W, tiles_x, tiles_y, nrange, crange, static_cast<int>(tile_blocks),
                        pad_mode);
     return launch_status();

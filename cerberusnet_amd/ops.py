@@ -236,7 +236,9 @@ def _flow_for(img, flow):
     return flow.to(dtype=img.dtype).contiguous()
 
 
-_CTX_HEADER_BYTES = 2048 * 16   # warp.hip: kCtxPartials x int4 tap ranges
+def _ctx_header_bytes(B, H, W):
+    """warp.hip ctx_header_bytes: one int4 tap range per 2 x 32 pixel strip."""
+    return B * ((H + 1) // 2) * ((W + 31) // 32) * 16
 
 
 def _flow_warp_run(image, flow, pad_mode, interp_mode, want_ctx, what):
@@ -273,7 +275,7 @@ def _flow_warp_ctx_cuda(image, flow, pad_mode, interp_mode):
 
 def _flow_warp_ctx_meta(image, flow, pad_mode, interp_mode):
     B, _, H, W = image.shape
-    n = (_CTX_HEADER_BYTES + B * 2 * H * W * 4 + 7) // 8
+    n = (_ctx_header_bytes(B, H, W) + B * 2 * H * W * 4 + 7) // 8
     return torch.empty_like(image), image.new_empty((n,), dtype=torch.int64)
 
 

@@ -184,6 +184,10 @@ int cerberus_flow_upsample_backward(const void *grad_out, void *grad_in, int64_t
  *   "warp_tile_ranges"   : channel ranges per warp-backward tile (0 auto)
  *   "warp_tile_h"        : rows per warp-backward tile (0 auto, 8, 16)
  *   "warp_force_scatter" : 1 = warp backward by global atomics even when a context exists
+ *   "warp_staged"        : 0 = auto (the forward gather goes through an LDS copy of the source
+ *                          window on large maps with 16-byte aligned rows), 2 = always gather
+ *                          from global memory, >= 4 = always staged where possible, with that
+ *                          many channels per workgroup
  * Returns CERB_EINVAL for an unknown key. */
 int cerberus_set_option(const char *key, int value);
 int cerberus_get_option(const char *key, int *value);

@@ -55,8 +55,8 @@ def test_argument_rejection_without_gpu():
                                             None) == -1
     assert lib.cerberus_flow_warp_forward(None, None, None, 1, 4, 8, 8, 7, 0, 0, None) == -4
     assert lib.cerberus_flow_warp_forward(None, None, None, 0, 4, 8, 8, 1, 0, 0, None) == 0
-    assert lib.cerberus_flow_warp_context_bytes(2, 8, 16) == 2048 * 16 + 2 * 2 * 8 * 16 * 4
-    assert lib.cerberus_flow_warp_backward_workspace_bytes(2, 6, 8, 16) == 16 + (2048 * 16 + 2 * 2 * 8 * 16 * 4)
+    assert lib.cerberus_flow_warp_context_bytes(2, 8, 16) == 2 * 4 * 1 * 16 + 2 * 2 * 8 * 16 * 4
+    assert lib.cerberus_flow_warp_backward_workspace_bytes(2, 6, 8, 16) == 16 + (2 * 4 * 1 * 16 + 2 * 2 * 8 * 16 * 4)
     assert b"stride1" in lib.cerberus_error_string(-3)
     assert lib.cerberus_set_option(b"no_such_key", 1) == -1
 
@@ -133,7 +133,7 @@ def test_warp_context_ops_are_registered_and_fail_loudly_on_cpu():
                                                   torch.zeros(16, dtype=torch.int64),
                                                   xc.detach(), 1, 0, True, True)
     # context / workspace sizes grow with the shape and never go negative
-    assert lib.cerberus_flow_warp_context_bytes(0, 8, 8) == 2048 * 16
+    assert lib.cerberus_flow_warp_context_bytes(0, 8, 8) == 0
     assert lib.cerberus_flow_warp_context_bytes(-1, 8, 8) == 0
     assert (lib.cerberus_flow_warp_backward_workspace_bytes(4, 32, 128, 256)
             == 16 + lib.cerberus_flow_warp_context_bytes(4, 128, 256))

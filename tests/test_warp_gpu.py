@@ -239,9 +239,8 @@ def test_tiled_grad_image_fixed_point_is_scale_free_and_deterministic(mag):
     assert torch.equal(c, a * 8.0)
 
 
-def test_backward_with_more_strips_than_context_partials():
-    """More than 2048 64-pixel strips: the forward folds several strips into one extent
-    partial (grid-stride); the tile kernel's reach test must stay conservative."""
+def test_backward_with_a_fast_object_on_a_large_map():
+    """One fast object on an otherwise smooth flow: only the tiles it feeds scan wide."""
     shape = (1, 4, 300, 520)     # 2438 strips; W not a multiple of 64: strips straddle rows
     img, go = dev(hash_uniform(shape, 71)), dev(hash_uniform(shape, 73))
     flo = hash_uniform((1, 2, 300, 520), 72, -3.0, 3.0)
@@ -255,6 +254,43 @@ def test_backward_with_more_strips_than_context_partials():
     assert rel_err(out.cpu().numpy(), ref.numpy()) < TOL
     assert rel_err(gi.cpu().numpy(), rgi.numpy()) < TOL
     assert rel_err(gf.cpu().numpy(), rgf.numpy()) < TOL
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.float16, torch.bfloat16])
+def test_lds_staged_gather_equals_the_direct_gather_bit_for_bit(dt):
+    """The forward takes its taps from an LDS copy of the tile's source window (one coalesced
+    pass over the window instead of a line-granular gather); same arithmetic in the same order,
+    so every output bit and the whole context must equal the direct-gather kernel's -- for
+    smooth flows (window fits), windows that only fit for a few channels at a time, diverged
+    flows (direct-gather fallback inside the staged kernel), taps off every border, ragged
+    tiles, non-finite flow values, and channel counts that are not a multiple of the
+    workgroup's channel range."""
+    from cerberusnet_amd import _lib
+    cases = [((2, 19, 37, 132), 0.7), ((1, 8, 64, 128), 6.0), ((2, 5, 24, 64), 30.0),
+             ((1, 33, 16, 32), 300.0), ((1, 3, 2, 4), 1.0), ((1, 9, 130, 260), 14.0)]
+    for k, (shape, amp) in enumerate(cases):
+        B, C, H, W = shape
+        img = dev(hash_uniform(shape, 600 + k)).to(dt)
+        flo = hash_uniform((B, 2, H, W), 700 + k, -amp, amp)
+        flo[0, 0, H // 2, W // 2] = np.nan
+        flo[0, 1, 0, W - 1] = np.inf
+        flo[-1, 0, H - 1, 0] = -np.inf
+        flo = dev(flo)
+        for pad in (0, 1):
+            for crange in (0, 4, 16, 32):
+                _lib.set_option("warp_staged", crange)
+                try:
+                    out, ctx = torch.ops.cerberus.flow_warp_ctx(img, flo, pad, 0)
+                    plain = torch.ops.cerberus.flow_warp(img, flo, pad, 0)
+                    _lib.set_option("warp_staged", 2)
+                    out0, ctx0 = torch.ops.cerberus.flow_warp_ctx(img, flo, pad, 0)
+                finally:
+                    _lib.set_option("warp_staged", 0)
+                assert torch.equal(out.view(torch.int16 if dt != torch.float32 else torch.int32),
+                                   out0.view(torch.int16 if dt != torch.float32 else torch.int32)), (shape, amp, pad, crange)
+                assert torch.equal(plain.view(torch.int16 if dt != torch.float32 else torch.int32),
+                                   out0.view(torch.int16 if dt != torch.float32 else torch.int32))
+                assert torch.equal(ctx, ctx0), (shape, amp, pad, crange)
 
 
 def test_seeded_random_shape_sweep_against_the_oracle():
