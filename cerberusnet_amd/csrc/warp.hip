@@ -320,6 +320,13 @@ __device__ __forceinline__ float4 buffer_load_px4(__amdgpu_buffer_rsrc_t rsrc, i
     }
 }
 template <typename T>
+__device__ __forceinline__ float buffer_load_px1(__amdgpu_buffer_rsrc_t rsrc, int voff, int soff) {
+    if constexpr (sizeof(T) == 4)
+        return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, soff, 0));
+    else
+        return widen16<T>(__builtin_amdgcn_raw_buffer_load_b16(rsrc, voff, soff, 0));
+}
+template <typename T>
 __device__ __forceinline__ void buffer_store_px(__amdgpu_buffer_rsrc_t rsrc, int voff, int soff, float v) {
     if constexpr (sizeof(T) == 4) {
         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsrc, voff, soff, 0);
@@ -332,13 +339,108 @@ __device__ __forceinline__ void buffer_store_px(__amdgpu_buffer_rsrc_t rsrc, int
     }
 }
 
+// The LDS window of a workgroup: the bounding box of its lanes' taps (a one-pixel apron of
+// zeros included where a tap leaves the image), and this thread's share of copying it.
+struct StageWindow {
+    int wx0, wy0, pitch, rows, area;   // uniform; columns start at a multiple of 4, pitch % 4 == 0
+    bool empty;                        // no tap of the workgroup is inside the image
+    int ncell;                         // 16-byte cells of one channel's window / 256, rounded up
+    int grp, ngrp;                     // ncell == 1: this thread copies channels grp, grp + ngrp, ...
+    int voff[4], slot[4];              // per owned cell: byte offset in channel 0 (or dead), float slot (or -1)
+
+    // (x0, y0): the lane's north-west tap; dead: no tap of the lane is inside the image.
+    // One barrier; boxes: one int4 per wave.
+    __device__ __forceinline__ void reduce(bool dead, int x0, int y0, int4 *boxes, int wave, int lane) {
+        int xl = wave_minmax<false>(dead ? kExtEmptyLo : x0), xh = wave_minmax<true>(dead ? kExtEmptyHi : x0 + 1);
+        int yl = wave_minmax<false>(dead ? kExtEmptyLo : y0), yh = wave_minmax<true>(dead ? kExtEmptyHi : y0 + 1);
+        if (lane == 0) boxes[wave] = make_int4(xl, xh, yl, yh);
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int4 e = boxes[k];
+            xl = min(xl, e.x); xh = max(xh, e.y); yl = min(yl, e.z); yh = max(yh, e.w);
+        }
+        xl = __builtin_amdgcn_readfirstlane(xl); xh = __builtin_amdgcn_readfirstlane(xh);
+        yl = __builtin_amdgcn_readfirstlane(yl); yh = __builtin_amdgcn_readfirstlane(yh);
+        empty = xl > xh;
+        wx0 = empty ? 0 : xl & ~3;
+        wy0 = empty ? 0 : yl;
+        pitch = empty ? 4 : (xh - wx0 + 4) & ~3;
+        rows = empty ? 1 : yh - yl + 1;
+        const int64_t a = static_cast<int64_t>(pitch) * rows;
+        area = a > kStageMaxArea ? kStageMaxArea + 1 : static_cast<int>(a);   // "does not fit"
+    }
+    __device__ __forceinline__ bool fits() const { return area <= kStageMaxArea; }
+
+    // Cell -> (row, column) once per thread; the channel is added to the byte offset per load.
+    // cell / p4 for cell < 1024, p4 <= 1024 as (cell * ceil(2^20 / p4)) >> 20: exact.
+    __device__ __forceinline__ void map_cells(int tid, int H, int W, int esz) {
+        const int p4 = pitch >> 2, cells = rows * p4;
+        const unsigned m_row = static_cast<unsigned>(ceilf(1048576.f / static_cast<float>(p4)));
+        auto place = [&](int j, int cell) {
+            const int row = static_cast<int>((cell * m_row) >> 20), q = cell - row * p4;
+            const int gx = wx0 + 4 * q, gy = wy0 + row;
+            const bool in = !empty && cell < cells && gx >= 0 && gx < W && gy >= 0 && gy < H;
+            voff[j] = in ? (gy * W + gx) * esz : kDeadOffset;
+            slot[j] = cell < cells ? 4 * cell : -1;
+        };
+        if (cells <= 256) {
+            // fewer cells than threads: 256 >> shift thread groups take every ngrp-th channel
+            const int shift = cells <= 1 ? 0 : 32 - __builtin_clz(cells - 1);
+            ncell = 1;
+            grp = tid >> shift;
+            ngrp = 256 >> shift;
+            place(0, tid & ((1 << shift) - 1));
+#pragma unroll
+            for (int j = 1; j < 4; ++j) { voff[j] = kDeadOffset; slot[j] = -1; }
+        } else {
+            ncell = (cells + 255) >> 8;
+            grp = 0;
+            ngrp = 1;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) place(j, tid + 256 * j);
+        }
+    }
+
+    // Copy channels [c, c + n) into win[n][rows][pitch]: eight loads in flight per thread, all
+    // issued before the first LDS store.  The caller brackets this with barriers.
+    template <typename T>
+    __device__ __forceinline__ void stage(float *win, __amdgpu_buffer_rsrc_t rsrc, int c, int n, int plane) const {
+        constexpr int esz = sizeof(T);
+        if (ncell == 1) {
+            for (int h0 = 0; h0 < n; h0 += 8 * ngrp) {
+                float4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int h = h0 + grp + ngrp * u;
+                    v[u] = buffer_load_px4<T>(rsrc, h < n ? voff[0] + (c + h) * plane * esz : kDeadOffset, 0);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int h = h0 + grp + ngrp * u;
+                    if (slot[0] >= 0 && h < n) *reinterpret_cast<float4 *>(win + h * area + slot[0]) = v[u];
+                }
+            }
+        } else {
+            for (int h = 0; h < n; ++h) {
+                float4 v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = buffer_load_px4<T>(rsrc, voff[j], (c + h) * plane * esz);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (slot[j] >= 0) *reinterpret_cast<float4 *>(win + h * area + slot[j]) = v[j];
+            }
+        }
+    }
+};
+
 template <typename T, typename F>
 __global__ __launch_bounds__(256) void warp_fwd_staged_kernel(
     const T *__restrict__ image, const F *__restrict__ flow, T *__restrict__ out,
     void *__restrict__ ctx, int B, int C, int H, int W, int pad_mode, int crange, int nrange) {
 #if defined(__HIP_DEVICE_COMPILE__)
     __shared__ __attribute__((aligned(16))) float win[kStageCap];
-    __shared__ int4 boxes[kStageRows];
+    __shared__ int4 boxes[4];
     constexpr int esz = sizeof(T);
     const int plane = H * W;   // the launcher guarantees C * plane * esz < 2^31
     const int tid = threadIdx.x;
@@ -385,18 +487,8 @@ __global__ __launch_bounds__(256) void warp_fwd_staged_kernel(
     // zero products for every channel); the others have x0 in [-1, W-1], y0 in [-1, H-1].
     const bool dead = !(x0 >= -1 && x0 <= W - 1 && y0 >= -1 && y0 <= H - 1);
     const float zsum = [&] { float a = 0.f * wnw; a += 0.f * wne; a += 0.f * wsw; a += 0.f * wse; return a; }();
-    // bounding box of the taps, apron included, over the workgroup
-    int bxl = wave_minmax<false>(dead ? kExtEmptyLo : x0), bxh = wave_minmax<true>(dead ? kExtEmptyHi : x0 + 1);
-    int byl = wave_minmax<false>(dead ? kExtEmptyLo : y0), byh = wave_minmax<true>(dead ? kExtEmptyHi : y0 + 1);
-    if (lane == 0) boxes[wave] = make_int4(bxl, bxh, byl, byh);
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < kStageRows; ++k) {
-        const int4 e = boxes[k];
-        bxl = min(bxl, e.x); bxh = max(bxh, e.y); byl = min(byl, e.z); byh = max(byh, e.w);
-    }
-    bxl = __builtin_amdgcn_readfirstlane(bxl); bxh = __builtin_amdgcn_readfirstlane(bxh);
-    byl = __builtin_amdgcn_readfirstlane(byl); byh = __builtin_amdgcn_readfirstlane(byh);
+    StageWindow w;
+    w.reduce(dead, x0, y0, boxes, wave, lane);
 
     const int c_begin = r * crange, c_end = min(C, c_begin + crange);
     const T *img = image + static_cast<int64_t>(b) * C * plane;
@@ -404,15 +496,11 @@ __global__ __launch_bounds__(256) void warp_fwd_staged_kernel(
     const __amdgpu_buffer_rsrc_t rsrc_out =
         uniform_rsrc(out + static_cast<int64_t>(b) * C * plane, C * plane * esz);
     const int out_voff = live ? p * esz : kDeadOffset;
-    if (bxl > bxh) {   // no tap of the tile is inside the image
+    if (w.empty) {   // no tap of the tile is inside the image
         for (int c = c_begin; c < c_end; ++c) buffer_store_px<T>(rsrc_out, out_voff, c * plane * esz, zsum);
         return;
     }
-    // window: columns from a multiple of 4 (16-byte loads), pitch a multiple of 4
-    const int wx0 = bxl & ~3, wy0 = byl;
-    const int pitch = (bxh - wx0 + 4) & ~3, rows = byh - byl + 1;
-    const int64_t area64 = static_cast<int64_t>(pitch) * rows;
-    if (area64 > kStageMaxArea) {
+    if (!w.fits()) {
         // diverged flow: direct gather, four channels in flight
         if (!live) return;
         const bool okx0 = x0 >= 0 && x0 < W, okx1 = x0 + 1 >= 0 && x0 + 1 < W;
@@ -439,55 +527,17 @@ __global__ __launch_bounds__(256) void warp_fwd_staged_kernel(
         }
         return;
     }
-    const int area = static_cast<int>(area64);
-    const int cch = min(crange, kStageCap / area);
-    // The 16-byte cells of one channel's window this thread copies: cell = tid + 256 j (a
-    // smooth flow has ~100 cells: one per thread of the first two waves).  Cell -> (row,
-    // column) once; the channel is the scalar offset of the load.  it / d for it < 1024,
-    // d <= 1024 as (it * ceil(2^20 / d)) >> 20: exact.
-    const int p4 = pitch >> 2, cells = rows * p4;
-    const int ncell = (cells + 255) >> 8;   // <= 4
-    const unsigned m_row = static_cast<unsigned>(ceilf(1048576.f / static_cast<float>(p4)));
-    int cell_voff[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int cell = tid + 256 * j;
-        const int row = static_cast<int>((cell * m_row) >> 20), q = cell - row * p4;
-        const int gx = wx0 + 4 * q, gy = wy0 + row;
-        cell_voff[j] = (cell < cells && gx >= 0 && gx < W && gy >= 0 && gy < H) ? (gy * W + gx) * esz
-                                                                                 : kDeadOffset;
-    }
-    const bool mine = tid < cells;
-    const float *tap = win + (dead ? 0 : (y0 - wy0) * pitch + (x0 - wx0));
+    w.map_cells(tid, H, W, esz);
+    const int cch = min(crange, kStageCap / w.area);
+    const float *tap = win + (dead ? 0 : (y0 - w.wy0) * w.pitch + (x0 - w.wx0));
     for (int c = c_begin; c < c_end; c += cch) {
         const int n = min(cch, c_end - c);
         if (c != c_begin) __syncthreads();   // the previous group's taps have been read
-        if (ncell == 1) {
-            // eight channels' loads in flight per thread, all issued before the first LDS store
-            for (int h = 0; h < n; h += 8) {
-                float4 v[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u)
-                    v[u] = buffer_load_px4<T>(rsrc_img, h + u < n ? cell_voff[0] : kDeadOffset,
-                                              (c + min(h + u, n - 1)) * plane * esz);
-#pragma unroll
-                for (int u = 0; u < 8; ++u)
-                    if (mine && h + u < n) *reinterpret_cast<float4 *>(win + (h + u) * area + 4 * tid) = v[u];
-            }
-        } else {
-            for (int h = 0; h < n; ++h) {
-                float4 v[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = buffer_load_px4<T>(rsrc_img, cell_voff[j], (c + h) * plane * esz);
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (tid + 256 * j < cells) *reinterpret_cast<float4 *>(win + h * area + 4 * (tid + 256 * j)) = v[j];
-            }
-        }
+        w.stage<T>(win, rsrc_img, c, n, plane);
         __syncthreads();
         for (int h = 0; h < n; ++h) {
-            const float *wc = tap + h * area;
-            const float v0 = wc[0], v1 = wc[1], v2 = wc[pitch], v3 = wc[pitch + 1];
+            const float *wc = tap + h * w.area;
+            const float v0 = wc[0], v1 = wc[1], v2 = wc[w.pitch], v3 = wc[w.pitch + 1];
             float acc = v0 * wnw;
             acc += v1 * wne;
             acc += v2 * wsw;
@@ -679,6 +729,168 @@ __global__ __launch_bounds__(kPix * kCg) void warp_bwd_kernel(
 // (ds_add_f32 on the two halves of the slot: slow, but only diverged steps get here) and
 // NaN / Inf reach exactly the elements they reach in ATen's scatter.
 
+// ---- backward, grad_flow with an LDS-staged source window --------------------------------
+// The FLOW role of warp_bwd_tile_kernel as an 8 x 32 pixel tile (4 strips, one per wave) over
+// ALL channels: the tile's source window is copied into LDS a few channels at a time
+// (StageWindow) and the four taps of a channel come from LDS; gradOutput at the lane's own
+// pixel is a coalesced buffer load whose channel is the scalar offset.  Channel c adds into
+// partial c & 3 in ascending order and the partials are summed 0..3 -- the order of the
+// four-wave strip role below, so the two produce identical bits.
+// Used when the map has >= 512 such tiles.  (Measured, 4 pairs, whole backward, us strip role
+// / this: 32x128x256 27.7 / 25.9, 64x128x256 46.3 / 42.9, 32x256x512 87.7 / 71.9, fp16 80.0 /
+// 65.3.  Splitting the channels of a smaller tile over the waves -- 2 x 32 or 4 x 32 pixels,
+// for the deep levels with few pixels and many channels -- measured SLOWER than the strip
+// role at every level (12.4 -> 25.4 us at 128x32x64): the window halo and the two barriers
+// per pass outweigh the gathers they replace.)
+// Returns false (nothing written) when a group of four channels' windows does not fit.
+template <typename T, typename F>
+__device__ __forceinline__ bool flow_role_staged(
+    float *__restrict__ win, int cap, int4 *__restrict__ boxes, const T *__restrict__ image,
+    const T *__restrict__ gout, const void *__restrict__ ctx, F *__restrict__ gflow, int flow_block,
+    int nflow_blocks, int B, int C, int H, int W, int pad_mode) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int esz = sizeof(T);
+    constexpr int SR = kStageRows, NPL = 4;   // strips per workgroup, partial sums per lane
+    const int plane = H * W;
+    const int tid = threadIdx.x;
+    const int lane = tid & (kPix - 1), wave = __builtin_amdgcn_readfirstlane(tid / kPix);
+    const Strips strips(H, W);
+    const int tyn = (strips.ny + SR - 1) / SR;
+    int id = xcd_chunk(flow_block, nflow_blocks);
+    const int tx = __builtin_amdgcn_readfirstlane(id % strips.nx); id /= strips.nx;
+    const int ty = __builtin_amdgcn_readfirstlane(id % tyn);
+    const int b = __builtin_amdgcn_readfirstlane(id / tyn);
+    const int jy = ty * SR + wave;
+    int x = 0, y = 0;
+    const bool live = jy < strips.ny && strips.pixel(jy * strips.nx + tx, lane, H, W, x, y);
+    const int p = y * W + x;
+    const int pc = live ? p : 0;
+    const float *pos = ctx_pos(ctx, B, H, W) + static_cast<int64_t>(b) * 2 * plane;
+    const float ixp = pos[pc], iyp = pos[plane + pc];
+    const float x0f = floorf(ixp), y0f = floorf(iyp);
+    const float x1f = x0f + 1.f, y1f = y0f + 1.f;
+    const int x0 = live ? tap_index(x0f) : -2, y0 = live ? tap_index(y0f) : -2;
+    const bool dead = !(x0 >= -1 && x0 <= W - 1 && y0 >= -1 && y0 <= H - 1);
+    StageWindow w;
+    w.reduce(dead, x0, y0, boxes, wave, lane);
+    if (!w.fits() || w.area * 4 > cap) return false;   // uniform: a diverged flow
+    w.map_cells(tid, H, W, esz);
+    const int cch = (cap / w.area) & ~3;   // whole groups of four partials per pass
+
+    const __amdgpu_buffer_rsrc_t rsrc_img =
+        uniform_rsrc(image + static_cast<int64_t>(b) * C * plane, C * plane * esz);
+    const __amdgpu_buffer_rsrc_t rsrc_go =
+        uniform_rsrc(gout + static_cast<int64_t>(b) * C * plane, C * plane * esz);
+    const int go_voff = live ? p * esz : kDeadOffset;
+    const float *tap = win + (dead ? 0 : (y0 - w.wy0) * w.pitch + (x0 - w.wx0));
+    float gix[NPL], giy[NPL];
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) gix[k] = giy[k] = 0.f;
+    for (int c = 0; c < C; c += cch) {
+        const int n = min(cch, C - c);
+        if (c != 0) __syncthreads();   // the previous group's taps have been read
+        w.stage<T>(win, rsrc_img, c, n, plane);
+        __syncthreads();
+        for (int h0 = 0; h0 < n; h0 += 8) {   // c and h0 are multiples of 4: channel c + h0 + u is partial u & 3
+            float g[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                g[u] = buffer_load_px1<T>(rsrc_go, h0 + u < n ? go_voff : kDeadOffset,
+                                          (c + min(h0 + u, n - 1)) * plane * esz);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int h = h0 + u;
+                if (h >= n) break;   // uniform
+                const float *wc = tap + h * w.area;
+                const float vnw = dead ? 0.f : wc[0], vne = dead ? 0.f : wc[1];
+                const float vsw = dead ? 0.f : wc[w.pitch], vse = dead ? 0.f : wc[w.pitch + 1];
+                gix[u % NPL] += (-vnw * (y1f - iyp) + vne * (y1f - iyp) - vsw * (iyp - y0f) +
+                                 vse * (iyp - y0f)) * g[u];
+                giy[u % NPL] += (-vnw * (x1f - ixp) - vne * (ixp - x0f) + vsw * (x1f - ixp) +
+                                 vse * (ixp - x0f)) * g[u];
+            }
+        }
+    }
+    float sx = 0.f, sy = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { sx += gix[k]; sy += giy[k]; }
+    if (live) {
+        float mx = static_cast<float>(W) / 2.0f, my = static_cast<float>(H) / 2.0f;
+        if (pad_mode == CERB_PAD_BORDER) {
+            if (ixp <= 0.f || ixp >= static_cast<float>(W - 1)) mx = 0.f;
+            if (iyp <= 0.f || iyp >= static_cast<float>(H - 1)) my = 0.f;
+        }
+        F *gf = gflow + static_cast<int64_t>(b) * 2 * plane + p;
+        st(gf, mx * sx / static_cast<float>(W - 1) * 2.0f);
+        st(gf + plane, my * sy / static_cast<float>(H - 1) * 2.0f);
+    }
+    return true;
+#else
+    return false;
+#endif
+}
+
+// The same tile by direct gathers (the window of a diverged flow does not fit LDS): one wave
+// per strip walks all of its channels, eight channels in flight.
+template <typename T, typename F>
+__device__ __forceinline__ void flow_role_tile_direct(
+    const T *__restrict__ image, const T *__restrict__ gout, const void *__restrict__ ctx,
+    F *__restrict__ gflow, int flow_block, int nflow_blocks, int B, int C, int H, int W, int pad_mode) {
+    const int plane = H * W;
+    const int lane = threadIdx.x & (kPix - 1), wave = threadIdx.x / kPix;
+    constexpr int SR = kStageRows;
+    const Strips strips(H, W);
+    const int tyn = (strips.ny + SR - 1) / SR;
+    int id = xcd_chunk(flow_block, nflow_blocks);
+    const int tx = id % strips.nx; id /= strips.nx;
+    const int ty = id % tyn;
+    const int b = id / tyn;
+    const int jy = ty * SR + wave;
+    int x = 0, y = 0;
+    if (!(jy < strips.ny && strips.pixel(jy * strips.nx + tx, lane, H, W, x, y))) return;
+    const int p = y * W + x;
+    const float *pos = ctx_pos(ctx, B, H, W) + static_cast<int64_t>(b) * 2 * plane;
+    const float ixp = pos[p], iyp = pos[plane + p];
+    const float x0f = floorf(ixp), y0f = floorf(iyp);
+    const float x1f = x0f + 1.f, y1f = y0f + 1.f;
+    const int x0 = tap_index(x0f), y0 = tap_index(y0f);
+    const bool okx0 = x0 >= 0 && x0 < W, okx1 = x0 + 1 >= 0 && x0 + 1 < W;
+    const bool oky0 = y0 >= 0 && y0 < H, oky1 = y0 + 1 >= 0 && y0 + 1 < H;
+    const int o00 = y0 * W + x0;
+    const T *im = image + static_cast<int64_t>(b) * C * plane;
+    const T *gob = gout + static_cast<int64_t>(b) * C * plane;
+    float gix[4] = {0.f, 0.f, 0.f, 0.f}, giy[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < C; c += 8) {
+        float g[8], vnw[8], vne[8], vsw[8], vse[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int64_t cp = static_cast<int64_t>(min(c + u, C - 1)) * plane;
+            g[u] = ld(gob + cp + p);
+            load_taps<false, T, float>(im + cp + o00, oky0 && okx0, oky0 && okx1, vnw[u], vne[u]);
+            load_taps<false, T, float>(im + cp + o00 + W, oky1 && okx0, oky1 && okx1, vsw[u], vse[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (c + u >= C) break;
+            gix[u & 3] += (-vnw[u] * (y1f - iyp) + vne[u] * (y1f - iyp) - vsw[u] * (iyp - y0f) +
+                           vse[u] * (iyp - y0f)) * g[u];
+            giy[u & 3] += (-vnw[u] * (x1f - ixp) - vne[u] * (ixp - x0f) + vsw[u] * (x1f - ixp) +
+                           vse[u] * (ixp - x0f)) * g[u];
+        }
+    }
+    float sx = 0.f, sy = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { sx += gix[k]; sy += giy[k]; }
+    float mx = static_cast<float>(W) / 2.0f, my = static_cast<float>(H) / 2.0f;
+    if (pad_mode == CERB_PAD_BORDER) {
+        if (ixp <= 0.f || ixp >= static_cast<float>(W - 1)) mx = 0.f;
+        if (iyp <= 0.f || iyp >= static_cast<float>(H - 1)) my = 0.f;
+    }
+    F *gf = gflow + static_cast<int64_t>(b) * 2 * plane + p;
+    st(gf, mx * sx / static_cast<float>(W - 1) * 2.0f);
+    st(gf + plane, my * sy / static_cast<float>(H - 1) * 2.0f);
+}
+
 #ifdef CERB_STAMP
 // diagnostic build only (-DCERB_STAMP): s_memtime at the phase boundaries of the first 64 tile
 // workgroups, fetched with cerberus_debug_stamps(); never compiled into the product
@@ -701,17 +913,27 @@ template <typename T, typename F, int TH, int CW, int NS>
 __global__ __launch_bounds__(256, 4) void warp_bwd_tile_kernel(
     const T *__restrict__ image, const T *__restrict__ gout, const void *__restrict__ ctx,
     T *__restrict__ gimage, F *__restrict__ gflow, int B, int C, int H, int W,
-    int tiles_x, int tiles_y, int nrange, int crange, int ntile_blocks, int pad_mode) {
+    int tiles_x, int tiles_y, int nrange, int crange, int ntile_blocks, int pad_mode,
+    int flow_staged) {
     constexpr int TW = kTileW, PW = TileGeom<TH>::PW, PS = TileGeom<TH>::PS;
     constexpr int NP = CW / 2;                       // channel pairs = planes of 64-bit slots
     static_assert(CW % 2 == 0, "channels are accumulated in pairs");
-    __shared__ long long acc[NP * PS];
-    __shared__ int red[4][8];
+    __shared__ __attribute__((aligned(16))) long long acc[NP * PS];
+    __shared__ __attribute__((aligned(16))) int red[4][8];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int plane = H * W;
 
     if (static_cast<int>(blockIdx.x) >= ntile_blocks) {
         // ------------------------------ FLOW workgroup ------------------------------
+        if (flow_staged) {
+            // an 8 x 32 tile x all channels through an LDS window (the accumulators' LDS)
+            const int fb = blockIdx.x - ntile_blocks, nfb = gridDim.x - ntile_blocks;
+            if (!flow_role_staged<T, F>(reinterpret_cast<float *>(acc), NP * PS * 2,
+                                        reinterpret_cast<int4 *>(&red[0][0]), image, gout, ctx, gflow,
+                                        fb, nfb, B, C, H, W, pad_mode))
+                flow_role_tile_direct<T, F>(image, gout, ctx, gflow, fb, nfb, B, C, H, W, pad_mode);
+            return;
+        }
         // one strip of 64 pixels x 4 channel groups (one wave each); positions from the context
         float(*part)[2][kPix] = reinterpret_cast<float(*)[2][kPix]>(acc);
         const Strips strips(H, W);
@@ -749,6 +971,7 @@ __global__ __launch_bounds__(256, 4) void warp_bwd_tile_kernel(
             }
 #pragma unroll
             for (int u = 0; u < kU; ++u) {
+                if (c + u * 4 >= C) break;   // (uniform) no 0 * Inf from a repeated channel
                 gix += (-vnw[u] * (y1f - iyp) + vne[u] * (y1f - iyp) - vsw[u] * (iyp - y0f) +
                         vse[u] * (iyp - y0f)) * g[u];
                 giy += (-vnw[u] * (x1f - ixp) - vne[u] * (ixp - x0f) + vsw[u] * (x1f - ixp) +
@@ -1286,14 +1509,22 @@ static int launch_tiles(const void *image, const void *gout, const void *ctx, vo
     const int crange = (groups + nrange - 1) / nrange * CW;
     nrange = (C + crange - 1) / crange;
     const int64_t tile_blocks = tiles * nrange;
-    const int64_t flow_blocks = gflow ? static_cast<int64_t>(B) * Strips(H, W).per_image() : 0;
+    // grad_flow: 8 x 32 tiles through an LDS window (16-byte aligned rows, 32-bit byte
+    // offsets), else 2 x 32 strips x 4 channel-group waves by direct gathers
+    const Strips strips(H, W);
+    const int64_t flow_tiles = static_cast<int64_t>(B) * ((strips.ny + kStageRows - 1) / kStageRows) * strips.nx;
+    const int staged_opt = option(OPT_WARP_STAGED);
+    const bool flow_staged = gflow && W % 4 == 0 && (reinterpret_cast<uintptr_t>(image) & 15) == 0 &&
+                             static_cast<int64_t>(C) * H * W * 4 < 0x7fffffff && staged_opt != 2 &&
+                             (flow_tiles >= 512 || staged_opt >= 4);
+    const int64_t flow_blocks = !gflow ? 0 : flow_staged ? flow_tiles : static_cast<int64_t>(B) * strips.per_image();
     if (tile_blocks + flow_blocks > 0x7fffffff) return CERB_ETOOLARGE;
     hipLaunchKernelGGL((warp_bwd_tile_kernel<T, F, TH, CW, NS>),
                        dim3(static_cast<unsigned>(tile_blocks + flow_blocks)), dim3(256), 0, s,
                        static_cast<const T *>(image), static_cast<const T *>(gout), ctx,
                        static_cast<T *>(gimage), static_cast<F *>(gflow), B,
                        C, H, W, tiles_x, tiles_y, nrange, crange, static_cast<int>(tile_blocks),
-                       pad_mode);
+                       pad_mode, flow_staged ? 1 : 0);
     return launch_status();
 }
 

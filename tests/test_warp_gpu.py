@@ -291,6 +291,23 @@ def test_lds_staged_gather_equals_the_direct_gather_bit_for_bit(dt):
                 assert torch.equal(plain.view(torch.int16 if dt != torch.float32 else torch.int32),
                                    out0.view(torch.int16 if dt != torch.float32 else torch.int32))
                 assert torch.equal(ctx, ctx0), (shape, amp, pad, crange)
+            # backward: the staged grad_flow role against the four-wave strip role
+            go = dev(hash_uniform(shape, 800 + k)).to(dt)
+            _lib.set_option("warp_staged", 2)
+            try:
+                gi0, gf0 = torch.ops.cerberus.flow_warp_backward_ctx(img, flo, ctx0, go, pad, 0, True, True)
+            finally:
+                _lib.set_option("warp_staged", 0)
+            bits = torch.int32 if gf0.dtype == torch.float32 else torch.int16
+            for force in (0, 8):          # auto (staged on large maps) / staged at any size
+                _lib.set_option("warp_staged", force)
+                try:
+                    gi, gf = torch.ops.cerberus.flow_warp_backward_ctx(img, flo, ctx0, go, pad, 0, True, True)
+                finally:
+                    _lib.set_option("warp_staged", 0)
+                assert torch.equal(gf.view(bits), gf0.view(bits)), (shape, amp, pad, force)
+                assert torch.equal(gi.view(torch.int16 if dt != torch.float32 else torch.int32),
+                                   gi0.view(torch.int16 if dt != torch.float32 else torch.int32))
 
 
 def test_seeded_random_shape_sweep_against_the_oracle():
