@@ -35,6 +35,7 @@ PROTOTYPES = {
     "cerberus_flow_warp_backward": (_I, [_P, _P, _P, _P, _P, _P, _I64, _P, _I64] + [_I] * 8 + [_P]),
     "cerberus_flow_upsample_forward": (_I, [_P, _P, _I64, _I, _I, _I, _I, _P]),
     "cerberus_flow_upsample_backward": (_I, [_P, _P, _I64, _I, _I, _I, _I, _P]),
+    "cerberus_area_resize": (_I, [_P, _P, _I64, _I, _I, _I, _I, _I, _P]),
     "cerberus_set_option": (_I, [ctypes.c_char_p, _I]),
     "cerberus_get_option": (_I, [ctypes.c_char_p, ctypes.POINTER(_I)]),
     "cerberus_last_kernel": (ctypes.c_char_p, [_I]),

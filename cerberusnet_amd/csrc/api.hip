@@ -205,6 +205,15 @@ int cerberus_flow_upsample_backward(const void *grad_out, void *grad_in, int64_t
     return upsample_entry(false, grad_out, grad_in, planes, H, W, factor, dtype, stream);
 }
 
+int cerberus_area_resize(const void *src, void *dst, int64_t planes, int H, int W, int out_h, int out_w,
+                         int dtype, void *stream) {
+    if (!dtype_ok(dtype)) return CERB_EDTYPE;
+    if (planes < 0 || H <= 0 || W <= 0 || out_h <= 0 || out_w <= 0) return CERB_EINVAL;
+    if (planes == 0) return CERB_OK;
+    if (!src || !dst) return CERB_EINVAL;
+    return area_resize(src, dst, planes, H, W, out_h, out_w, dtype, static_cast<hipStream_t>(stream));
+}
+
 int cerberus_set_option(const char *key, int value) {
     if (!key) return CERB_EINVAL;
     const int i = find_option(key);

@@ -143,6 +143,8 @@ int warp_backward(const void *image, const void *flow, const void *gout, void *g
 // upsample.hip: flow * factor -> bilinear x factor, align_corners = true (forward) / its adjoint
 int flow_upsample(bool forward, const void *src, void *dst, int64_t planes, int H, int W, int factor,
                   int dtype, hipStream_t s);
+int area_resize(const void *src, void *dst, int64_t planes, int H, int W, int oH, int oW, int dtype,
+                hipStream_t s);
 
 static inline int launch_status() {
     hipError_t e = hipGetLastError();

@@ -113,7 +113,52 @@ int launch(bool fwd, const void *a, void *b, int64_t planes, int H, int W, int o
     return launch_status();
 }
 
+// ---- 'area' resize of the photometric loss's target images -------------------------------
+// F.interpolate(image, (h, w), mode='area') (UnFlowLoss.py:279-280) = adaptive average pooling:
+// output (oy, ox) is the mean of rows [floor(oy H / h), ceil((oy + 1) H / h)) x the same in x.
+// ATen's arithmetic: an fp32 sum in row-major order, then / kh / kw -- reproduced exactly
+// (bit-identical to torch's CPU kernel on fp32).  One thread per output element; neighbouring
+// threads read neighbouring windows, so rows are read coalesced.
+template <typename T>
+__global__ __launch_bounds__(256) void area_resize_kernel(const T *__restrict__ in, T *__restrict__ out,
+                                                          int64_t planes, int H, int W, int oH, int oW) {
+    const int64_t total = planes * oH * oW;
+    for (int64_t idx = blockIdx.x * 256ll + threadIdx.x; idx < total; idx += static_cast<int64_t>(gridDim.x) * 256) {
+        const int ox = static_cast<int>(idx % oW);
+        const int oy = static_cast<int>((idx / oW) % oH);
+        const int64_t pl = idx / (static_cast<int64_t>(oW) * oH);
+        const int y0 = static_cast<int>(static_cast<int64_t>(oy) * H / oH);
+        const int y1 = static_cast<int>((static_cast<int64_t>(oy + 1) * H + oH - 1) / oH);
+        const int x0 = static_cast<int>(static_cast<int64_t>(ox) * W / oW);
+        const int x1 = static_cast<int>((static_cast<int64_t>(ox + 1) * W + oW - 1) / oW);
+        const T *p = in + pl * H * W;
+        float sum = 0.f;
+        for (int y = y0; y < y1; ++y)
+            for (int x = x0; x < x1; ++x) sum += ld(p + static_cast<int64_t>(y) * W + x);
+        st(out + idx, sum / static_cast<float>(y1 - y0) / static_cast<float>(x1 - x0));
+    }
+}
+
+template <typename T>
+int launch_area(const void *a, void *b, int64_t planes, int H, int W, int oH, int oW, hipStream_t s) {
+    const int64_t total = planes * oH * oW;
+    const unsigned blocks = static_cast<unsigned>(std::min<int64_t>((total + 255) / 256, 8192));
+    hipLaunchKernelGGL(area_resize_kernel<T>, dim3(blocks), dim3(256), 0, s, static_cast<const T *>(a),
+                       static_cast<T *>(b), planes, H, W, oH, oW);
+    return launch_status();
+}
+
 }  // namespace
+
+int area_resize(const void *src, void *dst, int64_t planes, int H, int W, int oH, int oW, int dtype,
+                hipStream_t s) {
+    switch (dtype) {
+        case CERB_F32: return launch_area<float>(src, dst, planes, H, W, oH, oW, s);
+        case CERB_F16: return launch_area<__half>(src, dst, planes, H, W, oH, oW, s);
+        case CERB_BF16: return launch_area<hip_bfloat16>(src, dst, planes, H, W, oH, oW, s);
+        default: return CERB_EDTYPE;
+    }
+}
 
 int flow_upsample(bool forward, const void *src, void *dst, int64_t planes, int H, int W, int factor,
                   int dtype, hipStream_t s) {

@@ -14,7 +14,13 @@ import torch
 
 from .. import ops as _ops
 
-__all__ = ["flow_warp", "mesh_grid", "norm_grid"]
+__all__ = ["flow_warp", "mesh_grid", "norm_grid", "area_resize"]
+
+
+def area_resize(image, size):
+    """``F.interpolate(image, size, mode='area')`` as one HIP launch: how the photometric loss
+    brings the target images to every flow scale (reference :279-280).  Forward only."""
+    return torch.ops.cerberus.area_resize(image, int(size[0]), int(size[1]))
 
 
 def mesh_grid(batch_sz, height, width):

@@ -45,6 +45,7 @@ _def.define("correlation_leaky_into(Tensor(a!) buffer, Tensor input1, Tensor inp
             "%s, float negative_slope) -> ()" % _CORR_ARGS)
 _def.define("flow_upsample(Tensor flow, int factor) -> Tensor")
 _def.define("flow_upsample_backward(Tensor grad_out, int factor) -> Tensor")
+_def.define("area_resize(Tensor image, int out_h, int out_w) -> Tensor")
 _def.define("flow_warp(Tensor image, Tensor flow, int pad_mode, int interp_mode) -> Tensor")
 _def.define("flow_warp_ctx(Tensor image, Tensor flow, int pad_mode, int interp_mode) -> "
             "(Tensor, Tensor)")
@@ -371,6 +372,30 @@ def _flow_upsample_backward_cuda(grad_out, factor):
     return _flow_upsample_run(grad_out, factor, False, "cerberus::flow_upsample_backward")
 
 
+def _area_resize_cuda(image, out_h, out_w):
+    """F.interpolate(image, (out_h, out_w), mode='area') (UnFlowLoss.py:279-280)."""
+    what = "cerberus::area_resize"
+    if image.dim() != 4:
+        raise RuntimeError("%s: expected a 4-D NCHW tensor, got %s" % (what, tuple(image.shape)))
+    if out_h < 1 or out_w < 1:
+        raise RuntimeError("%s: output size must be positive, got (%d, %d)" % (what, out_h, out_w))
+    code = _dtype_code(image, what)
+    if code == 3:
+        raise RuntimeError("%s: float64 is not supported" % what)
+    x = image.contiguous()
+    B, C, H, W = x.shape
+    out = x.new_empty((B, C, out_h, out_w))
+    if out.numel() == 0:
+        return out
+    if H == 0 or W == 0:
+        raise RuntimeError("%s: input has no pixels" % what)
+    with torch.cuda.device(x.device):
+        rc = _lib.get().cerberus_area_resize(x.data_ptr(), out.data_ptr(), B * C, H, W, out_h, out_w,
+                                             code, _stream_ptr(x))
+    _lib.check(rc, what)
+    return out
+
+
 def _no_cpu(name):
     def _raise(*_a, **_k):
         raise RuntimeError("cerberus::%s has no CPU implementation: this build is the "
@@ -397,6 +422,9 @@ _def.impl("flow_upsample_backward", _flow_upsample_backward_cuda, "CUDA")
 _def.impl("flow_upsample_backward",
           lambda g, k: g.new_empty((g.shape[0], g.shape[1], g.shape[2] // k, g.shape[3] // k)), "Meta")
 _def.impl("flow_upsample_backward", _no_cpu("flow_upsample_backward"), "CPU")
+_def.impl("area_resize", _area_resize_cuda, "CUDA")
+_def.impl("area_resize", lambda x, h, w: x.new_empty((x.shape[0], x.shape[1], h, w)), "Meta")
+_def.impl("area_resize", _no_cpu("area_resize"), "CPU")
 _def.impl("flow_warp", _flow_warp_cuda, "CUDA")
 _def.impl("flow_warp", lambda image, flow, p, m: torch.empty_like(image), "Meta")
 _def.impl("flow_warp", _no_cpu("flow_warp"), "CPU")
@@ -504,6 +532,13 @@ def _upsample_bwd_backward(ctx, grad):
     return torch.ops.cerberus.flow_upsample(grad, ctx.factor), None
 
 
+def _area_resize_backward(ctx, grad):
+    raise RuntimeError("cerberus::area_resize is not differentiable: the reference resizes the "
+                       "TARGET images with it (UnFlowLoss.py:279-280), which carry no gradient")
+
+
+torch.library.register_autograd("cerberus::area_resize", _area_resize_backward,
+                                setup_context=lambda ctx, inputs, output: None)
 torch.library.register_autograd("cerberus::flow_upsample", _upsample_backward,
                                 setup_context=_upsample_setup)
 torch.library.register_autograd("cerberus::flow_upsample_backward", _upsample_bwd_backward,

@@ -170,6 +170,17 @@ int cerberus_flow_upsample_forward(const void *src, void *dst, int64_t planes, i
 int cerberus_flow_upsample_backward(const void *grad_out, void *grad_in, int64_t planes, int H,
                                     int W, int factor, int dtype, void *stream);
 
+/* The photometric loss's image pyramid.  Replaces
+ *   F.interpolate(image, (out_h, out_w), mode='area')
+ * (nnet_training/loss_functions/UnFlowLoss.py:279-280: the target images resized to every flow
+ * scale) = ATen adaptive_avg_pool2d: output (oy, ox) is the mean over rows
+ * [floor(oy*H/out_h), ceil((oy+1)*H/out_h)) x the same in x, summed in fp32 in row-major order
+ * and divided by the window height, then width (bit-identical to torch's CPU kernel in fp32).
+ *   src (planes, H, W) -> dst (planes, out_h, out_w); any sizes >= 1; fp32 / fp16 / bf16.
+ * Forward only: the reference applies it to target images, which carry no gradient. */
+int cerberus_area_resize(const void *src, void *dst, int64_t planes, int H, int W, int out_h,
+                         int out_w, int dtype, void *stream);
+
 /* Diagnostics / tuning knobs (process-wide, read at launch time, default 0):
  *   "corr_force_generic" : 1 = always use the generic kernels (testing)
  *   "corr_fwd_variant"   : 0 = auto, 1..8 = force one register-staged forward variant,

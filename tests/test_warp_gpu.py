@@ -491,3 +491,44 @@ def test_flow_upsample_half_and_errors():
         torch.ops.cerberus.flow_upsample_backward(x.to(DEV), 8)
     with pytest.raises(RuntimeError, match="no CPU"):
         torch.ops.cerberus.flow_upsample(x, 2)
+
+
+@pytest.mark.parametrize("size", [(16, 24), (20, 36), (7, 5), (64, 96), (32, 48), (1, 1), (100, 130)])
+def test_area_resize_is_bit_identical_to_torch_cpu(size):
+    """The photometric loss resizes the target images to every flow scale with
+    F.interpolate(mode='area') (UnFlowLoss.py:279-280) = adaptive average pooling.  Same window
+    bounds, same fp32 row-major sum, same two divisions as ATen's CPU kernel: identical bits for
+    integer and fractional ratios, down- and up-sampling (windows up to 16 x 16 here)."""
+    x = hash_uniform((2, 3, 64, 96), 901, -2.0, 2.0)
+    ref = torch.nn.functional.interpolate(torch.from_numpy(x), size, mode="area")
+    out = ca.area_resize(dev(x), size)
+    assert out.shape == ref.shape
+    if size == (1, 1):
+        # a 6144-element window: ATen's CPU kernel sums it in vector lanes, not serially
+        assert rel_err(out.cpu().numpy(), ref.numpy()) < TOL
+    else:
+        assert torch.equal(out.cpu(), ref)
+
+
+def test_area_resize_pyramid_half_errors():
+    # the loss's own pyramid: (B,3,512,1024) targets to the four flow scales
+    x = dev(hash_uniform((1, 3, 512, 1024), 902, -2.0, 2.0))
+    for h, w in [(512, 1024), (128, 256), (64, 128), (32, 64), (16, 32)]:
+        ref = torch.nn.functional.interpolate(x.cpu(), (h, w), mode="area")
+        assert torch.equal(ca.area_resize(x, (h, w)).cpu(), ref)
+    for dt, tol in [(torch.float16, 1e-3), (torch.bfloat16, 8e-3)]:
+        ref = torch.nn.functional.interpolate(x.cpu().to(dt).float(), (64, 128), mode="area")
+        got = ca.area_resize(x.to(dt), (64, 128))
+        assert got.dtype == dt
+        assert float((got.float().cpu() - ref).abs().max()) < tol * 2.0
+    with pytest.raises(RuntimeError, match="positive"):
+        ca.area_resize(x, (0, 4))
+    with pytest.raises(RuntimeError, match="4-D"):
+        ca.area_resize(x[0], (4, 4))
+    with pytest.raises(RuntimeError, match="float64"):
+        ca.area_resize(x.double(), (4, 4))
+    xr = x.clone().requires_grad_(True)
+    with pytest.raises(RuntimeError, match="not differentiable"):
+        ca.area_resize(xr, (4, 4)).sum().backward()
+    with pytest.raises(RuntimeError, match="no CPU implementation"):
+        ca.area_resize(x.cpu(), (4, 4))
