@@ -31,6 +31,7 @@
 // No MFMA: this is a gather-reduce (a banded product wastes >7x the flops as a
 // dense GEMM and fp32 MFMA runs at the vector rate anyway).
 #include <atomic>
+#include <type_traits>
 
 #include "common.h"
 
@@ -2161,6 +2162,13 @@ int fwd_dispatch(const void *x1, const void *x2, void *o, const CorrGeom &g, flo
 template <typename T>
 int bwd_dispatch(const void *x1, const void *x2, const void *go, void *g1, void *g2,
                  const CorrGeom &g, bool vec, hipStream_t s) {
+    if constexpr (sizeof(T) == 2) {
+        // 16-bit storage: the matrix-core kernel (corr_mfma.hip); variants 1-3 keep the VALU kernels
+        const int v = option(OPT_CORR_BWD_VARIANT);
+        if (vec && dma_ok(g) && (v == 0 || v == 11))
+            return corr_mfma_backward(x1, x2, go, g1, g2, g,
+                                      std::is_same<T, __half>::value ? CERB_F16 : CERB_BF16, s);
+    }
     if (g.W <= 32) {
         if constexpr (sizeof(T) == 4) {
             if (vec && dma_ok(g) && option(OPT_CORR_BWD_VARIANT) != 1)

@@ -616,3 +616,38 @@ def test_concat_function_equals_cat_of_the_separate_ops():
     assert torch.equal(fused, sep)
     for u, v in zip(gf, gs):
         assert torch.equal(u, v)
+
+
+@pytest.mark.parametrize("dtype,ulp", [(torch.float16, 2.0 ** -10), (torch.bfloat16, 2.0 ** -7)])
+def test_mfma_backward_equals_the_valu_backward_up_to_output_rounding(dtype, ulp):
+    """16-bit storage: the backward runs on the matrix cores (corr_mfma.hip: band matrix of
+    gradOutput x window rows, v_mfma_f32_16x16x32).  fp16 / bf16 products are exact in fp32 and
+    both kernels accumulate in fp32, so they may differ only by summation order before the one
+    rounding to the storage type: at most one unit of the output's last place (relative to the
+    tensor's magnitude).  Shapes: ragged rows and tiles, W a multiple of 4 but not of 64,
+    channel counts that are not multiples of 16 / 32, several batch items, a map narrower than
+    a tile, and the padding on every border."""
+    p = (4, 1, 4, 1, 1, 1)
+    for k, shp in enumerate([(2, 32, 9, 68), (1, 24, 17, 132), (3, 7, 5, 12), (1, 64, 33, 64),
+                             (1, 256, 16, 32), (2, 40, 4, 200)]):
+        B, C, H, W = shp
+        x1 = torch.from_numpy(hash_uniform(shp, 910 + k)).to(dtype).to(DEV)
+        x2 = torch.from_numpy(hash_uniform(shp, 920 + k)).to(dtype).to(DEV)
+        go = torch.from_numpy(hash_uniform((B, 81, H, W), 930 + k)).to(dtype).to(DEV)
+        g1, g2 = torch.ops.cerberus.correlation_backward(x1, x2, go, *p)
+        assert _lib.last_kernel(1) == "corr_bwd_d4_mfma_4x64", _lib.last_kernel(1)
+        _lib.set_option("corr_bwd_variant", 1)
+        try:
+            v1, v2 = torch.ops.cerberus.correlation_backward(x1, x2, go, *p)
+            assert "mfma" not in _lib.last_kernel(1)
+        finally:
+            _lib.set_option("corr_bwd_variant", 0)
+        for a, b in ((g1, v1), (g2, v2)):
+            scale = float(b.float().abs().max())
+            assert float((a.float() - b.float()).abs().max()) <= ulp * scale, shp
+        if H * W * C <= 40000:
+            r1, r2 = oracle.corr_backward_ref(x1.double().cpu().numpy(), x2.double().cpu().numpy(),
+                                              go.double().cpu().numpy(), 4, 1, 4, 1, 1)
+            tol = 2e-3 if dtype == torch.float16 else 1.6e-2
+            assert rel_err(g1.double().cpu().numpy(), r1) < tol
+            assert rel_err(g2.double().cpu().numpy(), r2) < tol
