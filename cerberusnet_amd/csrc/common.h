@@ -134,6 +134,9 @@ int corr_d4_backward(const void *in1, const void *in2, const void *gout, void *g
 int corr_mfma_backward(const void *in1, const void *in2, const void *gout, void *gin1, void *gin2,
                        const CorrGeom &g, int dtype, hipStream_t s);
 
+int corr_mfma_forward(const void *in1, const void *in2, void *out, const CorrGeom &g, float slope,
+                      int64_t obs, int dtype, hipStream_t s);
+
 int64_t warp_context_bytes(int B, int H, int W);
 int64_t warp_backward_workspace_bytes(int B, int C, int H, int W);
 int warp_forward(const void *image, const void *flow, void *out, void *ctx, int64_t ctx_size,

@@ -2090,6 +2090,13 @@ bool aligned_group(const void *p, int dtype) {
 template <typename T>
 int fwd_dispatch(const void *x1, const void *x2, void *o, const CorrGeom &g, float slope,
                  int64_t obs, bool vec, hipStream_t s) {
+    if constexpr (sizeof(T) == 2) {
+        // 16-bit storage, 16 < C <= 64: the matrix-core kernel (corr_mfma.hip; 14 forces it); variants 1-8 keep the VALU kernels
+        const int v = option(OPT_CORR_FWD_VARIANT);
+        if (vec && dma_ok(g) && g.C <= 64 && (v == 14 || (v == 0 && g.C > 16)))   // <= 16 channels fill half an MFMA: no gain
+            return corr_mfma_forward(x1, x2, o, g, slope, obs,
+                                     std::is_same<T, __half>::value ? CERB_F16 : CERB_BF16, s);
+    }
     switch (option(OPT_CORR_FWD_VARIANT)) {  // tuning / test hook
         case 1: return launch_fwd<FwdA2, T>("corr_fwd_d4_8x64", x1, x2, o, g, slope, obs, vec, s);
         case 2: return launch_fwd<FwdA1, T>("corr_fwd_d4_4x64", x1, x2, o, g, slope, obs, vec, s);

@@ -221,6 +221,232 @@ __global__ __launch_bounds__(BwdMfmaCfg::THREADS, 2) void corr_bwd_d4_mfma_kerne
 #endif
 }
 
+// ============================================================================
+// forward
+// ============================================================================
+// out[(dy,dx)][y][x] = leaky(1/C * sum_c x1[c][y][x] * x2[c][y+dy][x+dx]): for an output row, a
+// 16-pixel segment and one dy, D[p][q] = sum_c x1[c][p] * x2[c][q] over a 16-column block of
+// the x2 row is ONE v_mfma_f32_16x16x32 per 32 channels (M = pixels, N = window columns, K =
+// channels); the nine wanted entries of a row of D are the diagonals q - p - 4 + 8 h = dx of
+// two blocks h = 0, 1 (columns x0 - 4 + 8 h ..).  No operand holds explicit zeros, so NaN / Inf
+// reach exactly the outputs they reach in the VALU kernels.
+// The contraction runs over channels, so a lane's 8 consecutive k must be 8 consecutive
+// CHANNELS of one pixel: the tiles are transposed to pixel-major / channel-minor on their way
+// into LDS (4 x 4 blocks in registers; the reference does the same as a separate pass over
+// global memory, correlation_cuda_kernel.cu:13-27).  A pixel's 16-byte chunks are XOR-swizzled
+// by its column so that the 16 lanes of an operand read start in different banks.
+// A wave owns one row: per dy 8 MFMAs; the wanted diagonals are scaled, LeakyReLU'd, rounded
+// and passed through a per-wave LDS tile to become whole 128 / 64-byte plane rows.
+// NKB = 32-channel blocks held at once (C <= 32 NKB); the tile is 4 rows x 64 / NKB pixels.
+template <int NKB_>
+struct FwdMfmaCfg {
+    static constexpr int NKB = NKB_, NSEG = 4 / NKB, TW = 16 * NSEG, TH = 4;
+    static constexpr int PIXB = 64 * NKB;                      // bytes per pixel (all channels)
+    static constexpr int WR = TH + 2 * kD, WCOL = TW + 2 * kD; // window rows / columns
+    static constexpr int GRP = 4 * PIXB + 16;                  // 4 pixels + 16 bytes: see pix()
+    static constexpr int WROW = (WCOL / 4) * GRP, XROW = (TW / 4) * GRP;   // row pitches in bytes
+    static constexpr int WIN_B = WR * WROW, X1_B = TH * XROW;
+    static constexpr int TP = TW + 1;                          // T row pitch: odd, so a diagonal of D spreads over the banks
+    static constexpr int T_B = (kND * TP + 64) * 4;            // per wave: 9 planes x TW pixels fp32 + 64 dump slots
+    static constexpr int THREADS = 64 * TH;
+    static constexpr size_t LDS_BYTES = WIN_B + X1_B;          // the T tiles reuse the x1 tile's LDS
+    static_assert(TH * T_B <= X1_B, "T tiles fit the x1 tile");
+    static_assert(NKB == 1 || NKB == 2, "channel blocks");
+    // Byte offset, inside a row, of 16-byte chunk ci (8 channels) of the pixel at column col.
+    // Two access patterns must both spread over the banks: the operand reads (16 lanes = 16
+    // consecutive columns, same chunk) and the transposing writes (16 lanes = columns 4 apart).
+    // 16 bytes of padding per 4 pixels staggers the 4-pixel groups, the XOR staggers the pixels
+    // inside a group; without them the staging writes alone cost 14 us of a 64 us launch.
+    static __device__ __forceinline__ int pix(int col, int ci) {
+        const int sw = (NKB == 1 ? (col >> 1) & 1 : col & 3) << 1;
+        return (col >> 2) * GRP + (col & 3) * PIXB + ((ci ^ sw) << 4);
+    }
+};
+
+template <typename K, typename T>
+__global__ __launch_bounds__(K::THREADS, 2) void corr_fwd_d4_mfma_kernel(
+    const T *__restrict__ x1, const T *__restrict__ x2, T *__restrict__ out, int C, int H, int W,
+    int tiles_x, int tiles_y, float slope, int64_t out_bstride, int dbg) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#ifndef CERB_ABLATE
+    dbg = 0;   // timing ablations exist in -DCERB_ABLATE builds only (tools/ablate_mfma.py)
+#endif
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    unsigned char *win = lds, *x1t = lds + K::WIN_B;
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+
+    int bid = xcd_chunk(blockIdx.x, gridDim.x);
+    const int tx = __builtin_amdgcn_readfirstlane(bid % tiles_x); bid /= tiles_x;
+    const int ty = __builtin_amdgcn_readfirstlane(bid % tiles_y);
+    const int b = __builtin_amdgcn_readfirstlane(bid / tiles_y);
+    const int x0 = tx * K::TW, y0 = ty * K::TH;
+    const int plane = H * W;
+    const __amdgpu_buffer_rsrc_t r1 = uniform_rsrc(x1 + static_cast<int64_t>(b) * C * plane, C * plane * 2);
+    const __amdgpu_buffer_rsrc_t r2 = uniform_rsrc(x2 + static_cast<int64_t>(b) * C * plane, C * plane * 2);
+
+    // ---- global (NCHW) -> LDS (pixel-major, channel-minor): units of 4 pixels x 4 channels ----
+    {
+        constexpr int CG = 8 * K::NKB;                                   // 4-channel groups
+        constexpr int WU = K::WR * (K::WCOL / 4) * CG;                   // window units
+        constexpr int XU = K::TH * (K::TW / 4) * CG;                     // x1 tile units
+        constexpr int NU = (WU + XU + K::THREADS - 1) / K::THREADS;
+        u2v v[NU][4];
+#pragma unroll
+        for (int i = 0; i < NU; ++i) {
+            if (dbg & 1) { v[i][0] = v[i][1] = v[i][2] = v[i][3] = u2v{0x3c003c00u, 0x3c003c00u}; continue; }
+            const int u = tid + K::THREADS * i;
+            const bool isw = u < WU;
+            const int uu = isw ? u : u - WU;
+            constexpr int WG4 = K::WCOL / 4, XG4 = K::TW / 4;
+            const int g4 = isw ? uu % WG4 : uu % XG4;                    // 4-pixel group in the row
+            const int rest = isw ? uu / WG4 : uu / XG4;
+            const int row = isw ? rest % K::WR : rest % K::TH;
+            const int cg = isw ? rest / K::WR : rest / K::TH;
+            const int gy = isw ? y0 - kD + row : y0 + row, gxx = isw ? x0 - kD + 4 * g4 : x0 + 4 * g4;
+            const bool ok = u < WU + XU && gy >= 0 && gy < H && gxx >= 0 && gxx < W;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int c = 4 * cg + k;
+                const int off = (ok && c < C) ? (c * plane + gy * W + gxx) * 2 : kDead;
+                v[i][k] = isw ? __builtin_amdgcn_raw_buffer_load_b64(r2, off, 0, 0)
+                              : __builtin_amdgcn_raw_buffer_load_b64(r1, off, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NU; ++i) {
+            const int u = tid + K::THREADS * i;
+            if (u >= WU + XU || (dbg & 2)) continue;
+            const bool isw = u < WU;
+            const int uu = isw ? u : u - WU;
+            constexpr int WG4 = K::WCOL / 4, XG4 = K::TW / 4;
+            const int g4 = isw ? uu % WG4 : uu % XG4;
+            const int rest = isw ? uu / WG4 : uu / XG4;
+            const int row = isw ? rest % K::WR : rest % K::TH;
+            const int cg = isw ? rest / K::WR : rest / K::TH;
+            unsigned char *base = isw ? win + row * K::WROW : x1t + row * K::XROW;
+            // v[i][k] = channel 4cg+k, pixels (0,1 | 2,3) -> per pixel j: channels (0,1 | 2,3)
+            const unsigned a0 = v[i][0].x, a1 = v[i][1].x, a2 = v[i][2].x, a3 = v[i][3].x;
+            const unsigned b0 = v[i][0].y, b1 = v[i][1].y, b2 = v[i][2].y, b3 = v[i][3].y;
+            const u2v px[4] = {
+                u2v{(a0 & 0xFFFFu) | (a1 << 16), (a2 & 0xFFFFu) | (a3 << 16)},
+                u2v{(a0 >> 16) | (a1 & 0xFFFF0000u), (a2 >> 16) | (a3 & 0xFFFF0000u)},
+                u2v{(b0 & 0xFFFFu) | (b1 << 16), (b2 & 0xFFFFu) | (b3 << 16)},
+                u2v{(b0 >> 16) | (b1 & 0xFFFF0000u), (b2 >> 16) | (b3 & 0xFFFF0000u)}};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int col = 4 * g4 + j;
+                *reinterpret_cast<u2v *>(base + K::pix(col, cg >> 1) + (cg & 1) * 8) = px[j];
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- this wave's row ----
+    const int p = lane & 15, kg = lane >> 4;
+    const int y = y0 + wave;
+    u4v a[K::NSEG][K::NKB];
+#pragma unroll
+    for (int s = 0; s < K::NSEG; ++s)
+#pragma unroll
+        for (int kb = 0; kb < K::NKB; ++kb) {
+            const int col = 16 * s + p;
+            a[s][kb] = *reinterpret_cast<const u4v *>(x1t + wave * K::XROW + K::pix(col, 4 * kb + kg));
+        }
+    __syncthreads();   // every wave holds its x1 operands in registers: the tile's LDS becomes the T tiles
+    float *tt = reinterpret_cast<float *>(x1t + wave * K::T_B);
+    const float inv_nelems = 1.0f / static_cast<float>(C);
+    const int64_t obs = out_bstride ? out_bstride : static_cast<int64_t>(kND * kND) * plane;
+    const __amdgpu_buffer_rsrc_t ro = uniform_rsrc(out + b * obs, kND * kND * plane * 2);
+    // D[m][q]: a lane holds q = p and m = 4 kg + j; dx = q - m - 4 + 8 h.  Block 0 serves the
+    // pixels m < 8 (lanes kg < 2), block 1 the pixels m >= 8 (kg >= 2), and then
+    // dx + 4 = p - 4 (kg & 1) - j for both: per j ONE predicate and ONE LDS slot per lane,
+    // fixed for the whole kernel (a lane without a wanted entry writes a dump slot).
+    const bool low = kg < 2;
+    int t_slot[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int dxi = p - 4 * (kg & 1) - j;
+        t_slot[j] = (dxi >= 0 && dxi < kND) ? dxi * K::TP + 4 * kg + j : kND * K::TP + p;   // (+ 16 s below: 64 dump slots)
+    }
+    constexpr int DPI = 64 / K::TW;                       // dx planes per store instruction
+    const int st_px = lane % K::TW, st_dx = lane / K::TW;
+    const int st_voff = (y < H && x0 + st_px < W) ? (st_dx * plane + y * W + x0 + st_px) * 2 : kDead;
+#pragma unroll 1
+    for (int dyi = 0; dyi < kND; ++dyi) {
+        const unsigned char *wrow = win + (wave + dyi) * K::WROW;
+        f4v acc[K::NSEG][2];
+#pragma unroll
+        for (int s = 0; s < K::NSEG; ++s)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                acc[s][h] = f4v{0.f, 0.f, 0.f, 0.f};
+                const int col = 16 * s + 8 * h + p;       // window column of this lane's q
+#pragma unroll
+                for (int kb = 0; kb < K::NKB; ++kb) {
+                    const u4v bv = *reinterpret_cast<const u4v *>(wrow + K::pix(col, 4 * kb + kg));
+                    acc[s][h] = Mma<T>::run(a[s][kb], bv, acc[s][h]);
+                }
+            }
+        if (dbg & 4) {   // no T tile, no stores: one store keeps the MFMAs alive
+            if (dyi == 8 && acc[0][0][0] + acc[K::NSEG - 1][1][3] == 123.f) tt[0] = 1.f;
+            continue;
+        }
+#pragma unroll
+        for (int s = 0; s < K::NSEG; ++s)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) tt[t_slot[j] + 16 * s] = low ? acc[s][0][j] : acc[s][1][j];
+        if (dbg & 8) continue;   // no read-back, no stores
+        // whole plane rows: lane = (dx sub-plane, pixel); scale, LeakyReLU, one rounding
+#pragma unroll
+        for (int i = 0; i < (kND + DPI - 1) / DPI; ++i) {
+            const int dxi = i * DPI + st_dx;
+            const float q = tt[min(dxi, kND - 1) * K::TP + st_px] * inv_nelems;
+            const float v = q > 0.f ? q : q * slope;
+            T t;
+            st(&t, v);
+            unsigned short bits;
+            __builtin_memcpy(&bits, &t, 2);
+            __builtin_amdgcn_raw_buffer_store_b16(bits, ro, dxi < kND ? st_voff : kDead,
+                                                  __builtin_amdgcn_readfirstlane((dyi * kND) * plane * 2) +
+                                                      (i * DPI) * plane * 2,
+                                                  0);
+        }
+    }
+#endif
+}
+
+template <typename K, typename T>
+int launch_fwd_mfma(const char *name, const void *in1, const void *in2, void *outp, const CorrGeom &g,
+                    float slope, int64_t obs, hipStream_t s) {
+    const int tiles_x = (g.W + K::TW - 1) / K::TW, tiles_y = (g.H + K::TH - 1) / K::TH;
+    const int64_t blocks = static_cast<int64_t>(g.B) * tiles_x * tiles_y;
+    if (blocks > 0x7fffffff) return CERB_ETOOLARGE;
+    static std::atomic<int> lds_set{0};
+    if (!lds_set.load(std::memory_order_acquire)) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(corr_fwd_d4_mfma_kernel<K, T>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                 static_cast<int>(K::LDS_BYTES));
+        if (e != hipSuccess) return static_cast<int>(e);
+        lds_set.store(1, std::memory_order_release);
+    }
+    note_kernel(0, name);
+    hipLaunchKernelGGL((corr_fwd_d4_mfma_kernel<K, T>), dim3(static_cast<unsigned>(blocks)), dim3(K::THREADS),
+                       K::LDS_BYTES, s, static_cast<const T *>(in1), static_cast<const T *>(in2),
+                       static_cast<T *>(outp), g.C, g.H, g.W, tiles_x, tiles_y, slope, obs, debug_mask());
+    return launch_status();
+}
+
+template <typename T>
+int fwd_pick(const void *in1, const void *in2, void *out, const CorrGeom &g, float slope, int64_t obs,
+             hipStream_t s) {
+    if (g.C <= 32)
+        return launch_fwd_mfma<FwdMfmaCfg<1>, T>("corr_fwd_d4_mfma_4x64", in1, in2, out, g, slope, obs, s);
+    if (g.C <= 64)
+        return launch_fwd_mfma<FwdMfmaCfg<2>, T>("corr_fwd_d4_mfma_4x32", in1, in2, out, g, slope, obs, s);
+    return CERB_EUNSUPPORTED;
+}
+
 template <typename T>
 int launch(const void *in1, const void *in2, const void *gout, void *gin1, void *gin2,
            const CorrGeom &g, hipStream_t s) {
@@ -254,6 +480,16 @@ int corr_mfma_backward(const void *in1, const void *in2, const void *gout, void 
     switch (dtype) {
         case CERB_F16: return launch<__half>(in1, in2, gout, gin1, gin2, g, s);
         case CERB_BF16: return launch<hip_bfloat16>(in1, in2, gout, gin1, gin2, g, s);
+        default: return CERB_EUNSUPPORTED;
+    }
+}
+
+// forward, 16-bit storage, C <= 64 (CERB_EUNSUPPORTED otherwise: the caller keeps its VALU kernels)
+int corr_mfma_forward(const void *in1, const void *in2, void *out, const CorrGeom &g, float slope,
+                      int64_t obs, int dtype, hipStream_t s) {
+    switch (dtype) {
+        case CERB_F16: return fwd_pick<__half>(in1, in2, out, g, slope, obs, s);
+        case CERB_BF16: return fwd_pick<hip_bfloat16>(in1, in2, out, g, slope, obs, s);
         default: return CERB_EUNSUPPORTED;
     }
 }

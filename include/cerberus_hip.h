@@ -185,11 +185,13 @@ int cerberus_area_resize(const void *src, void *dst, int64_t planes, int H, int 
  *   "corr_force_generic" : 1 = always use the generic kernels (testing)
  *   "corr_fwd_variant"   : 0 = auto, 1..8 = force one register-staged forward variant,
  *                          9..13 = the LDS-DMA variants (fp32, W % 4 == 0) with 1, 2, 4, 8,
- *                          16 channel groups
+ *                          16 channel groups, 14 = the matrix-core kernel (fp16 / bf16 storage,
+ *                          C <= 64; auto uses it for 16 < C <= 64)
  *   "corr_bwd_variant"   : 0 = auto, 1 = all 81 displacements per lane (register-staged),
  *                          2/3 = three displacement groups, 4 / 5 = LDS-DMA with the 8x64 /
  *                          16x32 tile (fp32, W % 4 == 0), 6..9 = displacement-row streaming
- *                          (4 configurations), 10 = the same walking down a column of tiles
+ *                          (4 configurations), 10 = the same walking down a column of tiles,
+ *                          11 = the matrix-core kernel (fp16 / bf16 storage; auto uses it)
  *   "corr_bwd_cslice"    : 0 = auto, else channels per backward workgroup
  *   "warp_pair_taps"     : warp gather variant (0 default, 1 paired everywhere, 2 unpaired)
  *   "warp_tile_ranges"   : channel ranges per warp-backward tile (0 auto)

@@ -651,3 +651,41 @@ def test_mfma_backward_equals_the_valu_backward_up_to_output_rounding(dtype, ulp
             tol = 2e-3 if dtype == torch.float16 else 1.6e-2
             assert rel_err(g1.double().cpu().numpy(), r1) < tol
             assert rel_err(g2.double().cpu().numpy(), r2) < tol
+
+
+@pytest.mark.parametrize("dtype,ulp", [(torch.float16, 2.0 ** -10), (torch.bfloat16, 2.0 ** -7)])
+def test_mfma_forward_equals_the_valu_forward_up_to_output_rounding(dtype, ulp):
+    """16-bit storage, C <= 64: the forward runs on the matrix cores (pixel x window-column
+    products per 32 channels, the wanted diagonals extracted through a per-wave LDS tile).  Same
+    exact products, fp32 sums, one rounding: at most one unit of the output's last place from
+    the VALU kernel.  Covers both tile shapes (C <= 32: 4 x 64, C <= 64: 4 x 32), ragged tiles,
+    odd channel counts, LeakyReLU fused, the strided (concat-buffer) output, and NaN / Inf
+    reaching exactly the same outputs."""
+    p = (4, 1, 4, 1, 1, 1)
+    for k, shp in enumerate([(2, 32, 9, 68), (1, 24, 17, 132), (3, 7, 5, 12), (1, 64, 33, 64),
+                             (2, 40, 6, 200), (1, 33, 4, 36)]):
+        B, C, H, W = shp
+        a1 = hash_uniform(shp, 940 + k)
+        a2 = hash_uniform(shp, 950 + k)
+        a1[0, 0, H // 2, W // 3] = np.inf
+        a2[-1, C - 1, 0, W - 1] = np.nan
+        x1 = torch.from_numpy(a1).to(dtype).to(DEV)
+        x2 = torch.from_numpy(a2).to(dtype).to(DEV)
+        _lib.set_option("corr_fwd_variant", 0 if C > 16 else 14)   # auto skips it for C <= 16
+        out = torch.ops.cerberus.correlation_leaky(x1, x2, *p, 0.1)
+        assert _lib.last_kernel(0).startswith("corr_fwd_d4_mfma"), _lib.last_kernel(0)
+        buf = torch.zeros(B, 81 + 5, H, W, dtype=dtype, device=DEV)
+        torch.ops.cerberus.correlation_leaky_into(buf, x1, x2, 3, *p, 0.1)
+        _lib.set_option("corr_fwd_variant", 7)
+        try:
+            ref = torch.ops.cerberus.correlation_leaky(x1, x2, *p, 0.1)
+            assert "mfma" not in _lib.last_kernel(0)
+        finally:
+            _lib.set_option("corr_fwd_variant", 0)
+        assert torch.equal(torch.isnan(out), torch.isnan(ref)), shp
+        assert torch.equal(torch.isinf(out), torch.isinf(ref)), shp
+        fin = torch.isfinite(ref)
+        scale = float(ref[fin].float().abs().max())
+        assert float((out[fin].float() - ref[fin].float()).abs().max()) <= ulp * scale, shp
+        assert torch.equal(buf[:, 3:84].view(torch.int16), out.view(torch.int16))
+        assert float(buf[:, :3].abs().max()) == 0.0 and float(buf[:, 84:].abs().max()) == 0.0
