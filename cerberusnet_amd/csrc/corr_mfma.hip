@@ -86,15 +86,17 @@ struct BwdMfmaCfg {
     static constexpr int THREADS = 64 * TH;
     static constexpr size_t LDS_BYTES = 2 * (WIN + TH * TW * AROW);
     static_assert((CSTR * 2) % 128 == 16, "channel stride must stagger the banks");
-    static_assert((CS * WR * UPR) % THREADS == 0, "window units per thread");
 };
 
 template <typename T>
 __global__ __launch_bounds__(BwdMfmaCfg::THREADS, 2) void corr_bwd_d4_mfma_kernel(
     const T *__restrict__ x1, const T *__restrict__ x2, const T *__restrict__ gout,
     T *__restrict__ gin1, T *__restrict__ gin2, int C, int H, int W, int tiles_x, int tiles_y,
-    int nslice) {
+    int nslice, int dbg) {
 #if defined(__HIP_DEVICE_COMPILE__)
+#ifndef CERB_ABLATE
+    dbg = 0;   // timing ablations exist in -DCERB_ABLATE builds only (tools/ablate_mfma.py)
+#endif
     using K = BwdMfmaCfg;
     extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
     unsigned short *win = smem;                 // [CS][WR][WC] halves, channel stride CSTR
@@ -122,48 +124,52 @@ __global__ __launch_bounds__(BwdMfmaCfg::THREADS, 2) void corr_bwd_d4_mfma_kerne
     // ---- this wave's row: gradOutput addressing (lane = pixel) ----
     const int y = y0 + wave;
     const int gx = x0 + lane;
-    // side 0: g[e][y][x] = gO[e][y][x];  side 1: g[e][y][x] = gO[80 - e][y + ey][x + ex]
-    auto g_load = [&](int eyi, int exi) -> unsigned short {
-        const int e = eyi * kND + exi;
-        const int d = side ? kND * kND - 1 - e : e;
-        const int yy = side ? y + eyi - kD : y, xx = side ? gx + exi - kD : gx;
-        const bool rok = yy >= 0 && yy < H && y < H;                         // wave-uniform
-        const int soff = __builtin_amdgcn_readfirstlane(rok ? (d * plane + yy * W) * 2 : 0);
-        const int voff = (rok && xx >= 0 && xx < W) ? xx * 2 : kDead;
-        return __builtin_amdgcn_raw_buffer_load_b16(rsrc_go, voff, soff, 0);
-    };
-    // all 81 values of this lane's pixel, in flight during the window copy: the displacement
-    // loop below then never waits on global memory
+    // side 0: g[e][y][x] = gO[e][y][x];  side 1: g[e][y][x] = gO[80 - e][y + ey][x + ex].
+    // All 81 values of this lane's pixel are loaded up front (in flight during the window copy:
+    // the displacement loop below never waits on global memory).  Addressing is split so that a
+    // load costs no vector arithmetic: nine per-lane column offsets (one per ex), a scalar row /
+    // plane offset per ey, and the plane step per ex added on the scalar unit.
+    int g_voff[kND];
+#pragma unroll
+    for (int i = 0; i < kND; ++i) {
+        const int xx = side ? gx + i - kD : gx;
+        g_voff[i] = (xx >= 0 && xx < W) ? xx * 2 : kDead;
+    }
+    const int g_step = side ? -plane * 2 : plane * 2;   // plane step per ex
     unsigned short gv[kND][kND];
 #pragma unroll
-    for (int j = 0; j < kND; ++j)
+    for (int j = 0; j < kND; ++j) {
+        const int yy = side ? y + j - kD : y;
+        const bool rok = yy >= 0 && yy < H && y < H;     // wave-uniform
+        const int d0 = side ? kND * kND - 1 - j * kND : j * kND;
+        const int row_off = __builtin_amdgcn_readfirstlane((d0 * plane + yy * W) * 2);
 #pragma unroll
-        for (int i = 0; i < kND; ++i) gv[j][i] = g_load(j, i);
+        for (int i = 0; i < kND; ++i) {
+            gv[j][i] = 0;
+            if (rok && !(dbg & 1)) gv[j][i] = __builtin_amdgcn_raw_buffer_load_b16(rsrc_go, g_voff[i], row_off + i * g_step, 0);
+        }
+    }
 
     // ---- the source window of the slice's channels -> LDS; zero the A rows ----
+    // A thread owns ONE 8-byte unit position (row, 4 columns) of the window for all channels: the
+    // channel is the scalar offset of the load and an immediate offset of the LDS store.
     {
-        constexpr int UNITS = K::CS * K::WR * K::UPR, PER = UNITS / K::THREADS, BATCH = 30;
-        static_assert(PER % BATCH == 0, "window copy batches");
-#pragma unroll 1
-        for (int i0 = 0; i0 < PER; i0 += BATCH) {
-            u2v v[BATCH];
+        constexpr int POS = K::WR * K::UPR;                 // unit positions of one channel's window
+        static_assert(POS <= K::THREADS, "one unit position per thread");
+        const int row = tid / K::UPR, un = tid % K::UPR;
+        const int sy = y0 - kD + row, sx = x0 - kD + 4 * un;
+        const bool ok = tid < POS && un < (K::TW + 2 * kD) / 4 && sy >= 0 && sy < H && sx >= 0 && sx < W;
+        const int w_voff = ok ? (sy * W + sx) * 2 : kDead;
+        u2v v[K::CS];
 #pragma unroll
-            for (int i = 0; i < BATCH; ++i) {
-                const int u = tid + K::THREADS * (i0 + i);
-                const int ch = u / (K::WR * K::UPR), rem = u % (K::WR * K::UPR);
-                const int row = rem / K::UPR, un = rem % K::UPR;
-                const int sy = y0 - kD + row, sx = x0 - kD + 4 * un;
-                const bool ok = un < (K::TW + 2 * kD) / 4 && sy >= 0 && sy < H && sx >= 0 && sx < W &&
-                                c_begin + ch < C;
-                v[i] = __builtin_amdgcn_raw_buffer_load_b64(
-                    rsrc_src, ok ? ((c_begin + ch) * plane + sy * W + sx) * 2 : kDead, 0, 0);
-            }
+        for (int ch = 0; ch < K::CS; ++ch) {
+            v[ch] = u2v{0, 0};
+            if (c_begin + ch < C && !(dbg & 2))             // uniform
+                v[ch] = __builtin_amdgcn_raw_buffer_load_b64(rsrc_src, w_voff, (c_begin + ch) * plane * 2, 0);
+        }
+        if (tid < POS && !(dbg & 4)) {
 #pragma unroll
-            for (int i = 0; i < BATCH; ++i) {
-                const int u = tid + K::THREADS * (i0 + i);
-                const int ch = u / (K::WR * K::UPR), rem = u % (K::WR * K::UPR);
-                *reinterpret_cast<u2v *>(win + ch * K::CSTR + rem * 4) = v[i];
-            }
+            for (int ch = 0; ch < K::CS; ++ch) *reinterpret_cast<u2v *>(win + ch * K::CSTR + tid * 4) = v[ch];
         }
         unsigned short *mine = arow + (wave * K::TW + lane) * K::AROW;
 #pragma unroll
@@ -185,7 +191,9 @@ __global__ __launch_bounds__(BwdMfmaCfg::THREADS, 2) void corr_bwd_d4_mfma_kerne
     for (int eyi = 0; eyi < kND; ++eyi) {
         // this lane's pixel: the nine g values of the row into its band slots
 #pragma unroll
-        for (int i = 0; i < kND; ++i) my_arow[i] = gv[eyi][i];
+        for (int i = 0; i < kND; ++i)
+            if (!(dbg & 8)) my_arow[i] = gv[eyi][i];
+        if (dbg & 16) { if (gv[eyi][0] + gv[eyi][8] == 77) acc[0][0][0] += 1.f; continue; }
         // (same wave wrote the rows it reads: program order + the compiler's lgkmcnt wait)
         u4v a[K::NSEG];
 #pragma unroll
@@ -204,6 +212,7 @@ __global__ __launch_bounds__(BwdMfmaCfg::THREADS, 2) void corr_bwd_d4_mfma_kerne
 
     // ---- D[pixel][channel] -> gradInput[c][y][x]: 4 consecutive pixels of one channel per lane ----
     if (y >= H) return;
+    if ((dbg & 32) && acc[0][0][0] + acc[3][1][3] != 12345.f) return;
     const float inv_nelems = 1.0f / static_cast<float>(C);
 #pragma unroll
     for (int cb = 0; cb < K::CB; ++cb) {
@@ -467,7 +476,7 @@ int launch(const void *in1, const void *in2, const void *gout, void *gin1, void 
     hipLaunchKernelGGL((corr_bwd_d4_mfma_kernel<T>), dim3(static_cast<unsigned>(blocks)), dim3(K::THREADS),
                        K::LDS_BYTES, s, static_cast<const T *>(in1), static_cast<const T *>(in2),
                        static_cast<const T *>(gout), static_cast<T *>(gin1), static_cast<T *>(gin2), g.C,
-                       g.H, g.W, tiles_x, tiles_y, nslice);
+                       g.H, g.W, tiles_x, tiles_y, nslice, debug_mask());
     return launch_status();
 }
 
