@@ -92,25 +92,31 @@ template <typename T>
 __global__ __launch_bounds__(BwdMfmaCfg::THREADS, 2) void corr_bwd_d4_mfma_kernel(
     const T *__restrict__ x1, const T *__restrict__ x2, const T *__restrict__ gout,
     T *__restrict__ gin1, T *__restrict__ gin2, int C, int H, int W, int tiles_x, int tiles_y,
-    int nslice, int dbg) {
+    int nslice, int nwalk, int dbg) {
 #if defined(__HIP_DEVICE_COMPILE__)
 #ifndef CERB_ABLATE
     dbg = 0;   // timing ablations exist in -DCERB_ABLATE builds only (tools/ablate_mfma.py)
 #endif
     using K = BwdMfmaCfg;
     extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
-    unsigned short *win = smem;                 // [CS][WR][WC] halves, channel stride CSTR
+    unsigned short *win = smem;                 // [CS][WR ring slots][WC] halves, channel stride CSTR
     unsigned short *arow = smem + K::WIN;       // [TH][TW][AROW]
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
 
+    // A workgroup WALKS DOWN nwalk vertically adjacent tiles of one (item, column, channel slice,
+    // side): the 12 window rows live in a ring (slot = (row + 4) mod 12), so every further tile
+    // loads 4 new rows instead of 12 (window traffic 3x -> ~1x the source), and those loads, as
+    // well as the next tile's 81 gradOutput values, are in flight while the current tile computes.
+    const int walks_y = (tiles_y + nwalk - 1) / nwalk;
     int bid = xcd_chunk(blockIdx.x, gridDim.x);
     const int side = __builtin_amdgcn_readfirstlane(bid & 1); bid >>= 1;   // 0: gradInput1
     const int slice = __builtin_amdgcn_readfirstlane(bid % nslice); bid /= nslice;
     const int tx = __builtin_amdgcn_readfirstlane(bid % tiles_x); bid /= tiles_x;
-    const int ty = __builtin_amdgcn_readfirstlane(bid % tiles_y);
-    const int b = __builtin_amdgcn_readfirstlane(bid / tiles_y);
-    const int x0 = tx * K::TW, y0 = ty * K::TH;
+    const int wy = __builtin_amdgcn_readfirstlane(bid % walks_y);
+    const int b = __builtin_amdgcn_readfirstlane(bid / walks_y);
+    const int ty_begin = wy * nwalk, ty_end = min(tiles_y, ty_begin + nwalk);
+    const int x0 = tx * K::TW;
     const int c_begin = slice * K::CS;
     const int plane = H * W;
 
@@ -121,14 +127,11 @@ __global__ __launch_bounds__(BwdMfmaCfg::THREADS, 2) void corr_bwd_d4_mfma_kerne
     const __amdgpu_buffer_rsrc_t rsrc_go =
         uniform_rsrc(gout + static_cast<int64_t>(b) * (kND * kND) * plane, kND * kND * plane * 2);
 
-    // ---- this wave's row: gradOutput addressing (lane = pixel) ----
-    const int y = y0 + wave;
-    const int gx = x0 + lane;
+    // ---- gradOutput addressing (lane = pixel of this wave's row) ----
     // side 0: g[e][y][x] = gO[e][y][x];  side 1: g[e][y][x] = gO[80 - e][y + ey][x + ex].
-    // All 81 values of this lane's pixel are loaded up front (in flight during the window copy:
-    // the displacement loop below never waits on global memory).  Addressing is split so that a
-    // load costs no vector arithmetic: nine per-lane column offsets (one per ex), a scalar row /
-    // plane offset per ey, and the plane step per ex added on the scalar unit.
+    // A load costs no vector arithmetic: nine per-lane column offsets (one per ex), a scalar
+    // row / plane offset per ey, and the plane step per ex added on the scalar unit.
+    const int gx = x0 + lane;
     int g_voff[kND];
 #pragma unroll
     for (int i = 0; i < kND; ++i) {
@@ -137,29 +140,35 @@ __global__ __launch_bounds__(BwdMfmaCfg::THREADS, 2) void corr_bwd_d4_mfma_kerne
     }
     const int g_step = side ? -plane * 2 : plane * 2;   // plane step per ex
     unsigned short gv[kND][kND];
+    auto load_g = [&](int y) {
 #pragma unroll
-    for (int j = 0; j < kND; ++j) {
-        const int yy = side ? y + j - kD : y;
-        const bool rok = yy >= 0 && yy < H && y < H;     // wave-uniform
-        const int d0 = side ? kND * kND - 1 - j * kND : j * kND;
-        const int row_off = __builtin_amdgcn_readfirstlane((d0 * plane + yy * W) * 2);
+        for (int j = 0; j < kND; ++j) {
+            const int yy = side ? y + j - kD : y;
+            const bool rok = yy >= 0 && yy < H && y < H;     // wave-uniform
+            const int d0 = side ? kND * kND - 1 - j * kND : j * kND;
+            const int row_off = __builtin_amdgcn_readfirstlane((d0 * plane + yy * W) * 2);
 #pragma unroll
-        for (int i = 0; i < kND; ++i) {
-            gv[j][i] = 0;
-            if (rok && !(dbg & 1)) gv[j][i] = __builtin_amdgcn_raw_buffer_load_b16(rsrc_go, g_voff[i], row_off + i * g_step, 0);
+            for (int i = 0; i < kND; ++i) {
+                gv[j][i] = 0;
+                if (rok && !(dbg & 1))
+                    gv[j][i] = __builtin_amdgcn_raw_buffer_load_b16(rsrc_go, g_voff[i], row_off + i * g_step, 0);
+            }
         }
-    }
+    };
+    load_g(ty_begin * K::TH + wave);   // in flight during the window copy
 
-    // ---- the source window of the slice's channels -> LDS; zero the A rows ----
-    // A thread owns ONE 8-byte unit position (row, 4 columns) of the window for all channels: the
-    // channel is the scalar offset of the load and an immediate offset of the LDS store.
+    // ---- first tile: the whole 12-row window -> ring; zero the A rows ----
+    // A thread owns ONE 8-byte unit position (row, 4 columns) for all channels: the channel is the
+    // scalar offset of the load and an immediate offset of the LDS store.
     {
-        constexpr int POS = K::WR * K::UPR;                 // unit positions of one channel's window
+        constexpr int POS = K::WR * K::UPR;
         static_assert(POS <= K::THREADS, "one unit position per thread");
+        const int y0 = ty_begin * K::TH;
         const int row = tid / K::UPR, un = tid % K::UPR;
         const int sy = y0 - kD + row, sx = x0 - kD + 4 * un;
         const bool ok = tid < POS && un < (K::TW + 2 * kD) / 4 && sy >= 0 && sy < H && sx >= 0 && sx < W;
         const int w_voff = ok ? (sy * W + sx) * 2 : kDead;
+        const int slot = (y0 + row) % K::WR;                // ring slot of window row (sy + 4)
         u2v v[K::CS];
 #pragma unroll
         for (int ch = 0; ch < K::CS; ++ch) {
@@ -168,8 +177,9 @@ __global__ __launch_bounds__(BwdMfmaCfg::THREADS, 2) void corr_bwd_d4_mfma_kerne
                 v[ch] = __builtin_amdgcn_raw_buffer_load_b64(rsrc_src, w_voff, (c_begin + ch) * plane * 2, 0);
         }
         if (tid < POS && !(dbg & 4)) {
+            unsigned short *w = win + slot * K::WC + un * 4;
 #pragma unroll
-            for (int ch = 0; ch < K::CS; ++ch) *reinterpret_cast<u2v *>(win + ch * K::CSTR + tid * 4) = v[ch];
+            for (int ch = 0; ch < K::CS; ++ch) *reinterpret_cast<u2v *>(w + ch * K::CSTR) = v[ch];
         }
         unsigned short *mine = arow + (wave * K::TW + lane) * K::AROW;
 #pragma unroll
@@ -177,55 +187,97 @@ __global__ __launch_bounds__(BwdMfmaCfg::THREADS, 2) void corr_bwd_d4_mfma_kerne
     }
     __syncthreads();
 
-    // ---- 9 vertical displacements x (4 segments x CB channel blocks) MFMAs ----
+    // next tile's 4 new rows: thread -> (unit position of the 4 x 20 units, every 3rd channel)
+    constexpr int NPOS = K::TH * K::UPR, NCG = K::THREADS / NPOS, NPF = (K::CS + NCG - 1) / NCG;
+    const int pf_pos = tid % NPOS, pf_cg = tid / NPOS;      // pf_cg == NCG: idle thread
+    const int pf_row = pf_pos / K::UPR, pf_un = pf_pos % K::UPR;
+    const int pf_sx = x0 - kD + 4 * pf_un;
+    const bool pf_col_ok = pf_cg < NCG && pf_un < (K::TW + 2 * kD) / 4 && pf_sx >= 0 && pf_sx < W;
+
     const int p = lane & 15, kg = lane >> 4;
-    f4v acc[K::NSEG][K::CB];
-#pragma unroll
-    for (int s = 0; s < K::NSEG; ++s)
-#pragma unroll
-        for (int cb = 0; cb < K::CB; ++cb) acc[s][cb] = f4v{0.f, 0.f, 0.f, 0.f};
     unsigned short *my_arow = arow + (wave * K::TW + lane) * K::AROW + p;   // band slots p .. p + 8
     const unsigned short *a_rd = arow + (wave * K::TW + p) * K::AROW + 8 * (kg < 3 ? kg : 0);
-    const unsigned short *b_rd = win + p * K::CSTR + wave * K::WC + 8 * kg;
-#pragma unroll
-    for (int eyi = 0; eyi < kND; ++eyi) {
-        // this lane's pixel: the nine g values of the row into its band slots
-#pragma unroll
-        for (int i = 0; i < kND; ++i)
-            if (!(dbg & 8)) my_arow[i] = gv[eyi][i];
-        if (dbg & 16) { if (gv[eyi][0] + gv[eyi][8] == 77) acc[0][0][0] += 1.f; continue; }
-        // (same wave wrote the rows it reads: program order + the compiler's lgkmcnt wait)
-        u4v a[K::NSEG];
-#pragma unroll
-        for (int s = 0; s < K::NSEG; ++s) {
-            a[s] = *reinterpret_cast<const u4v *>(a_rd + s * 16 * K::AROW);
-            if (kg == 3) a[s] = u4v{0, 0, 0, 0};   // k = 24..31: outside every band
-        }
-#pragma unroll
-        for (int cb = 0; cb < K::CB; ++cb)
-#pragma unroll
-            for (int s = 0; s < K::NSEG; ++s) {
-                const u4v bv = *reinterpret_cast<const u4v *>(b_rd + cb * 16 * K::CSTR + eyi * K::WC + 16 * s);
-                acc[s][cb] = Mma<T>::run(a[s], bv, acc[s][cb]);
-            }
-    }
-
-    // ---- D[pixel][channel] -> gradInput[c][y][x]: 4 consecutive pixels of one channel per lane ----
-    if (y >= H) return;
-    if ((dbg & 32) && acc[0][0][0] + acc[3][1][3] != 12345.f) return;
+    const unsigned short *b_lane = win + p * K::CSTR + 8 * kg;
     const float inv_nelems = 1.0f / static_cast<float>(C);
+
+    for (int ty = ty_begin; ty < ty_end; ++ty) {
+        const int y0 = ty * K::TH, y = y0 + wave;
+        const bool more = ty + 1 < ty_end;
+        // ---- prefetch the next tile's new window rows (rows y0 + 8 .. y0 + 11) into registers ----
+        u2v pf[NPF];
+        if (more) {
+            const int sy = y0 + K::TH + kD + pf_row;
+            const int base = (pf_col_ok && sy < H) ? (sy * W + pf_sx) * 2 : kDead;
 #pragma unroll
-    for (int cb = 0; cb < K::CB; ++cb) {
-        const int c = c_begin + cb * 16 + p;
-#pragma unroll
-        for (int s = 0; s < K::NSEG; ++s) {
-            const int x = x0 + 16 * s + 4 * kg;
-            const f4v d = acc[s][cb];
-            const u2v o = {Mma<T>::pack2(d[0] * inv_nelems, d[1] * inv_nelems),
-                           Mma<T>::pack2(d[2] * inv_nelems, d[3] * inv_nelems)};
-            __builtin_amdgcn_raw_buffer_store_b64(o, rsrc_dst, (c < C && x < W) ? (c * plane + y * W + x) * 2 : kDead,
-                                                  0, 0);
+            for (int k = 0; k < NPF; ++k) {
+                const int ch = pf_cg + NCG * k;
+                const bool on = ch < K::CS && c_begin + ch < C;
+                pf[k] = __builtin_amdgcn_raw_buffer_load_b64(rsrc_src, on ? base + (c_begin + ch) * plane * 2 : kDead, 0, 0);
+            }
         }
+        // ---- 9 vertical displacements x (4 segments x CB channel blocks) MFMAs ----
+        f4v acc[K::NSEG][K::CB];
+#pragma unroll
+        for (int s = 0; s < K::NSEG; ++s)
+#pragma unroll
+            for (int cb = 0; cb < K::CB; ++cb) acc[s][cb] = f4v{0.f, 0.f, 0.f, 0.f};
+        int slot = __builtin_amdgcn_readfirstlane((y0 + wave) % K::WR);   // ring slot of window row y - 4
+#pragma unroll
+        for (int eyi = 0; eyi < kND; ++eyi) {
+            // this lane's pixel: the nine g values of the row into its band slots
+#pragma unroll
+            for (int i = 0; i < kND; ++i)
+                if (!(dbg & 8)) my_arow[i] = gv[eyi][i];
+            if (!(dbg & 16)) {
+                // (same wave wrote the rows it reads: program order + the compiler's lgkmcnt wait)
+                u4v a[K::NSEG];
+#pragma unroll
+                for (int s = 0; s < K::NSEG; ++s) {
+                    a[s] = *reinterpret_cast<const u4v *>(a_rd + s * 16 * K::AROW);
+                    if (kg == 3) a[s] = u4v{0, 0, 0, 0};   // k = 24..31: outside every band
+                }
+                const unsigned short *b_rd = b_lane + slot * K::WC;
+#pragma unroll
+                for (int cb = 0; cb < K::CB; ++cb)
+#pragma unroll
+                    for (int s = 0; s < K::NSEG; ++s) {
+                        const u4v bv = *reinterpret_cast<const u4v *>(b_rd + cb * 16 * K::CSTR + 16 * s);
+                        acc[s][cb] = Mma<T>::run(a[s], bv, acc[s][cb]);
+                    }
+            }
+            slot = slot + 1 == K::WR ? 0 : slot + 1;
+        }
+        // ---- the next tile's gradOutput values: in flight during the stores and the ring update ----
+        if (more) load_g(y + K::TH);
+        // ---- D[pixel][channel] -> gradInput[c][y][x]: 4 consecutive pixels of one channel per lane ----
+        if (y < H && !((dbg & 32) && acc[0][0][0] + acc[3][1][3] != 12345.f)) {
+#pragma unroll
+            for (int cb = 0; cb < K::CB; ++cb) {
+                const int c = c_begin + cb * 16 + p;
+#pragma unroll
+                for (int s = 0; s < K::NSEG; ++s) {
+                    const int x = x0 + 16 * s + 4 * kg;
+                    const f4v d = acc[s][cb];
+                    const u2v o = {Mma<T>::pack2(d[0] * inv_nelems, d[1] * inv_nelems),
+                                   Mma<T>::pack2(d[2] * inv_nelems, d[3] * inv_nelems)};
+                    __builtin_amdgcn_raw_buffer_store_b64(
+                        o, rsrc_dst, (c < C && x < W) ? (c * plane + y * W + x) * 2 : kDead, 0, 0);
+                }
+            }
+        }
+        if (!more) break;
+        // ---- ring update: the new rows replace the 4 oldest (rows y0 - 4 .. y0 - 1) ----
+        __syncthreads();   // every wave is done reading this tile's window
+        if (pf_cg < NCG) {
+            const int nslot = (y0 + K::TH + 2 * kD + pf_row) % K::WR;   // window row (y0 + 8 + pf_row) + 4
+            unsigned short *w = win + nslot * K::WC + pf_un * 4;
+#pragma unroll
+            for (int k = 0; k < NPF; ++k) {
+                const int ch = pf_cg + NCG * k;
+                if (ch < K::CS && !(dbg & 4)) *reinterpret_cast<u2v *>(w + ch * K::CSTR) = pf[k];
+            }
+        }
+        __syncthreads();
     }
 #endif
 }
@@ -462,7 +514,14 @@ int launch(const void *in1, const void *in2, const void *gout, void *gin1, void 
     using K = BwdMfmaCfg;
     const int tiles_x = (g.W + K::TW - 1) / K::TW, tiles_y = (g.H + K::TH - 1) / K::TH;
     const int nslice = (g.C + K::CS - 1) / K::CS;
-    const int64_t blocks = static_cast<int64_t>(g.B) * tiles_x * tiles_y * nslice * 2;
+    // tiles a workgroup walks down: as many as still leave ~512 workgroups = ONE round of 2 per
+    // CU, every workgroup walking.  Measured (4 pairs, fp16, us by tiles per walk 1 / 2 / 4 / 8):
+    // 32x128x256 26.9 / 23.6 / 30.6 / 52.9, 64x128x256 48.1 / 44.7 / 39.6 / 55.7, 32x256x512
+    // 90.8 / 84.2 / 78.3 / 72.8: the best is where the launch is one round.
+    const int64_t cols = static_cast<int64_t>(g.B) * tiles_x * nslice * 2;
+    int nwalk = static_cast<int>(std::min<int64_t>(tiles_y, std::max<int64_t>(1, cols * tiles_y / 512)));
+    if (const int forced = option(OPT_CORR_BWD_CSLICE)) nwalk = std::max(1, std::min(forced, tiles_y));
+    const int64_t blocks = cols * ((tiles_y + nwalk - 1) / nwalk);
     if (blocks > 0x7fffffff) return CERB_ETOOLARGE;
     static std::atomic<int> lds_set{0};
     if (!lds_set.load(std::memory_order_acquire)) {
@@ -476,7 +535,7 @@ int launch(const void *in1, const void *in2, const void *gout, void *gin1, void 
     hipLaunchKernelGGL((corr_bwd_d4_mfma_kernel<T>), dim3(static_cast<unsigned>(blocks)), dim3(K::THREADS),
                        K::LDS_BYTES, s, static_cast<const T *>(in1), static_cast<const T *>(in2),
                        static_cast<const T *>(gout), static_cast<T *>(gin1), static_cast<T *>(gin2), g.C,
-                       g.H, g.W, tiles_x, tiles_y, nslice, debug_mask());
+                       g.H, g.W, tiles_x, tiles_y, nslice, nwalk, debug_mask());
     return launch_status();
 }
 
