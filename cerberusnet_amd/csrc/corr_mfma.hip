@@ -299,6 +299,10 @@ __global__ __launch_bounds__(BwdMfmaCfg::THREADS, 2) void corr_bwd_d4_mfma_kerne
 // A wave owns one row: per dy 8 MFMAs; the wanted diagonals are scaled, LeakyReLU'd, rounded
 // and passed through a per-wave LDS tile to become whole 128 / 64-byte plane rows.
 // NKB = 32-channel blocks held at once (C <= 32 NKB); the tile is 4 rows x 64 / NKB pixels.
+// (Walking down a column of tiles as the backward does -- x2 rows in a ring, the next tile's rows
+// prefetched -- was measured and dropped: 32x256x512 55.6 -> 53.5 us, but 32x128x256 16.4 -> 18.2
+// and 64x64x128 9.7 -> 11.3: the forward's traffic is dominated by its 81-plane output, not by
+// the window halo.)
 template <int NKB_>
 struct FwdMfmaCfg {
     static constexpr int NKB = NKB_, NSEG = 4 / NKB, TW = 16 * NSEG, TH = 4;
@@ -464,10 +468,7 @@ __global__ __launch_bounds__(K::THREADS, 2) void corr_fwd_d4_mfma_kernel(
             const int dxi = i * DPI + st_dx;
             const float q = tt[min(dxi, kND - 1) * K::TP + st_px] * inv_nelems;
             const float v = q > 0.f ? q : q * slope;
-            T t;
-            st(&t, v);
-            unsigned short bits;
-            __builtin_memcpy(&bits, &t, 2);
+            const unsigned short bits = static_cast<unsigned short>(Mma<T>::pack2(v, v));   // one rounding instruction
             __builtin_amdgcn_raw_buffer_store_b16(bits, ro, dxi < kND ? st_voff : kDead,
                                                   __builtin_amdgcn_readfirstlane((dyi * kND) * plane * 2) +
                                                       (i * DPI) * plane * 2,
