@@ -13,6 +13,10 @@ mkdir -p $OUT
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/_stats -- python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline > $OUT/${TAG}_bench_under_rocprof.json 2> $OUT/_stats.err
 cp "$(find $OUT/_stats -name '*kernel_stats.csv' | head -1)" $OUT/${TAG}_kernel_stats.csv
 python3 tools/trace_by_grid.py "$(find $OUT/_stats -name '*kernel_trace.csv' | head -1)" > $OUT/${TAG}_kernel_trace_by_grid.csv
+# 1b. BASELINE config 5 (fp16, 2048x1024 pyramid): the matrix-core correlation kernels
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/_c5 -- python3 bench.py --dtype f16 --width 2048 --height 1024 --steps 20 --warmup 3 --no-cpu-baseline > $OUT/${TAG}_bench_under_rocprof_config5_f16.json 2> $OUT/_c5.err
+cp "$(find $OUT/_c5 -name '*kernel_stats.csv' | head -1)" $OUT/${TAG}_kernel_stats_config5_f16.csv
+python3 tools/trace_by_grid.py "$(find $OUT/_c5 -name '*kernel_trace.csv' | head -1)" > $OUT/${TAG}_kernel_trace_by_grid_config5_f16.csv
 # 2. every pyramid level on its own (one symbol serves several levels with different grids)
 for L in 0 1 2 3; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/_l$L -- python3 tools/prof_kernels.py --levels $L --warp --reps 20 > /dev/null 2> $OUT/_l$L.err
@@ -45,5 +49,5 @@ json.dump(res, open("%s/%s_fetch_size_calibration.json" % (out, tag), "w"), inde
 print(json.dumps(res, indent=1))
 PY
 fi
-rm -rf $OUT/_stats $OUT/_l? $OUT/_pmc_* $OUT/_calib $OUT/*.err $OUT/_calib.out
+rm -rf $OUT/_stats $OUT/_c5 $OUT/_l? $OUT/_pmc_* $OUT/_calib $OUT/*.err $OUT/_calib.out
 ls -la $OUT
