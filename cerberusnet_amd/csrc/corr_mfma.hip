@@ -33,10 +33,9 @@
 // channels of a B read start in different banks) + the A rows (12 KB): 2 workgroups / CU.
 //
 // Non-finite inputs: a band matrix has explicit zeros, and 0 * Inf = NaN inside the MFMA: an
-// Inf / NaN in the source reaches every pixel of its 16-pixel segment whose row window holds
-// it (up to 19 pixels away horizontally instead of 4).  Finite data -- every training step that
-// has not already diverged -- is unaffected; the VALU kernels (corr_bwd_variant = 1) keep the
-// reference's exact NaN reach.
+// Inf / NaN in the source would reach every pixel of its 16-pixel segment whose row window
+// holds it.  That can only add non-finite results, so a row with a non-finite accumulator is
+// recomputed tap by tap (see the kernel): NaN / Inf reach exactly the vector kernels' elements.
 #include <atomic>
 
 #include "common.h"
@@ -62,6 +61,9 @@ template <> struct Mma<__half> {
         const __half2 h = __floats2half2_rn(a, b);
         return __builtin_bit_cast(unsigned, h);
     }
+    static __device__ __forceinline__ float widen(unsigned short bits) {
+        return static_cast<float>(__builtin_bit_cast(_Float16, bits));
+    }
 };
 template <> struct Mma<hip_bfloat16> {
     static __device__ __forceinline__ f4v run(u4v a, u4v b, f4v c) {
@@ -71,6 +73,9 @@ template <> struct Mma<hip_bfloat16> {
         typedef float f2v __attribute__((ext_vector_type(2)));
         typedef __bf16 bf2v __attribute__((ext_vector_type(2)));
         return __builtin_bit_cast(unsigned, __builtin_convertvector(f2v{a, b}, bf2v));
+    }
+    static __device__ __forceinline__ float widen(unsigned short bits) {
+        return __uint_as_float(static_cast<unsigned>(bits) << 16);
     }
 };
 
@@ -249,8 +254,53 @@ __global__ __launch_bounds__(BwdMfmaCfg::THREADS, 2) void corr_bwd_d4_mfma_kerne
         }
         // ---- the next tile's gradOutput values: in flight during the stores and the ring update ----
         if (more) load_g(y + K::TH);
+        // ---- non-finite results: redo this row exactly ----
+        // The band matrix holds explicit zeros and 0 x Inf = NaN inside an MFMA, so an Inf / NaN of
+        // the source can spread over its whole 16-pixel segment.  It can only ADD non-finite
+        // results, never hide one: a row whose accumulators are all finite is right as it is, and
+        // a row with a non-finite accumulator (a diverged step) is recomputed tap by tap -- lane =
+        // pixel, the window and this pixel's 81 gradOutput values are still at hand -- so that
+        // NaN / Inf reach exactly the elements they reach in the vector kernels.
+        // (one test on the SUM of the lane's accumulators: NaN and Inf survive addition)
+        f4v tot = acc[0][0];
+#pragma unroll
+        for (int s = 0; s < K::NSEG; ++s)
+#pragma unroll
+            for (int cb = 0; cb < K::CB; ++cb)
+                if (s + cb) tot += acc[s][cb];
+        const float tsum = (tot[0] + tot[1]) + (tot[2] + tot[3]);
+        const bool bad = (__float_as_uint(tsum) & 0x7F800000u) == 0x7F800000u;
+        const bool redo = __builtin_amdgcn_ballot_w64(bad) != 0;   // wave-uniform: a wave owns a row
+        if (redo && y < H) {
+            // (gradOutput is read again instead of keeping the 81 registers alive across this
+            // rarely taken branch: that cost the common path 8 % in spills)
+            const int slot0 = (y0 + wave) % K::WR;
+            for (int c = 0; c < K::CS && c_begin + c < C; ++c) {
+                const unsigned short *wc = win + c * K::CSTR + lane;
+                float sum = 0.f;
+                int sl = slot0;
+#pragma unroll 1
+                for (int j = 0; j < kND; ++j) {
+                    const int yy = side ? y + j - kD : y;
+                    const bool rok = yy >= 0 && yy < H;
+                    const int d0 = side ? kND * kND - 1 - j * kND : j * kND;
+                    const int row_off = __builtin_amdgcn_readfirstlane((d0 * plane + (rok ? yy : 0) * W) * 2);
+#pragma unroll
+                    for (int i = 0; i < kND; ++i) {
+                        const unsigned short gb = __builtin_amdgcn_raw_buffer_load_b16(
+                            rsrc_go, rok ? g_voff[i] : kDead, row_off + i * g_step, 0);
+                        sum = fmaf(Mma<T>::widen(gb), Mma<T>::widen(wc[sl * K::WC + i]), sum);
+                    }
+                    sl = sl + 1 == K::WR ? 0 : sl + 1;
+                }
+                const int x = x0 + lane;
+                __builtin_amdgcn_raw_buffer_store_b16(
+                    static_cast<unsigned short>(Mma<T>::pack2(sum * inv_nelems, 0.f)), rsrc_dst,
+                    x < W ? ((c_begin + c) * plane + y * W + x) * 2 : kDead, 0, 0);
+            }
+        }
         // ---- D[pixel][channel] -> gradInput[c][y][x]: 4 consecutive pixels of one channel per lane ----
-        if (y < H && !((dbg & 32) && acc[0][0][0] + acc[3][1][3] != 12345.f)) {
+        if (y < H && !redo && !((dbg & 32) && acc[0][0][0] + acc[3][1][3] != 12345.f)) {
 #pragma unroll
             for (int cb = 0; cb < K::CB; ++cb) {
                 const int c = c_begin + cb * 16 + p;

@@ -689,3 +689,42 @@ def test_mfma_forward_equals_the_valu_forward_up_to_output_rounding(dtype, ulp):
         assert float((out[fin].float() - ref[fin].float()).abs().max()) <= ulp * scale, shp
         assert torch.equal(buf[:, 3:84].view(torch.int16), out.view(torch.int16))
         assert float(buf[:, :3].abs().max()) == 0.0 and float(buf[:, 84:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_mfma_backward_keeps_nonfinite_values_local(dtype):
+    """The band matrix of the matrix-core backward holds explicit zeros, and 0 x Inf = NaN inside
+    an MFMA: left alone, an Inf / NaN of the source would spread over its 16-pixel segment.  A row
+    with a non-finite accumulator is therefore recomputed tap by tap; NaN and Inf must land on
+    exactly the elements the vector kernel gives them (same masks), finite values must agree."""
+    p = (4, 1, 4, 1, 1, 1)
+    shp = (2, 40, 13, 132)
+    B, C, H, W = shp
+    a1, a2 = hash_uniform(shp, 971), hash_uniform(shp, 972)
+    g = hash_uniform((B, 81, H, W), 973)
+    a1[0, 3, 5, 17] = np.inf
+    a1[1, 39, 12, 131] = np.nan
+    a2[0, 0, 0, 0] = -np.inf
+    a2[1, 20, 6, 64] = np.nan
+    a2[0, 33, 9, 70] = np.inf
+    g[0, 40, 2, 100] = np.nan
+    g[1, 0, 12, 3] = np.inf
+    x1 = torch.from_numpy(a1).to(dtype).to(DEV)
+    x2 = torch.from_numpy(a2).to(dtype).to(DEV)
+    go = torch.from_numpy(g).to(dtype).to(DEV)
+    g1, g2 = torch.ops.cerberus.correlation_backward(x1, x2, go, *p)
+    assert _lib.last_kernel(1) == "corr_bwd_d4_mfma_4x64"
+    _lib.set_option("corr_bwd_variant", 1)
+    try:
+        v1, v2 = torch.ops.cerberus.correlation_backward(x1, x2, go, *p)
+    finally:
+        _lib.set_option("corr_bwd_variant", 0)
+    ulp = 2.0 ** -10 if dtype == torch.float16 else 2.0 ** -7
+    for a, b in ((g1, v1), (g2, v2)):
+        assert torch.equal(torch.isnan(a), torch.isnan(b))
+        assert torch.equal(torch.isinf(a), torch.isinf(b))
+        assert int(torch.isnan(b).sum()) > 0 and int(torch.isfinite(b).sum()) > b.numel() // 2
+        fin = torch.isfinite(b)
+        assert torch.equal(torch.sign(a[torch.isinf(b)]), torch.sign(b[torch.isinf(b)]))
+        scale = float(b[fin].float().abs().max())
+        assert float((a[fin].float() - b[fin].float()).abs().max()) <= ulp * scale
