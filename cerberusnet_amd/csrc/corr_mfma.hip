@@ -91,6 +91,7 @@ struct BwdMfmaCfg {
     static constexpr int THREADS = 64 * TH;
     static constexpr size_t LDS_BYTES = 2 * (WIN + TH * TW * AROW);
     static_assert((CSTR * 2) % 128 == 16, "channel stride must stagger the banks");
+    static_assert(NSEG * 16 == TW && UPR * 4 == WC, "whole segments and units");
 };
 
 template <typename T>

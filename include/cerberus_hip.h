@@ -192,7 +192,8 @@ int cerberus_area_resize(const void *src, void *dst, int64_t planes, int H, int 
  *                          16x32 tile (fp32, W % 4 == 0), 6..9 = displacement-row streaming
  *                          (4 configurations), 10 = the same walking down a column of tiles,
  *                          11 = the matrix-core kernel (fp16 / bf16 storage; auto uses it)
- *   "corr_bwd_cslice"    : 0 = auto, else channels per backward workgroup
+ *   "corr_bwd_cslice"    : 0 = auto, else channels per backward workgroup (the matrix-core
+ *                          backward reads it as the number of tiles a workgroup walks down)
  *   "warp_pair_taps"     : warp gather variant (0 default, 1 paired everywhere, 2 unpaired)
  *   "warp_tile_ranges"   : channel ranges per warp-backward tile (0 auto)
  *   "warp_tile_h"        : rows per warp-backward tile (0 auto, 8, 16)
