@@ -517,13 +517,15 @@ def main():
         # kernels (tools/collect_profiles.sh: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE);
         # a constant read from a file, labelled as such -- it is not measured by this run
         traffic, traffic_src = None, None
-        for tag in ("r02", "r01"):
-            tpath = os.path.join(REPO, "profiles", tag + "_pmc_traffic.json")
-            if (os.path.exists(tpath) and args.pairs == 4 and not args.fuse_directions and
-                    (args.width, args.height, args.dtype) == (1024, 512, "f32")):
+        cfg_key = (args.width, args.height, args.dtype)
+        tnames = {(1024, 512, "f32"): ("r02_pmc_traffic.json", "r01_pmc_traffic.json"),
+                  (2048, 1024, "f16"): ("r02_config5_f16_pmc_traffic.json",)}.get(cfg_key, ())
+        for tname in tnames:
+            tpath = os.path.join(REPO, "profiles", tname)
+            if os.path.exists(tpath) and args.pairs == 4 and not args.fuse_directions:
                 blob = json.load(open(tpath))
                 traffic = blob.get(dominant, {}).get("traffic_bytes")
-                traffic_src = {"file": "profiles/" + tag + "_pmc_traffic.json",
+                traffic_src = {"file": "profiles/" + tname,
                                "commit": blob.get("_commit"), "kernels": blob.get("_kernels"),
                                "note": "constant from the committed PMC passes, not collected by this run"}
                 break

@@ -30,6 +30,16 @@ for L in 0 1 2 3; do
   done
 done
 python3 tools/pmc_to_traffic.py $OUT $TAG $COMMIT
+# 3b. the same two traffic passes for BASELINE config 5 (fp16, 2048x1024 pyramid): the matrix-core kernels
+rm -rf $OUT/_pmc_*
+for L in 0 1 2 3; do
+  for pass in "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum"; do
+    name=$(echo $pass | cut -d' ' -f1)
+    rocprofv3 --kernel-trace --pmc $pass --output-format csv -d $OUT/_pmc_L${L}_$name -- python3 tools/prof_kernels.py --levels $L --warp --reps 5 --dtype f16 --width 2048 --height 1024 > /dev/null 2> $OUT/_pmc_L${L}_$name.err
+  done
+done
+python3 tools/pmc_to_traffic.py $OUT ${TAG}_config5_f16 $COMMIT
+rm -f $OUT/${TAG}_config5_f16_pmc_counters.csv
 # 4. FETCH_SIZE calibration for the access widths of the warp gathers (known 1 GiB reads)
 if [ -x tools/ubench/fetch_calib ]; then
   rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/_calib -- ./tools/ubench/fetch_calib > $OUT/_calib.out 2> $OUT/_calib.err

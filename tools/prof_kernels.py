@@ -20,17 +20,21 @@ ap.add_argument("--fwd-variant", type=int, default=0)
 ap.add_argument("--bwd-cslice", type=int, default=0)
 ap.add_argument("--reps", type=int, default=5)
 ap.add_argument("--warp", action="store_true")
+ap.add_argument("--dtype", default="f32", choices=["f32", "f16", "bf16"])
+ap.add_argument("--width", type=int, default=1024)
+ap.add_argument("--height", type=int, default=512)
 args = ap.parse_args()
+DT = {"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16}[args.dtype]
 dev = "cuda:0"
 ops = torch.ops.cerberus
 _lib.set_option("corr_fwd_variant", args.fwd_variant)
 _lib.set_option("corr_bwd_cslice", args.bwd_cslice)
 for lvl in [int(x) for x in args.levels.split(",")]:
-    C, H, W = pyramid_shapes()[lvl]
+    C, H, W = pyramid_shapes(args.width, args.height)[lvl]
     B = args.pairs
-    x1 = torch.from_numpy(hash_uniform((B, C, H, W), 1)).to(dev)
-    x2 = torch.from_numpy(hash_uniform((B, C, H, W), 2)).to(dev)
-    go = torch.from_numpy(hash_uniform((B, 81, H, W), 3)).to(dev)
+    x1 = torch.from_numpy(hash_uniform((B, C, H, W), 1)).to(DT).to(dev)
+    x2 = torch.from_numpy(hash_uniform((B, C, H, W), 2)).to(DT).to(dev)
+    go = torch.from_numpy(hash_uniform((B, 81, H, W), 3)).to(DT).to(dev)
     from bench import Workload
     fl = Workload._flow(B, H, W, 4, "smooth", dev)   # the bench's flow field
     for _ in range(args.reps):
