@@ -228,29 +228,42 @@ __global__ __launch_bounds__(BwdMfmaCfg::THREADS, 2) void corr_bwd_d4_mfma_kerne
 #pragma unroll
             for (int cb = 0; cb < K::CB; ++cb) acc[s][cb] = f4v{0.f, 0.f, 0.f, 0.f};
         int slot = __builtin_amdgcn_readfirstlane((y0 + wave) % K::WR);   // ring slot of window row y - 4
-#pragma unroll
-        for (int eyi = 0; eyi < kND; ++eyi) {
-            // this lane's pixel: the nine g values of the row into its band slots
+        // Software pipeline over the displacement rows: while the MFMAs of row ey run on the A
+        // operands already in registers, the band of row ey + 1 is written and read back (LDS
+        // executes a wave's operations in order, so the one band-row buffer is enough).
+        auto write_band = [&](int eyi) {
 #pragma unroll
             for (int i = 0; i < kND; ++i)
                 if (!(dbg & 8)) my_arow[i] = gv[eyi][i];
-            if (!(dbg & 16)) {
-                // (same wave wrote the rows it reads: program order + the compiler's lgkmcnt wait)
-                u4v a[K::NSEG];
+        };
+        auto read_a = [&](u4v (&a)[K::NSEG]) {
 #pragma unroll
-                for (int s = 0; s < K::NSEG; ++s) {
-                    a[s] = *reinterpret_cast<const u4v *>(a_rd + s * 16 * K::AROW);
-                    if (kg == 3) a[s] = u4v{0, 0, 0, 0};   // k = 24..31: outside every band
-                }
+            for (int s = 0; s < K::NSEG; ++s) {
+                a[s] = *reinterpret_cast<const u4v *>(a_rd + s * 16 * K::AROW);
+                if (kg == 3) a[s] = u4v{0, 0, 0, 0};   // k = 24..31: outside every band
+            }
+        };
+        u4v a_cur[K::NSEG], a_nxt[K::NSEG];
+        write_band(0);
+        read_a(a_cur);
+#pragma unroll
+        for (int eyi = 0; eyi < kND; ++eyi) {
+            if (eyi + 1 < kND) {
+                write_band(eyi + 1);
+                read_a(a_nxt);
+            }
+            if (!(dbg & 16)) {
                 const unsigned short *b_rd = b_lane + slot * K::WC;
 #pragma unroll
                 for (int cb = 0; cb < K::CB; ++cb)
 #pragma unroll
                     for (int s = 0; s < K::NSEG; ++s) {
                         const u4v bv = *reinterpret_cast<const u4v *>(b_rd + cb * 16 * K::CSTR + 16 * s);
-                        acc[s][cb] = Mma<T>::run(a[s], bv, acc[s][cb]);
+                        acc[s][cb] = Mma<T>::run(a_cur[s], bv, acc[s][cb]);
                     }
             }
+#pragma unroll
+            for (int s = 0; s < K::NSEG; ++s) a_cur[s] = a_nxt[s];
             slot = slot + 1 == K::WR ? 0 : slot + 1;
         }
         // ---- the next tile's gradOutput values: in flight during the stores and the ring update ----
