@@ -728,3 +728,38 @@ def test_mfma_backward_keeps_nonfinite_values_local(dtype):
         assert torch.equal(torch.sign(a[torch.isinf(b)]), torch.sign(b[torch.isinf(b)]))
         scale = float(b[fin].float().abs().max())
         assert float((a[fin].float() - b[fin].float()).abs().max()) <= ulp * scale
+
+
+@pytest.mark.parametrize("dtype,ulp", [(torch.float16, 2.0 ** -10), (torch.bfloat16, 2.0 ** -7)])
+def test_seeded_random_shape_sweep_16bit_tuned_vs_generic(dtype, ulp):
+    """40 seeded random shapes in 16-bit storage: whatever the dispatcher picks (matrix-core
+    forward for 16 < C <= 64, vector forward otherwise, matrix-core backward walking 1..n tiles,
+    generic kernels when W % 4 != 0) against the generic 16-bit kernels (fp32 accumulation, same
+    exact products), forward and both gradients: at most two units of the output's last place."""
+    rng = np.random.RandomState(20241003)
+    kernels = set()
+    p = (4, 1, 4, 1, 1, 1)
+    for trial in range(40):
+        B = int(rng.randint(1, 4))
+        C = int(rng.choice([1, 3, 8, 16, 17, 24, 32, 33, 48, 64, 65, 96, 130]))
+        H = int(rng.randint(1, 70))
+        W = int(rng.choice([4, 8, 12, 20, 32, 36, 64, 68, 100, 128, 132, 200, 260])) + int(rng.randint(0, 2)) * int(rng.randint(0, 4))
+        shape = (B, C, H, W)
+        x1 = torch.from_numpy(hash_uniform(shape, 5900 + trial)).to(dtype).to(DEV)
+        x2 = torch.from_numpy(hash_uniform(shape, 6900 + trial)).to(dtype).to(DEV)
+        go = torch.from_numpy(hash_uniform((B, 81, H, W), 7900 + trial)).to(dtype).to(DEV)
+        out = torch.ops.cerberus.correlation(x1, x2, *p)
+        kernels.add(_lib.last_kernel(0))
+        g1, g2 = torch.ops.cerberus.correlation_backward(x1, x2, go, *p)
+        kernels.add(_lib.last_kernel(1))
+        _lib.set_option("corr_force_generic", 1)
+        try:
+            ref = torch.ops.cerberus.correlation(x1, x2, *p)
+            r1, r2 = torch.ops.cerberus.correlation_backward(x1, x2, go, *p)
+        finally:
+            _lib.set_option("corr_force_generic", 0)
+        for a, b, what in ((out, ref, "out"), (g1, r1, "g1"), (g2, r2, "g2")):
+            scale = float(b.float().abs().max()) or 1.0
+            err = float((a.float() - b.float()).abs().max()) / scale
+            assert err <= 2 * ulp, (shape, what, err, sorted(kernels))
+    assert any("mfma" in k and "fwd" in k for k in kernels) and any("mfma" in k and "bwd" in k for k in kernels), kernels
