@@ -5,6 +5,7 @@
 #include <hip/hip_bfloat16.h>
 #include <stdint.h>
 #include <algorithm>
+#include <atomic>
 
 #include "../../include/cerberus_hip.h"
 
@@ -114,6 +115,26 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const void *p, in
         __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
 }
 #endif
+
+// LDS above 64 KiB needs an explicit opt-in, once per kernel AND device (function attributes
+// are per device): one bit per device ordinal in an atomic mask owned by the call site.  The
+// bit is set only AFTER hipFuncSetAttribute has succeeded, so a concurrent caller either sees
+// the bit (attribute in place) or sets the attribute again itself (harmless), and a failed
+// call is retried by the next launch.
+template <typename Kern>
+int ensure_lds(Kern kern, size_t bytes, std::atomic<uint64_t> *done) {
+    if (bytes <= 64 * 1024) return CERB_OK;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    const uint64_t bit = 1ull << (dev & 63);
+    if (done->load(std::memory_order_acquire) & bit) return CERB_OK;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       static_cast<int>(bytes));
+    if (e != hipSuccess) return static_cast<int>(e);
+    done->fetch_or(bit, std::memory_order_release);
+    return CERB_OK;
+}
 
 // ---- launchers implemented in the kernel translation units ------------------
 // all return hipError_t (as int) of the launch, or a negative CERB_E* code.

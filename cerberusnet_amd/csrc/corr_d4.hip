@@ -1811,26 +1811,6 @@ __global__ __launch_bounds__(K::THREADS, 2) void corr_bwd_d4_col_kernel(
 }
 
 // ---- host side -------------------------------------------------------------
-// LDS above 64 KiB needs an explicit opt-in, once per kernel AND device (function attributes
-// are per device): one bit per device ordinal in an atomic mask owned by the call site.  The
-// bit is set only AFTER hipFuncSetAttribute has succeeded, so a concurrent caller either sees
-// the bit (attribute in place) or sets the attribute again itself (harmless), and a failed
-// call is retried by the next launch.
-template <typename Kern>
-int ensure_lds(Kern kern, size_t bytes, std::atomic<uint64_t> *done) {
-    if (bytes <= 64 * 1024) return CERB_OK;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
-    const uint64_t bit = 1ull << (dev & 63);
-    if (done->load(std::memory_order_acquire) & bit) return CERB_OK;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       static_cast<int>(bytes));
-    if (e != hipSuccess) return static_cast<int>(e);
-    done->fetch_or(bit, std::memory_order_release);
-    return CERB_OK;
-}
-
 // 16-bit storage is only instantiated for the vector (aligned, W % 4 == 0) path; other
 // shapes of those dtypes take the generic kernels.
 template <typename K, typename T>

@@ -548,14 +548,8 @@ int launch_fwd_mfma(const char *name, const void *in1, const void *in2, void *ou
     const int tiles_x = (g.W + K::TW - 1) / K::TW, tiles_y = (g.H + K::TH - 1) / K::TH;
     const int64_t blocks = static_cast<int64_t>(g.B) * tiles_x * tiles_y;
     if (blocks > 0x7fffffff) return CERB_ETOOLARGE;
-    static std::atomic<int> lds_set{0};
-    if (!lds_set.load(std::memory_order_acquire)) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(corr_fwd_d4_mfma_kernel<K, T>),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                 static_cast<int>(K::LDS_BYTES));
-        if (e != hipSuccess) return static_cast<int>(e);
-        lds_set.store(1, std::memory_order_release);
-    }
+    static std::atomic<uint64_t> lds_done{0};
+    if (const int rc = ensure_lds(corr_fwd_d4_mfma_kernel<K, T>, K::LDS_BYTES, &lds_done)) return rc;
     note_kernel(0, name);
     hipLaunchKernelGGL((corr_fwd_d4_mfma_kernel<K, T>), dim3(static_cast<unsigned>(blocks)), dim3(K::THREADS),
                        K::LDS_BYTES, s, static_cast<const T *>(in1), static_cast<const T *>(in2),
@@ -588,14 +582,8 @@ int launch(const void *in1, const void *in2, const void *gout, void *gin1, void 
     if (const int forced = option(OPT_CORR_BWD_CSLICE)) nwalk = std::max(1, std::min(forced, tiles_y));
     const int64_t blocks = cols * ((tiles_y + nwalk - 1) / nwalk);
     if (blocks > 0x7fffffff) return CERB_ETOOLARGE;
-    static std::atomic<int> lds_set{0};
-    if (!lds_set.load(std::memory_order_acquire)) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(corr_bwd_d4_mfma_kernel<T>),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                 static_cast<int>(K::LDS_BYTES));
-        if (e != hipSuccess) return static_cast<int>(e);
-        lds_set.store(1, std::memory_order_release);
-    }
+    static std::atomic<uint64_t> lds_done{0};
+    if (const int rc = ensure_lds(corr_bwd_d4_mfma_kernel<T>, K::LDS_BYTES, &lds_done)) return rc;
     note_kernel(1, "corr_bwd_d4_mfma_4x64");
     hipLaunchKernelGGL((corr_bwd_d4_mfma_kernel<T>), dim3(static_cast<unsigned>(blocks)), dim3(K::THREADS),
                        K::LDS_BYTES, s, static_cast<const T *>(in1), static_cast<const T *>(in2),
