@@ -10,7 +10,7 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libcerberus_hip.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _lock = threading.Lock()
 _lib = None

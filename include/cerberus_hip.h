@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define CERBERUS_HIP_ABI_VERSION 3
+#define CERBERUS_HIP_ABI_VERSION 4   /* 4: + cerberus_area_resize; the warp context holds one tap range per 2 x 32 strip (size: cerberus_flow_warp_context_bytes) */
 
 /* element types (AT_DISPATCH_FLOATING_TYPES_AND_HALF in the reference,
  * correlation_cuda_kernel.cu:269,303; bf16 is an extension) */
