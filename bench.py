@@ -353,6 +353,9 @@ def main():
     ap.add_argument("--grad-mb", type=float, default=GRAD_BYTES / 1e6,
                     help="size of the gradient buffer exchanged per step (MB, fp32)")
     ap.add_argument("--bucket-mb", type=float, default=64.0)
+    ap.add_argument("--no-mfma", action="store_true",
+                    help="fp16 / bf16: keep the correlation on the vector kernels (option corr_no_mfma); "
+                         "the fp32 path uses no MFMA either way")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -366,6 +369,9 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no CPU path exists for the product)")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    if args.no_mfma:
+        from cerberusnet_amd import _lib as _cerb_lib
+        _cerb_lib.set_option("corr_no_mfma", 1)
     dist = None
     if world > 1 or os.environ.get("CERB_FORCE_DIST") == "1":  # the latter: 1-rank RCCL self-test
         import torch.distributed as dist

@@ -14,6 +14,7 @@ const char *const g_option_names[OPT_COUNT] = {
     "corr_fwd_variant",     // 0: auto, 1..8: force a register-staged variant, 9..13: LDS-DMA, 14: matrix cores (16-bit)
     "corr_bwd_variant",     // 0: auto, 1: all-81 per lane, 2/3: 3 dy groups, 4/5: LDS-DMA, 6-9: dy-streaming, 10: column walk, 11: matrix cores (16-bit)
     "corr_bwd_cslice",      // 0: auto, else channels per backward workgroup (matrix-core backward: tiles per column walk)
+    "corr_no_mfma",         // 1: 16-bit storage never takes the matrix-core kernels (vector kernels, auto-selected)
     "warp_pair_taps",       // 0: default, 1: pairs everywhere, 2: none
     "warp_tile_ranges",     // 0: auto, else channel ranges per warp-backward tile
     "warp_tile_h",          // 0: auto, 8 / 16: rows per warp-backward tile

@@ -70,6 +70,7 @@ enum OptId {
     OPT_CORR_FWD_VARIANT,
     OPT_CORR_BWD_VARIANT,
     OPT_CORR_BWD_CSLICE,
+    OPT_CORR_NO_MFMA,
     OPT_WARP_PAIR_TAPS,
     OPT_WARP_TILE_RANGES,
     OPT_WARP_TILE_H,

@@ -194,6 +194,8 @@ int cerberus_area_resize(const void *src, void *dst, int64_t planes, int H, int 
  *                          11 = the matrix-core kernel (fp16 / bf16 storage; auto uses it)
  *   "corr_bwd_cslice"    : 0 = auto, else channels per backward workgroup (the matrix-core
  *                          backward reads it as the number of tiles a workgroup walks down)
+ *   "corr_no_mfma"       : 1 = fp16 / bf16 storage never takes the matrix-core kernels: the vector
+ *                          kernels, selected as for fp32 (the fp32 path uses no MFMA either way)
  *   "warp_pair_taps"     : warp gather variant (0 default, 1 paired everywhere, 2 unpaired)
  *   "warp_tile_ranges"   : channel ranges per warp-backward tile (0 auto)
  *   "warp_tile_h"        : rows per warp-backward tile (0 auto, 8, 16)
