@@ -156,6 +156,10 @@ int corr_d4_backward(const void *in1, const void *in2, const void *gout, void *g
 int corr_mfma_backward(const void *in1, const void *in2, const void *gout, void *gin1, void *gin2,
                        const CorrGeom &g, int dtype, hipStream_t s);
 
+// fp32 backward for image rows that fit one wavefront (corr_strip.hip); CERB_EUNSUPPORTED otherwise
+int corr_strip_backward(const void *in1, const void *in2, const void *gout, void *gin1, void *gin2,
+                        const CorrGeom &g, hipStream_t s);
+
 int corr_mfma_forward(const void *in1, const void *in2, void *out, const CorrGeom &g, float slope,
                       int64_t obs, int dtype, hipStream_t s);
 

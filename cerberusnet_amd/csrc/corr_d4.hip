@@ -2163,6 +2163,20 @@ int bwd_dispatch(const void *x1, const void *x2, const void *go, void *g1, void 
         }
         return launch_bwd<BwdNarrow, T>("corr_bwd_d4_16x32", x1, x2, go, g1, g2, g, vec, s);
     }
+    if constexpr (sizeof(T) == 4) {
+        // whole image rows per wavefront, neighbours by DPP (corr_strip.hip): forced by 12
+        // whole image rows per wavefront, horizontal neighbours by DPP (corr_strip.hip).  Ten
+        // barrier-separated steps per workgroup make it latency-bound on small problems: it is
+        // the default where the 256-wide level fills the chip (>= 0.75 eight-wave workgroups per
+        // CU: 31.6 vs 38.1 us at 4 pairs of 32 x 128 x 256, 20.4 vs 25.0 at two, 18.1 vs 16.2 at one);
+        // variant 12 forces it on every shape it supports.
+        const int v = option(OPT_CORR_BWD_VARIANT);
+        const int64_t strip_wgs = static_cast<int64_t>(g.B) * (g.H / 2) * (g.C / 32) * 2;
+        if (vec && dma_ok(g) && (v == 12 || (v == 0 && g.W == 256 && strip_wgs >= 192))) {
+            const int rc = corr_strip_backward(x1, x2, go, g1, g2, g, s);
+            if (rc != CERB_EUNSUPPORTED) return rc;
+        }
+    }
     switch (option(OPT_CORR_BWD_VARIANT)) {
         case 1: return launch_bwd<BwdWide, T>("corr_bwd_d4_8x64", x1, x2, go, g1, g2, g, vec, s);
         case 2: return launch_bwd_g3<BwdG3Wide, T>("corr_bwd_d4_g3_4x64", x1, x2, go, g1, g2, g, vec, s);

@@ -1,0 +1,448 @@
+// corr_strip.hip -- correlation backward for image rows that fit one wavefront (fp32, d = 4).
+//
+//   gI1[c][y][x] = 1/C sum_{dy,dx} gO[dy,dx][y][x]          * x2[c][y+dy][x+dx]
+//   gI2[c][y][x] = 1/C sum_{ey,ex} gO[-ey,-ex][y+ey][x+ex]  * x1[c][y+ey][x+ex]
+//   (reference: correlation_cuda_kernel.cu:97-172 and :174-242; same sums, other order)
+//
+// The kernels of corr_d4.hip cut the map into 4x64 / 8x64 tiles and read the x window of a
+// lane's strip from LDS: three ds_read_b128 per 36 FMAs keep the LDS two thirds busy, the 81
+// gradOutput values of a pixel either sit in 162 registers (2 waves/SIMD) or are re-read per
+// channel slice, and one round of workgroups runs its phases in lock-step.
+// Here a lane owns a 4-pixel STRIP and a wavefront owns whole image rows (W = 256: one row per
+// wave, 64 strips), so the horizontal neighbours of a strip are the neighbouring LANES:
+//   * x rows go global -> registers, one 16-byte load per lane, channel and row; the left and
+//     right neighbour strips of the 12-float window come from v_mov_b32_dpp (wave_shr:1 /
+//     wave_shl:1, bound_ctrl): at W = 256 the wave's ends ARE the image's ends, and the zero a
+//     DPP shift fills in is the reference's zero padding -- no halo, no LDS for x at all;
+//   * a lane accumulates NR = 2 vertically adjacent output rows x CW = 4 channels (32
+//     accumulators): the x row of step s serves dy = s-4 of the upper and dy = s-5 of the lower
+//     row, so a wave reads 10 rows for 2 (5x from L2 instead of 9x);
+//   * gradOutput is streamed, never held: step s needs 2 x 9 planes of one image row (18 KB).
+//     They arrive by LDS-DMA two steps ahead in a ring of three slots, shared by the 8 waves of
+//     the workgroup (8 x 4 = 32 channels): gradOutput is read ONCE per side whatever C, and a
+//     lane fetches the 4 values of (row, dx) just in time -- one ds_read_b128 per 16 FMAs;
+//   * side 2 (gI2) is the same arithmetic on the flipped plane index with the gradOutput row
+//     read SHIFTED by ex: every LDS row carries a 16-byte halo of zeros on both sides and the
+//     lane reads at its cell + 4*ex bytes (an unaligned ds_read_b128): taps outside the row read
+//     exact zeros, as the reference skips them;
+//   * ~110 VGPRs -> 4 waves/SIMD (2 workgroups of 8 waves per CU at the 32 x 128 x 256 level);
+//     waves of one workgroup meet at ONE barrier per step, loads of step s+1 / DMAs of step s+2
+//     are in flight under the FMAs of step s.
+// The FMAs, LDS reads and their waits are inline asm in program order (hipcc hoists every LDS
+// read of an unrolled step to its top and spills otherwise); global loads, DMAs
+// and DPP moves are builtins the compiler counts and pads itself.
+#include <atomic>
+#include <type_traits>
+#include <utility>
+
+#include "common.h"
+
+namespace cerb {
+namespace {
+
+constexpr int kD = 4;
+constexpr int kND = 2 * kD + 1;
+constexpr int kDead = static_cast<int>(0x80000000u);   // buffer offset that is out of range: reads 0
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef int i4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void *lds_void_ptr;
+
+template <int B, int E, typename F>
+__device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (B < E) {
+        f(std::integral_constant<int, B>{});
+        static_for<B + 1, E>(f);
+    }
+}
+
+// SPR  4-pixel strips per image row (W = 4 * SPR); a wave holds RW = 64 / SPR lane-rows
+// NWV  waves per workgroup = channel groups of CW = 4 that share the gradOutput stream
+template <int SPR_, int NWV_, int FLAGS_ = 0>
+struct StripCfg {
+    // timing-experiment flags (-DCERB_ABLATE builds): 1 gradOutput DMA non-temporal, 2 x loads non-temporal, 4 no FMAs,
+    // 8 no loads / DMAs, 16 no LDS reads, 32 natural step order, 64 no step barrier, 256 no stores (all but 1, 2, 32: wrong results)
+    static constexpr int FLAGS = FLAGS_;
+    static constexpr int SPR = SPR_, W = 4 * SPR_, RW = 64 / SPR_;
+    static constexpr int NR = 2, CW = 4, NWV = NWV_, CWG = CW * NWV_;
+    static constexpr int ROWS = NR * RW;                 // image rows per workgroup
+    static constexpr int THREADS = 64 * NWV_;
+    static constexpr int NSLOT = 4;
+    // waves per SIMD the register allocator leaves room for: two 8-wave workgroups per CU on the 256-wide level
+    // (one round of 512 workgroups at 4 pairs); the narrower levels have fewer workgroups than that anyway
+    static constexpr int WPS = SPR_ == 64 ? 4 : 2;
+    static constexpr int PITCH = W * 4;                  // bytes per staged gradOutput row
+    static constexpr int ENTRY = RW * PITCH;             // one (j, dx) plane: RW rows
+    static constexpr int SLOT = NR * kND * ENTRY;        // one step
+    static constexpr int NDMA = (NR * kND + NWV_ - 1) / NWV_;   // DMA instructions per wave and step
+    static constexpr size_t LDS_BYTES = static_cast<size_t>(NSLOT) * SLOT + ENTRY;   // + a scratch entry for idle DMA slots
+    static_assert(64 % SPR_ == 0, "whole rows per wave");
+    static_assert((NR * kND - 1) * ENTRY < 65536, "ds_read immediate offsets");
+};
+
+#ifdef CERB_STAMP
+// diagnostic build only (-DCERB_STAMP): s_memtime of every wave of the first 64 workgroups at the phase
+// boundaries of each step, fetched with cerberus_debug_strip_stamps(); never compiled into the product
+__device__ unsigned long long g_strip_stamps[64][8][64];
+__device__ unsigned long long g_strip_life[512][8][4];   // s_memrealtime: wave start, loop end, stores acknowledged
+#define STRIP_STAMP(k)                                                                                   \
+    do {                                                                                                 \
+        if ((threadIdx.x & 63) == 0 && blockIdx.x < 64) g_strip_stamps[blockIdx.x][threadIdx.x >> 6][k] = __builtin_readcyclecounter(); \
+    } while (0)
+#else
+#define STRIP_STAMP(k) do {} while (0)
+#endif
+
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ float dpp_mov(float v, std::integral_constant<int, 0>) {   // from lane-1 (wave)
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float dpp_mov(float v, std::integral_constant<int, 1>) {   // from lane+1 (wave)
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float dpp_mov(float v, std::integral_constant<int, 2>) {   // from lane-1 (16-lane row)
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float dpp_mov(float v, std::integral_constant<int, 3>) {   // from lane+1 (16-lane row)
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x101, 0xf, 0xf, true));
+}
+
+template <int OFF>
+__device__ __forceinline__ void lds_read16(f4 &dst, unsigned addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(OFF));
+}
+template <int N>
+__device__ __forceinline__ void lgkm_wait(f4 &v) {
+    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(v) : "i"(N));
+}
+__device__ __forceinline__ void fmac(float &acc, float a, float b) {
+    asm volatile("v_fmac_f32_e32 %0, %1, %2" : "+v"(acc) : "v"(a), "v"(b));
+}
+
+template <typename K, int SIDE>
+struct StripBwd {
+    __amdgpu_buffer_rsrc_t rsrc_x, rsrc_g;
+    float *smem;
+    int H, plane, wave, lane, y0;
+    unsigned lds_base, lds_lane;   // byte address of the ring / of the lane's cell inside an entry
+    int row0, voff0;               // image row of the lane's x row at step 0, its byte offset in a plane
+    f4 xs[2][K::CW];
+    float acc[K::NR][K::CW][4];
+
+    // x rows of step S (image row row0 + S), CW channels; `live` false: nothing is fetched (zeros)
+    __device__ __forceinline__ void load_x(int S, bool live, f4 (&dst)[K::CW]) {
+        const int row = row0 + S;
+        int vo = voff0 + S * (K::W * 4);
+        vo = (live && static_cast<unsigned>(row) < static_cast<unsigned>(H)) ? vo : kDead;
+#pragma unroll
+        for (int c = 0; c < K::CW; ++c)
+            if constexpr (!(K::FLAGS & 8))
+                dst[c] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, vo, c * plane * 4, (K::FLAGS & 2) ? 2 : 0));
+    }
+
+    // gradOutput planes of step S -> ring slot `slot`.  Plane k = j * 9 + dx is requested by wave
+    // k % NWV.  Every wave issues the SAME number of DMA instructions per step, unconditionally
+    // (a wave without a plane to fetch sends an out-of-range request to a scratch row): the
+    // compiler's vmcnt bookkeeping for the x loads then knows exactly how many younger
+    // operations exist, and never waits for a request that has just been issued.
+    __device__ __forceinline__ void issue_g(int S, bool live, int slot) {
+        const int lr = lane / K::SPR, sx = lane % K::SPR;
+#pragma unroll
+        for (int q = 0; q < K::NDMA; ++q) {
+            const int k = wave + K::NWV * q;                    // wave-uniform
+            const int j = k >= kND ? 1 : 0, dx = k - j * kND;
+            const int dyi = S - j;                              // vertical displacement index of the block
+            const bool act = live && k < K::NR * kND && dyi >= 0 && dyi < kND;
+            const int pl = SIDE == 0 ? dyi * kND + dx : (kND - 1 - dyi) * kND + (kND - 1 - dx);
+            // one instruction = the 64 cells of an entry: lane-row lr reads its image row (side 0:
+            // the lane's own output row j; side 1: the x row of the step)
+            const int row = SIDE == 0 ? y0 + lr * K::NR + j : y0 + lr * K::NR + S - kD;
+            const bool ok = act && static_cast<unsigned>(row) < static_cast<unsigned>(H);
+            // side 1 reads the row shifted by ex = dx - 4 (a dword-aligned 16-byte read per lane).
+            // The request never leaves the batch item's 81 planes (ex < 0 only occurs on planes
+            // >= 5, ex > 0 only on planes <= 75), so the cells at a row's ends pick up a few values
+            // of the neighbouring row: patch_g() zeroes them once the data has landed.  (The row
+            // offset rides in the VGPR offset: the range check looks at that one alone, and the
+            // shift by ex < 0 of a row's first lane must not make it negative.)
+            const int vo = (pl * H + row) * (K::W * 4) + sx * 16 + (SIDE ? (dx - kD) * 4 : 0);
+            const int doff = act ? slot * K::SLOT + k * K::ENTRY : K::NSLOT * K::SLOT;   // idle: scratch entry behind the ring
+            if constexpr (!(K::FLAGS & 8))
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_g, (lds_void_ptr)(smem + doff / 4), 16,
+                                                         ok ? vo : kDead, 0, 0, (K::FLAGS & 1) ? 2 : 0);
+        }
+    }
+
+    // side 1: zero the taps of step S's staged rows that lie outside the image row (|ex| dwords at
+    // one end of the row); each wave patches the planes it requested, after they have landed
+    __device__ __forceinline__ void patch_g(int S, int slot) {
+        if constexpr (SIDE == 1 && !(K::FLAGS & 8)) {
+#pragma unroll
+            for (int q = 0; q < K::NDMA; ++q) {
+                const int k = wave + K::NWV * q;
+                const int j = k >= kND ? 1 : 0, dx = k - j * kND, ex = dx - kD;
+                const int dyi = S - j;
+                const bool act = k < K::NR * kND && dyi >= 0 && dyi < kND;
+                const int n = act ? (ex < 0 ? -ex : ex) : 0;
+#pragma unroll
+                for (int lr = 0; lr < K::RW; ++lr) {
+                    const unsigned row = lds_base + slot * K::SLOT + k * K::ENTRY + lr * K::PITCH;
+                    const unsigned a = ex < 0 ? row + lane * 4 : row + K::PITCH - 4 - lane * 4;
+                    if (lane < n) asm volatile("ds_write_b32 %0, %1" ::"v"(a), "v"(0.f) : "memory");
+                }
+            }
+        }
+    }
+
+    // the nine (j, dx) blocks of output row j: 4 gradOutput values just in time, 16 FMAs each
+    template <int J>
+    __device__ __forceinline__ void row_blocks(const float (&win)[K::CW][12], unsigned lds_cur) {
+        constexpr int DEPTH = 2;                              // reads in flight
+        f4 gq[DEPTH + 1];
+        auto issue = [&](auto bc) {
+            constexpr int dx = decltype(bc)::value;
+            if constexpr (!(K::FLAGS & 16)) lds_read16<(J * kND + dx) * K::ENTRY>(gq[dx % (DEPTH + 1)], lds_cur);
+        };
+        static_for<0, DEPTH>(issue);
+        static_for<0, kND>([&](auto bc) {
+            constexpr int dx = decltype(bc)::value;
+            if constexpr (dx + DEPTH < kND) issue(std::integral_constant<int, dx + DEPTH>{});
+            constexpr int pending = (kND - 1 - dx) < DEPTH ? (kND - 1 - dx) : DEPTH;
+            if constexpr (!(K::FLAGS & 16)) lgkm_wait<pending>(gq[dx % (DEPTH + 1)]);
+            const f4 g = gq[dx % (DEPTH + 1)];
+#pragma unroll
+            for (int c = 0; c < K::CW; ++c)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (!(K::FLAGS & 4) || (c == 0 && dx == 0)) fmac(acc[J][c][i], win[c][i + dx], g[i]);
+        });
+    }
+
+    // one step at time t: x row S of the lane (register set XSET), gradOutput in ring slot `cur`.
+    // AFTER its FMAs a wave requests the x row of step t+2 (S2, into the register set it has just
+    // finished with) and the planes of step t+3 (S3, into the slot last read a step ago): the
+    // vector-memory instructions (~130 cycles each when all waves of a CU issue together) are
+    // spread over the waves' staggered arrivals at the barrier instead of following it.
+    template <int XSET>
+    __device__ __forceinline__ void step(int S, int S1, int S2, int S3, bool live2, bool live3, int cur, int nxt,
+                                         int s3, int t) {
+        // ---- 12-float windows of the CW channels: [left strip | own | right strip] ----
+        using ShrT = std::integral_constant<int, K::SPR == 64 || K::SPR == 32 ? 0 : 2>;
+        using ShlT = std::integral_constant<int, K::SPR == 64 || K::SPR == 32 ? 1 : 3>;
+        float win[K::CW][12];
+#pragma unroll
+        for (int c = 0; c < K::CW; ++c) {
+            const f4 v = xs[XSET][c];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float l = dpp_mov(v[q], ShrT{}), r = dpp_mov(v[q], ShlT{});
+                if constexpr (K::SPR != 64 && K::SPR != 16) {
+                    // lane-rows narrower than the DPP row: the image's ends fall inside it
+                    l = (lane % K::SPR) == 0 ? 0.f : l;
+                    r = (lane % K::SPR) == K::SPR - 1 ? 0.f : r;
+                }
+                win[c][q] = l; win[c][4 + q] = v[q]; win[c][8 + q] = r;
+            }
+        }
+        const unsigned lds_cur = lds_lane + cur * K::SLOT;
+#ifdef CERB_STAMP
+        asm volatile("" : "+v"(win[0][0]), "+v"(win[1][3]), "+v"(win[3][11]));
+        STRIP_STAMP(3 + 4 * t);
+#endif
+        if (S <= kND - 1) row_blocks<0>(win, lds_cur);        // dy = S - 4
+        if (S >= 1) row_blocks<1>(win, lds_cur);              // dy = S - 5
+        STRIP_STAMP(4 + 4 * t);
+
+        load_x(S2, live2, xs[XSET]);
+        issue_g(S3, live3, s3);
+        // the gradOutput planes of the next step (requested two steps ago) have landed once only
+        // the requests of the previous and of this step may still be in flight; nobody reads
+        // slot `cur` after the barrier
+        constexpr int younger = (K::FLAGS & 8) ? 0 : 2 * (K::CW + K::NDMA);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"i"(younger) : "memory");
+        patch_g(S1, nxt);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        STRIP_STAMP(5 + 4 * t);
+        if constexpr (!(K::FLAGS & 64)) __builtin_amdgcn_s_barrier();
+        STRIP_STAMP(6 + 4 * t);
+    }
+};
+#endif
+
+template <typename K>
+__global__ __launch_bounds__(K::THREADS, K::WPS)
+void corr_bwd_d4_strip_kernel(const float *__restrict__ x1, const float *__restrict__ x2,
+                              const float *__restrict__ gout, float *__restrict__ gin1,
+                              float *__restrict__ gin2, int C, int H, int nyb, int ncb) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int lr = lane / K::SPR, sx = lane % K::SPR;
+
+    // (row block, channel block, side) with the side fastest: the two workgroups that stream
+    // the same gradOutput rows are neighbours in the XCD-contiguous order
+    int bid = xcd_chunk(blockIdx.x, gridDim.x);
+    const int side = __builtin_amdgcn_readfirstlane(bid & 1); bid >>= 1;
+    const int cb = __builtin_amdgcn_readfirstlane(bid % ncb); bid /= ncb;
+    const int yb = __builtin_amdgcn_readfirstlane(bid % nyb);
+    const int b = __builtin_amdgcn_readfirstlane(bid / nyb);
+    const int plane = H * K::W;
+    const int c0 = cb * K::CWG + wave * K::CW;
+    const int y0 = yb * K::ROWS;
+
+    const float *src = (side == 0 ? x2 : x1) + (static_cast<int64_t>(b) * C + c0) * plane;
+    float *dst = (side == 0 ? gin1 : gin2) + (static_cast<int64_t>(b) * C + c0) * plane;
+    const float *gob = gout + static_cast<int64_t>(b) * (kND * kND) * plane;
+
+    auto run = [&](auto sidec) {
+        constexpr int SIDE = decltype(sidec)::value;
+        StripBwd<K, SIDE> st;
+        st.rsrc_x = uniform_rsrc(src, K::CW * plane * 4);
+        st.rsrc_g = uniform_rsrc(gob, kND * kND * plane * 4);
+        st.smem = smem;
+        st.H = H; st.plane = plane; st.wave = wave; st.lane = lane; st.y0 = y0;
+        st.lds_base = static_cast<unsigned>(reinterpret_cast<size_t>((__attribute__((address_space(3))) float *)smem));
+        st.lds_lane = st.lds_base + lr * K::PITCH + sx * 16;
+        st.row0 = y0 + lr * K::NR - kD;
+        st.voff0 = (st.row0 * K::W + sx * 4) * 4;
+#pragma unroll
+        for (int j = 0; j < K::NR; ++j)
+#pragma unroll
+            for (int c = 0; c < K::CW; ++c)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) st.acc[j][c][i] = 0.f;
+
+        // A workgroup walks its ten x rows CYCLICALLY, starting where its neighbours are: at time
+        // t it is at step S = (t - y0) mod 10, i.e. at image row y0 - 4 + S = t - 4 (mod 10) --
+        // the five workgroups whose windows hold an image row all fetch it in the same time step,
+        // one L2 miss and four hits.  (In natural order they fetch it two steps apart, and the
+        // 2 x 3.2 MB an XCD moves in two steps do not fit its 4 MiB L2: 2.1x the bytes at the fabric.)
+        const auto next = [](int S) { return S + 1 == 10 ? 0 : S + 1; };
+        int S = (K::FLAGS & 32) ? 0 : (10 - y0 % 10) % 10;
+        int S1 = next(S), S2 = next(S1), S3 = next(S2);
+        st.issue_g(S, true, 0);
+        st.load_x(S, true, st.xs[0]);
+        st.issue_g(S1, true, 1);
+        st.load_x(S1, true, st.xs[1]);
+        st.issue_g(S2, true, 2);
+        STRIP_STAMP(0);
+#ifdef CERB_STAMP
+        if ((threadIdx.x & 63) == 0 && blockIdx.x < 64) g_strip_stamps[blockIdx.x][threadIdx.x >> 6][44] = __builtin_amdgcn_s_memrealtime();
+        if ((threadIdx.x & 63) == 0 && blockIdx.x < 512) g_strip_life[blockIdx.x][threadIdx.x >> 6][0] = __builtin_amdgcn_s_memrealtime();
+#endif
+        // the first step needs its own planes and x rows only: everything requested after them stays in flight
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"i"((K::FLAGS & 8) ? 0 : 2 * K::NDMA + K::CW) : "memory");
+        STRIP_STAMP(1);
+        st.patch_g(S, 0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        STRIP_STAMP(2);
+        int cur = 0, nxt = 1, n2 = 2, n3 = 3;
+#pragma unroll 1
+        for (int t = 0; t < 10; t += 2) {
+            st.template step<0>(S, S1, S2, S3, t + 2 < 10, t + 3 < 10, cur, nxt, n3, t);
+            S = S1; S1 = S2; S2 = S3; S3 = next(S3);
+            { const int q = cur; cur = nxt; nxt = n2; n2 = n3; n3 = q; }
+            st.template step<1>(S, S1, S2, S3, t + 3 < 10, t + 4 < 10, cur, nxt, n3, t + 1);
+            S = S1; S1 = S2; S2 = S3; S3 = next(S3);
+            { const int q = cur; cur = nxt; nxt = n2; n2 = n3; n3 = q; }
+        }
+
+        STRIP_STAMP(43);
+#ifdef CERB_STAMP
+        if ((threadIdx.x & 63) == 0 && blockIdx.x < 64) g_strip_stamps[blockIdx.x][threadIdx.x >> 6][45] = __builtin_amdgcn_s_memrealtime();
+        if ((threadIdx.x & 63) == 0 && blockIdx.x < 512) g_strip_life[blockIdx.x][threadIdx.x >> 6][1] = __builtin_amdgcn_s_memrealtime();
+#endif
+        const float inv = 1.0f / static_cast<float>(C);
+#pragma unroll
+        for (int j = 0; j < K::NR; ++j)
+#pragma unroll
+            for (int c = 0; c < K::CW; ++c) {
+                float *p = dst + static_cast<int64_t>(c) * plane + (y0 + lr * K::NR + j) * K::W + sx * 4;
+                const f4 r = f4{st.acc[j][c][0] * inv, st.acc[j][c][1] * inv, st.acc[j][c][2] * inv, st.acc[j][c][3] * inv};
+                if constexpr (K::FLAGS & 256) { if (r[0] == 1.2345e-30f) *reinterpret_cast<f4 *>(p) = r; }   // experiment: no stores
+                else __builtin_nontemporal_store(r, reinterpret_cast<f4 *>(p));
+            }
+#ifdef CERB_STAMP
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if ((threadIdx.x & 63) == 0 && blockIdx.x < 512) g_strip_life[blockIdx.x][threadIdx.x >> 6][2] = __builtin_amdgcn_s_memrealtime();
+#endif
+    };
+    if (side == 0) run(std::integral_constant<int, 0>{});
+    else run(std::integral_constant<int, 1>{});
+#endif
+}
+
+template <typename K>
+int launch_strip(const char *name, const void *in1, const void *in2, const void *goutp, void *g1p,
+                 void *g2p, const CorrGeom &g, hipStream_t s) {
+    const int nyb = g.H / K::ROWS, ncb = g.C / K::CWG;
+    const int64_t blocks = static_cast<int64_t>(g.B) * nyb * ncb * 2;
+    if (blocks > 0x7fffffff) return CERB_ETOOLARGE;
+    static std::atomic<uint64_t> lds_done{0};
+    int rc;
+    if ((rc = ensure_lds(corr_bwd_d4_strip_kernel<K>, K::LDS_BYTES, &lds_done))) return rc;
+    note_kernel(1, name);
+    hipLaunchKernelGGL((corr_bwd_d4_strip_kernel<K>), dim3(static_cast<unsigned>(blocks)),
+                       dim3(K::THREADS), K::LDS_BYTES, s, static_cast<const float *>(in1),
+                       static_cast<const float *>(in2), static_cast<const float *>(goutp),
+                       static_cast<float *>(g1p), static_cast<float *>(g2p), g.C, g.H, nyb, ncb);
+    return launch_status();
+}
+
+}  // namespace
+
+#ifdef CERB_STAMP
+extern "C" int cerberus_debug_strip_occupancy(void) {
+    using K = StripCfg<64, 8>;
+    int n = -1;
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, corr_bwd_d4_strip_kernel<K>, K::THREADS, K::LDS_BYTES);
+    return e == hipSuccess ? n : -static_cast<int>(e);
+}
+extern "C" int cerberus_debug_strip_life(void *dst, int bytes) {
+    return static_cast<int>(hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_strip_life), std::min<size_t>(bytes, sizeof(g_strip_life))));
+}
+extern "C" int cerberus_debug_strip_stamps(void *dst, int bytes) {
+    return static_cast<int>(hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_strip_stamps),
+                                                std::min<size_t>(bytes, sizeof(g_strip_stamps))));
+}
+#endif
+
+// fp32, pad = d = 4 (checked by the caller); returns CERB_EUNSUPPORTED for shapes it does not cover:
+// W in {256, 128, 64} (whole rows per wavefront), H a multiple of the rows a workgroup owns, C a
+// multiple of the workgroup's channels.  `experiment` = StripCfg::FLAGS of a timing experiment.
+int corr_strip_backward(const void *in1, const void *in2, const void *gout, void *gin1, void *gin2,
+                        const CorrGeom &g, hipStream_t s) {
+    if (static_cast<int64_t>(kND * kND) * g.H * g.W >= (1ll << 29) ||
+        static_cast<int64_t>(g.C) * g.H * g.W >= (1ll << 29))
+        return CERB_EUNSUPPORTED;
+#define CERB_STRIP(SPR, NWV, FL, NAME)                                                              \
+    if (g.H % StripCfg<SPR, NWV, FL>::ROWS == 0 && g.C % StripCfg<SPR, NWV, FL>::CWG == 0)           \
+        return launch_strip<StripCfg<SPR, NWV, FL>>(NAME, in1, in2, gout, gin1, gin2, g, s)
+    if (g.W == 256) {
+#ifdef CERB_ABLATE
+        switch (option(OPT_CORR_BWD_CSLICE)) {   // timing experiments (tools/_strip_exp.py): flags of StripCfg
+            case 1: CERB_STRIP(64, 8, 1, "corr_bwd_d4_strip_w256_f1"); break;
+            case 4: CERB_STRIP(64, 8, 4, "corr_bwd_d4_strip_w256_f4"); break;
+            case 8: CERB_STRIP(64, 8, 8, "corr_bwd_d4_strip_w256_f8"); break;
+            case 16: CERB_STRIP(64, 8, 16, "corr_bwd_d4_strip_w256_f16"); break;
+            case 24: CERB_STRIP(64, 8, 24, "corr_bwd_d4_strip_w256_f24"); break;
+            case 28: CERB_STRIP(64, 8, 28, "corr_bwd_d4_strip_w256_f28"); break;
+            case 32: CERB_STRIP(64, 8, 32, "corr_bwd_d4_strip_w256_f32"); break;
+            case 64: CERB_STRIP(64, 8, 64, "corr_bwd_d4_strip_w256_f64"); break;
+            case 256: CERB_STRIP(64, 8, 256, "corr_bwd_d4_strip_w256_f256"); break;
+            default: break;
+        }
+#endif
+        CERB_STRIP(64, 8, 0, "corr_bwd_d4_strip_w256");
+    } else if (g.W == 128) {
+        CERB_STRIP(32, 8, 0, "corr_bwd_d4_strip_w128");
+    } else if (g.W == 64) {
+        CERB_STRIP(16, 8, 0, "corr_bwd_d4_strip_w64");
+        CERB_STRIP(16, 4, 0, "corr_bwd_d4_strip_w64_c16");
+    }
+#undef CERB_STRIP
+    return CERB_EUNSUPPORTED;
+}
+
+}  // namespace cerb

@@ -763,3 +763,120 @@ def test_seeded_random_shape_sweep_16bit_tuned_vs_generic(dtype, ulp):
             err = float((a.float() - b.float()).abs().max()) / scale
             assert err <= 2 * ulp, (shape, what, err, sorted(kernels))
     assert any("mfma" in k and "fwd" in k for k in kernels) and any("mfma" in k and "bwd" in k for k in kernels), kernels
+
+
+# ---- round 3: the strip backward (corr_strip.hip) ------------------------------------------
+STRIP_SHAPES = [(2, 32, 16, 256), (1, 64, 6, 256), (5, 32, 10, 256), (1, 32, 12, 128), (2, 64, 8, 128),
+                (2, 32, 8, 64), (1, 16, 16, 64), (1, 96, 24, 64)]
+
+
+@pytest.mark.parametrize("shape", STRIP_SHAPES)
+def test_strip_backward_against_the_oracle(shape):
+    """corr_bwd_d4_strip_kernel (whole image rows per wavefront, neighbours by DPP, gradOutput
+    streamed through LDS-DMA, cyclic step order): every supported width -- 256 (wave_shr), 128
+    (wave_shr + edge select), 64 (row_shr) --, rows at both image borders in one workgroup,
+    several batch items (every rotation of the step order), against the C oracle; two launches
+    are bit-identical."""
+    B, C, H, W = shape
+    x1, x2 = hash_uniform(shape, 401), hash_uniform(shape, 402)
+    go = hash_uniform((B, 81, H, W), 403)
+    r1, r2 = oracle.corr_backward_ref(x1, x2, go, 4, 1, 4, 1, 1)
+    _lib.set_option("corr_bwd_variant", 12)
+    try:
+        g1, g2 = run_bwd(x1, x2, go, (4, 1, 4, 1, 1))
+        name = _lib.last_kernel(1)
+        g1b, g2b = run_bwd(x1, x2, go, (4, 1, 4, 1, 1))
+    finally:
+        _lib.set_option("corr_bwd_variant", 0)
+    assert name.startswith("corr_bwd_d4_strip_w%d" % W), name
+    assert rel_err(g1, r1) < TOL
+    assert rel_err(g2, r2) < TOL
+    assert np.array_equal(g1, g1b) and np.array_equal(g2, g2b)
+
+
+def test_strip_backward_is_the_default_where_the_wide_level_fills_the_chip():
+    shape = (4, 32, 128, 256)
+    x1, x2 = dev(hash_uniform(shape, 1)), dev(hash_uniform(shape, 2))
+    go = dev(hash_uniform((4, 81, 128, 256), 3))
+    torch.ops.cerberus.correlation_backward(x1, x2, go, 4, 1, 4, 1, 1, 1)
+    assert _lib.last_kernel(1) == "corr_bwd_d4_strip_w256", _lib.last_kernel(1)
+    torch.ops.cerberus.correlation_backward(x1[:1], x2[:1], go[:1], 4, 1, 4, 1, 1, 1)
+    assert not _lib.last_kernel(1).startswith("corr_bwd_d4_strip"), _lib.last_kernel(1)
+
+
+@pytest.mark.parametrize("W", [256, 128, 64])
+def test_strip_backward_keeps_nonfinite_values_local(W):
+    """The zeros a DPP shift fills in at a row's ends are the reference's zero padding, rows
+    outside the image are read as zeros through the buffer bounds, and the shifted gradOutput
+    rows of the second gradient get their out-of-row taps zeroed in LDS: NaN / Inf in gradOutput
+    or in the feature maps reach exactly the elements the reference's sums touch (which include
+    0 x Inf = NaN against the zero padding in the first gradient, correlation_cuda_kernel.cu:150-165)."""
+    H = 16 if W == 64 else 12         # a 64-wide workgroup owns 8 rows
+    shape = (1, 32, H, W)
+    x1, x2 = hash_uniform(shape, 411), hash_uniform(shape, 412)
+    go = hash_uniform((1, 81, H, W), 413)
+    go[0, 40, 5, 0] = np.nan          # centre displacement, left border pixel
+    go[0, 3, 0, W - 1] = np.inf       # top-right corner, tap above the image
+    go[0, 77, H - 1, W - 3] = -np.inf  # bottom row, near the right end
+    go[0, 9, 6, W // 2] = np.nan
+    x1[0, 3, 4, W - 1] = np.inf       # last pixel of a row: the next row's first strip must not see it
+    x2[0, 17, 7, 0] = -np.inf
+    x2[0, 5, 0, W // 3] = np.nan
+    r1, r2 = oracle.corr_backward_ref(x1, x2, go, 4, 1, 4, 1, 1)
+    _lib.set_option("corr_bwd_variant", 12)
+    try:
+        g1, g2 = run_bwd(x1, x2, go, (4, 1, 4, 1, 1))
+        assert _lib.last_kernel(1).startswith("corr_bwd_d4_strip"), _lib.last_kernel(1)
+    finally:
+        _lib.set_option("corr_bwd_variant", 0)
+    assert np.array_equal(np.isnan(g1), np.isnan(r1)) and np.array_equal(np.isinf(g1), np.isinf(r1))
+    assert np.array_equal(np.isnan(g2), np.isnan(r2)) and np.array_equal(np.isinf(g2), np.isinf(r2))
+    ok1, ok2 = np.isfinite(r1), np.isfinite(r2)
+    assert ok1.sum() > ok1.size // 2 and ok2.sum() > ok2.size // 2
+    assert rel_err(np.where(ok1, g1, 0), np.where(ok1, r1, 0)) < TOL
+    assert rel_err(np.where(ok2, g2, 0), np.where(ok2, r2, 0)) < TOL
+
+
+# ---- round 3: the benched configurations against the oracle at FULL size ---------------------
+@pytest.mark.parametrize("lvl", [0, 1, 2, 3])
+def test_config3_batch4_levels_against_the_oracle_at_full_size(lvl):
+    """The benched workload itself (BASELINE configs 3 / 4: W32 levels of 1024x512, 4 pairs per
+    GPU, fp32): forward and both gradients of the DEFAULT kernels, full tensors, against the C
+    restatement of the reference's CUDA kernels (seconds per level on the host)."""
+    C, H, W = W32_PYRAMID_1024x512[lvl]
+    shp = (4, C, H, W)
+    x1, x2, go = hash_uniform(shp, 31), hash_uniform(shp, 32), hash_uniform((4, 81, H, W), 33)
+    p = (4, 1, 4, 1, 1)
+    out = run_fwd(x1, x2, p)
+    g1, g2 = run_bwd(x1, x2, go, p)
+    assert _lib.last_kernel(0).startswith("corr_fwd_d4") and _lib.last_kernel(1).startswith("corr_bwd_d4")
+    assert rel_err(out, oracle.corr_forward_ref(x1, x2, *p)) < TOL
+    r1, r2 = oracle.corr_backward_ref(x1, x2, go, *p)
+    assert rel_err(g1, r1) < TOL
+    assert rel_err(g2, r2) < TOL
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float16, 2e-3), (torch.bfloat16, 1.6e-2)])
+@pytest.mark.parametrize("lvl", [0, 1, 2, 3])
+def test_config5_16bit_levels_against_the_oracle_at_full_size(lvl, dtype, tol):
+    """BASELINE config 5 (AMP, 2048x1024 -> W32 levels) at full level size: the 16-bit kernels
+    (matrix cores where the dispatcher takes them) against the fp64 oracle run on the rounded
+    inputs, full tensors; the tolerance is the output rounding of the storage type."""
+    C, H, W = CONFIG5_PYRAMID_2048x1024[lvl]
+    shp = (1, C, H, W)
+    x1 = torch.from_numpy(hash_uniform(shp, 61)).to(dtype)
+    x2 = torch.from_numpy(hash_uniform(shp, 62)).to(dtype)
+    go = torch.from_numpy(hash_uniform((1, 81, H, W), 63)).to(dtype)
+    p = (4, 1, 4, 1, 1)
+    out = torch.ops.cerberus.correlation(x1.to(DEV), x2.to(DEV), *p, 1)
+    fwd_name = _lib.last_kernel(0)
+    g1, g2 = torch.ops.cerberus.correlation_backward(x1.to(DEV), x2.to(DEV), go.to(DEV), *p, 1)
+    bwd_name = _lib.last_kernel(1)
+    assert "mfma" in bwd_name, bwd_name
+    if 16 < C <= 64:
+        assert "mfma" in fwd_name, fwd_name
+    a1, a2, ag = x1.double().numpy(), x2.double().numpy(), go.double().numpy()
+    assert rel_err(out.double().cpu().numpy(), oracle.corr_forward_ref(a1, a2, *p)) < tol
+    r1, r2 = oracle.corr_backward_ref(a1, a2, ag, *p)
+    assert rel_err(g1.double().cpu().numpy(), r1) < tol
+    assert rel_err(g2.double().cpu().numpy(), r2) < tol
