@@ -168,50 +168,81 @@ class Workload:
         return keep
 
 
-def per_kernel_times(wl, reps):
-    """Seconds per launch for every distinct kernel of the step (direction 0 tensors)."""
+L3_BYTES = 256 << 20   # MI355X Infinity Cache (MI355X_MICROARCH.md): FETCH_SIZE counts its hits, a replay of one launch sits in it
+
+
+def _time_graph(fn_list, reps):
+    """`reps` launches (cycling through fn_list) captured back to back in one hipGraph, replayed between
+    HIP events on the launch stream: seconds per launch (mean of 12 timed replays after 6 untimed ones:
+    the first replays after an idle gap run up to 30 % slow, tools/timing_spread.py)."""
+    for fn in fn_list[:2]:
+        fn()
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        fn_list[0]()
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        keep = [fn_list[i % len(fn_list)]() for i in range(reps)]
+    for _ in range(6):
+        graph.replay()
+    torch.cuda.synchronize()
+    samples = []
+    for _ in range(12):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        graph.replay()
+        b.record()
+        torch.cuda.synchronize()
+        samples.append(a.elapsed_time(b) * 1e-3 / reps)
+    del keep, graph
+    return float(np.mean(samples))
+
+
+def per_kernel_times(wl, reps, cold=True):
+    """Seconds per launch for every distinct kernel of the step (direction 0 tensors), two ways:
+      hot  : the same launch replayed back to back on the same tensors -- its whole working set
+             (<= 110 MB) stays in the 256 MiB Infinity Cache, so this is an on-die number;
+      cold : the launches of one graph walk through enough independent copies of the tensors that
+             more than 256 MiB (inputs alone) pass between two uses of a copy: every launch reads
+             its inputs from HBM, as it does inside the step.  The roofline fractions use this one."""
     ops = torch.ops.cerberus
     lv = wl.dirs[0]
-    calls = {}
     if "warped" not in lv[-1]:
         wl.step()
-    for l, t in enumerate(lv):
-        calls["corr_fwd_L%d" % l] = (lambda t=t: ops.correlation(t["f1"], t["warped"], *CORR_P))
-        calls["corr_bwd_L%d" % l] = (lambda t=t: ops.correlation_backward(
-            t["f1"], t["warped"], t["gout"], *CORR_P))
+    kern = dict(wl.kernels())
+
+    def calls_for(t, l):
+        c = {"corr_fwd_L%d" % l: (lambda: ops.correlation(t["f1"], t["warped"], *CORR_P)),
+             "corr_bwd_L%d" % l: (lambda: ops.correlation_backward(t["f1"], t["warped"], t["gout"], *CORR_P))}
         if l > 0:
-            calls["warp_fwd_L%d" % l] = (lambda t=t: ops.flow_warp_ctx(t["f2"], t["flow"], 1, 0))
-            calls["warp_bwd_L%d" % l] = (lambda t=t: ops.flow_warp_backward_ctx(
-                t["f2"], t["flow"], t["ctx"], t["f1"], 1, 0, True, True))
-    out = {}
-    for label, fn in calls.items():
-        fn()
-        torch.cuda.synchronize()
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            fn()
-        torch.cuda.current_stream().wait_stream(side)
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            keep = [fn() for _ in range(reps)]
-        # The first few replays after an idle gap run up to 30 % slow (clock / power ramp:
-        # tools/timing_spread.py), the step itself runs in steady state: replay a few times
-        # untimed, then report the AVERAGE launch duration over 12 timed replays.
-        for _ in range(6):
-            graph.replay()
-        torch.cuda.synchronize()
-        samples = []
-        for _ in range(12):
-            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record()
-            graph.replay()
-            b.record()
-            torch.cuda.synchronize()
-            samples.append(a.elapsed_time(b) * 1e-3 / reps)
-        out[label] = float(np.mean(samples))
-        del keep, graph
-    return out
+            c["warp_fwd_L%d" % l] = (lambda: ops.flow_warp_ctx(t["f2"], t["flow"], 1, 0))
+            c["warp_bwd_L%d" % l] = (lambda: ops.flow_warp_backward_ctx(t["f2"], t["flow"], t["ctx"], t["f1"],
+                                                                         1, 0, True, True))
+        return c
+
+    hot, cold_t = {}, {}
+    for l, t in enumerate(lv):
+        for label, fn in calls_for(t, l).items():
+            hot[label] = _time_graph([fn], reps)
+        if not cold:
+            continue
+        # independent copies of this level's tensors: enough that the smallest kernel of the level
+        # (the forward warp / correlation) still cycles through more than the Infinity Cache
+        smallest = min(v for k, v in kern.items() if k.endswith("_L%d" % l))
+        ncopy = int(min(48, L3_BYTES // smallest + 2))
+        copies = [{k: (v.clone() if torch.is_tensor(v) else v) for k, v in t.items()} for _ in range(ncopy)]
+        per_label = {}
+        for cp in copies:
+            for label, fn in calls_for(cp, l).items():
+                per_label.setdefault(label, []).append(fn)
+        for label, fns in per_label.items():
+            cold_t[label] = _time_graph(fns, max(reps, len(fns)))
+        del copies, per_label
+        torch.cuda.empty_cache()
+    return hot, cold_t
 
 
 def torch_gpu_reference(wl, budget_s=4.0):
@@ -256,50 +287,80 @@ def torch_gpu_reference(wl, budget_s=4.0):
                     "F.grid_sample + autograd, eager), %d steps in %.1f s" % (n, dt)}
 
 
-def cpu_baseline(levels, budget_s=12.0):
-    """Reference CPU path: CorrelationTorch semantics (oracle port) forward +
-    autograd backward on the B=1 pyramid, both directions = one image pair."""
+def cpu_baseline(levels, budget_s=20.0):
+    """Reference CPU path: the semantics of CorrelationTorch.forward
+    (correlation.py:11-21; oracle port, bit-identical to the reference in the build container) on
+    the config-1 tensor and the four config-3 level shapes, B = 1: forward, and forward +
+    autograd backward; 3 warm-ups, then >= 10 timed iterations each (fewer only if the time budget
+    runs out), min and median.  `value` = image pairs/s from the median fwd+bwd times (4 levels x 2
+    flow directions = one pair; correlation only)."""
     from oracle import correlation_torch_ref
     from cerberusnet_amd.synth import hash_uniform
-    data = []
-    for l, (C, H, W) in enumerate(levels):
-        data.append((torch.from_numpy(hash_uniform((1, C, H, W), 4 * l)).requires_grad_(True),
-                     torch.from_numpy(hash_uniform((1, C, H, W), 4 * l + 1)).requires_grad_(True),
-                     torch.from_numpy(hash_uniform((1, 81, H, W), 4 * l + 2))))
+    shapes = [("config1_1x64x64x128", (64, 64, 128))] + [("L%d" % l, s) for l, s in enumerate(levels)]
+    data = {}
+    for i, (name, (C, H, W)) in enumerate(shapes):
+        data[name] = (torch.from_numpy(hash_uniform((1, C, H, W), 4 * i)).requires_grad_(True),
+                      torch.from_numpy(hash_uniform((1, C, H, W), 4 * i + 1)).requires_grad_(True),
+                      torch.from_numpy(hash_uniform((1, 81, H, W), 4 * i + 2)))
 
-    def one_pair():
-        for _ in range(2):
-            for x1, x2, go in data:
-                out = correlation_torch_ref(x1, x2, 4)
-                torch.autograd.grad(out, (x1, x2), go)
+    def fwd(name):
+        x1, x2, _ = data[name]
+        with torch.no_grad():
+            return correlation_torch_ref(x1, x2, 4)
 
-    # torch's default (one thread per host core) is far from optimal on small maps: probe a
-    # few thread counts briefly and time the sample with the best one (stated in the report)
+    def fwdbwd(name):
+        x1, x2, go = data[name]
+        torch.autograd.grad(correlation_torch_ref(x1, x2, 4), (x1, x2), go)
+
+    # torch's default (one thread per host core) is far from optimal on these small maps (14x slower
+    # on the 256-core GPU box): probe a few thread counts on one image pair and use the best
     default_threads = torch.get_num_threads()
+    ncpu = os.cpu_count() or 1
     probe = {}
     for th in sorted({default_threads, 32, 16, 8}):
-        if th > (os.cpu_count() or 1):
+        if th > ncpu:
             continue
         torch.set_num_threads(th)
-        one_pair()
+        for name, _ in shapes[1:]:
+            fwdbwd(name)
         t0 = time.perf_counter()
-        one_pair()
+        for name, _ in shapes[1:]:
+            fwdbwd(name)
         probe[th] = time.perf_counter() - t0
     threads = min(probe, key=probe.get)
     torch.set_num_threads(threads)
-    n, t0 = 0, time.perf_counter()
-    while True:
-        one_pair()
-        n += 1
-        dt = time.perf_counter() - t0
-        if dt > budget_s or n >= 200:
-            break
+    t_start = time.perf_counter()
+    table = {}
+    for name, _ in shapes:
+        row = {}
+        for what, fn in (("fwd", fwd), ("fwd_bwd", fwdbwd)):
+            for _ in range(3):
+                fn(name)
+            ts = []
+            while len(ts) < 10 and (len(ts) < 3 or time.perf_counter() - t_start < budget_s):
+                t0 = time.perf_counter()
+                fn(name)
+                ts.append(time.perf_counter() - t0)
+            row[what + "_ms_min"] = round(1e3 * min(ts), 3)
+            row[what + "_ms_median"] = round(1e3 * float(np.median(ts)), 3)
+            row[what + "_iters"] = len(ts)
+        table[name] = row
+    # for the record: the config-1 forward with torch's default of one thread per host core
+    torch.set_num_threads(ncpu)
+    fwd(shapes[0][0])
+    t0 = time.perf_counter()
+    fwd(shapes[0][0])
+    all_cores_ms = round(1e3 * (time.perf_counter() - t0), 3)
     torch.set_num_threads(default_threads)
-    return {"value": round(n / dt, 4), "unit": "image-pairs/s", "cores": threads,
-            "kind": "port",
-            "sample": "%d image pairs (B=1, 4 levels x 2 directions, correlation fwd+bwd only, "
-                      "torch CPU, best of %s threads = %d, %d host cores) in %.1f s"
-                      % (n, sorted(probe), threads, os.cpu_count(), dt)}
+    pair_s = 2 * sum(table["L%d" % l]["fwd_bwd_ms_median"] for l in range(len(levels))) * 1e-3
+    return {"value": round(1.0 / pair_s, 4), "unit": "image-pairs/s", "cores": threads, "kind": "port",
+            "host_cores": ncpu, "per_shape_ms": table,
+            "config1_fwd_ms_with_all_%d_cores" % ncpu: all_cores_ms,
+            "sample": "CorrelationTorch semantics on torch CPU, B=1: config-1 tensor + the 4 level shapes, "
+                      "3 warm-ups + up to 10 timed iterations each of fwd and fwd+autograd bwd (min / median "
+                      "in per_shape_ms); value = 1 / (2 directions x sum of the levels' median fwd+bwd); "
+                      "%d threads = best of %s on a box with %d host cores, %.1f s in all"
+                      % (threads, sorted(probe), ncpu, time.perf_counter() - t_start)}
 
 
 GRAD_BYTES = 137_100_000   # HRNetV2-W32 + FlowEstimatorLite: 34.27 M fp32 parameters (BASELINE.md section 3)
@@ -323,6 +384,97 @@ def spawn_ranks(n):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     return subprocess.run(cmd, env=env).returncode
+
+
+def head_step_mode(args, device, rank, world, dist):
+    """--step head: what `--gpus N` scaling is judged on.  One step = zero_grad, PWCNetHead(1 -> 2),
+    PWCNetHead(2 -> 1), loss, backward on `--pairs` image pairs per rank at the config-3 pyramid
+    (reference loop: utilities/model_trainer.py:187-226; the head is called twice per step,
+    cerberus.py:131,135).  N > 1: the head is wrapped by cerberusnet_amd.distributed.wrap_ddp
+    (DistributedDataParallel over RCCL, 64 MB buckets, static graph): the all-reduce of its
+    gradients overlaps the backward it belongs to.  Eager launches at every N (DDP's bucket hooks
+    are not captured); at N = 1 the hipGraph replay of the same step is reported beside it."""
+    from cerberusnet_amd.distributed import wrap_ddp
+    from cerberusnet_amd.nnet_models import PWCNetHead
+    from cerberusnet_amd.synth import fill_parameters, hash_uniform, pyramid_shapes
+    levels = pyramid_shapes(args.width, args.height, 32)
+    chans = [c for c, _, _ in reversed(levels)]          # high resolution first, as HRNet lists them
+    head = PWCNetHead(chans, upsample=True,
+                      correlation_args=dict(pad_size=4, kernel_size=1, max_displacement=4, stride1=1,
+                                            stride2=1, corr_multiply=1),
+                      flow_est_network=dict(type="FlowEstimatorLite", args={}),
+                      context_network=dict(type="ContextNetwork", args={}),
+                      **{"1x1_conv_out": 32}).to(device).train()
+    fill_parameters(head, 7)                              # the same weights on every rank
+    B = args.pairs
+    pyr = lambda seed: [torch.from_numpy(hash_uniform((B, C, H, W), seed + i + 1000 * rank)).to(device)
+                        for i, (C, H, W) in enumerate(levels)]
+    p1, p2 = pyr(10), pyr(20)
+    model = wrap_ddp(head, device) if world > 1 else head
+    params = [p for p in head.parameters() if p.requires_grad]
+    loss_fn = lambda flows: sum(f.abs().mean() for f in flows)
+
+    def step():
+        for p in params:
+            p.grad = None
+        fw = model((None, p1), (None, p2))
+        bw = model((None, p2), (None, p1))
+        loss_fn(list(fw) + list(bw)).backward()
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(max(3, args.warmup)):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank != 0:
+        return
+    nparam = sum(p.numel() for p in params)
+    result = {
+        "metric": METRIC, "value": round(B * world * args.steps / dt, 2), "unit": "image-pairs/s",
+        "n_gpus": world, "steps": args.steps, "warmup": max(3, args.warmup),
+        "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {
+            "step": "head",
+            "workload": "one training step of the flow head (PWCNetHead + FlowEstimatorLite + ContextNetwork, "
+                        "%d parameters, random init) on the HRNetV2-W32 pyramid of %dx%d, %d image pairs per GPU: "
+                        "both flow directions, loss, backward; the correlation / warp / flow-upsample ops are this "
+                        "package's HIP kernels, the convolutions MIOpen's" % (nparam, args.width, args.height, B),
+            "pairs_per_gpu": B, "levels_CHW": [list(x) for x in levels],
+            "launch": "eager",
+            "sharding": ("DistributedDataParallel over RCCL (64 MB buckets, static graph): %.1f MB of gradients "
+                         "all-reduced inside every step, overlapped with backward" % (4e-6 * nparam)
+                         if world > 1 else "one rank"),
+        },
+        "roofline": None, "cpu_baseline": None,
+        "note": "the op-only headline (python bench.py, no --step) carries roofline and cpu_baseline",
+    }
+    if world == 1:
+        from cerberusnet_amd.graphs import GraphedFlowStep
+        gstep = GraphedFlowStep(head, loss_fn, p1, p2)
+        for _ in range(5):
+            gstep.graph.replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            gstep.graph.replay()
+        torch.cuda.synchronize()
+        g = (time.perf_counter() - t0) / args.steps
+        result["hipgraph_replay"] = {"ms_per_step": round(1e3 * g, 4), "pairs_per_s": round(B / g, 2)}
+    print(json.dumps(result), flush=True)
 
 
 def main():
@@ -356,6 +508,14 @@ def main():
     ap.add_argument("--no-mfma", action="store_true",
                     help="fp16 / bf16: keep the correlation on the vector kernels (option corr_no_mfma); "
                          "the fp32 path uses no MFMA either way")
+    ap.add_argument("--step", choices=["ops", "head"], default="ops",
+                    help="ops (default, the headline): the hot-path ops alone, both directions x 4 levels; "
+                         "head: one training step of the whole flow head (PWCNetHead, FlowEstimatorLite) on the same "
+                         "pyramid -- both directions, loss, backward -- under DistributedDataParallel when N > 1, so the "
+                         "gradient all-reduce runs inside the step it can hide behind")
+    ap.add_argument("--no-cold", action="store_true", help="skip the cold (HBM-resident inputs) per-kernel pass")
+    ap.add_argument("--bwd-variant", type=int, default=0, help="experiments: option corr_bwd_variant")
+    ap.add_argument("--fwd-variant", type=int, default=0, help="experiments: option corr_fwd_variant")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -369,15 +529,30 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no CPU path exists for the product)")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if args.no_mfma:
+    if args.no_mfma or args.bwd_variant or args.fwd_variant:
         from cerberusnet_amd import _lib as _cerb_lib
-        _cerb_lib.set_option("corr_no_mfma", 1)
+        _cerb_lib.set_option("corr_no_mfma", int(args.no_mfma))
+        _cerb_lib.set_option("corr_bwd_variant", args.bwd_variant)
+        _cerb_lib.set_option("corr_fwd_variant", args.fwd_variant)
     dist = None
     if world > 1 or os.environ.get("CERB_FORCE_DIST") == "1":  # the latter: 1-rank RCCL self-test
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)  # RCCL
+
+    if args.step == "head":
+        if args.dtype != "f32":
+            raise SystemExit("--step head runs in fp32")
+        if world > 1 and dist is None:
+            raise SystemExit("--step head with N > 1 needs torch.distributed")
+        if args.steps == 200 and args.warmup == 20:      # the defaults are sized for the 0.4 ms op step
+            args.steps, args.warmup = 30, 5
+        head_step_mode(args, device, rank, world, dist)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     dtype = {"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16}[args.dtype]
     wl = Workload(args.pairs, args.width, args.height, device, args.flow, args.fuse_directions,
@@ -481,6 +656,7 @@ def main():
             "ms_per_step": round(1e3 * elapsed / args.steps, 5), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {
+                "step": "ops",
                 "workload": "%s (HRNetV2-W32 pyramid of %dx%d, corr d=4 + flow-warp, %s), %d image "
                             "pairs per GPU per step (config 4's per-GPU batch), both flow "
                             "directions, fwd+bwd" % (cfg, args.width, args.height, args.dtype, args.pairs),
@@ -506,7 +682,10 @@ def main():
     # R back-to-back launches of ONE kernel are captured into a hipGraph (no host launch
     # gaps between them) and the replay is bracketed by HIP events on the launch stream.
     if rank == 0:
-        per = per_kernel_times(wl, max(2, args.probe_steps))
+        hot, cold = per_kernel_times(wl, max(2, args.probe_steps), cold=not args.no_cold)
+        # the roofline figures use the COLD launch time (inputs from HBM, as inside the step) where it
+        # was measured; "us_hot" (same tensors replayed, Infinity-Cache resident) is reported beside it
+        per = cold if cold else hot
         kern = dict(wl.kernels())
         gbps = lambda k: kern[k] / per[k] / 1e9
         # dominant kernel = the longest single launch of the step, over ALL kernels; the longest
@@ -524,8 +703,8 @@ def main():
         # a constant read from a file, labelled as such -- it is not measured by this run
         traffic, traffic_src = None, None
         cfg_key = (args.width, args.height, args.dtype)
-        tnames = {(1024, 512, "f32"): ("r02_pmc_traffic.json", "r01_pmc_traffic.json"),
-                  (2048, 1024, "f16"): ("r02_config5_f16_pmc_traffic.json",)}.get(cfg_key, ())
+        tnames = {(1024, 512, "f32"): ("r03_pmc_traffic.json", "r02_pmc_traffic.json"),
+                  (2048, 1024, "f16"): ("r03_config5_f16_pmc_traffic.json", "r02_config5_f16_pmc_traffic.json")}.get(cfg_key, ())
         for tname in tnames:
             tpath = os.path.join(REPO, "profiles", tname)
             if os.path.exists(tpath) and args.pairs == 4 and not args.fuse_directions:
@@ -540,6 +719,9 @@ def main():
             "frac": round(gbps(dominant) / HBM_PEAK_GBPS, 4), "traffic": traffic,
             "traffic_source": traffic_src, "kernel": dominant,
             "avg_us": round(per[dominant] * 1e6, 2), "algorithmic_bytes": kern[dominant],
+            "timing": ("cold: every launch of the timed graph works on its own copy of the tensors, > 256 MiB "
+                       "(the Infinity Cache) apart" if cold else
+                       "hot: one launch replayed on the same tensors (Infinity-Cache resident)"),
             "dominant_any": dominant,
             "dominant_corr": {"kernel": dom_corr, "avg_us": round(per[dom_corr] * 1e6, 2),
                               "GBps": round(gbps(dom_corr), 1),
@@ -551,7 +733,9 @@ def main():
             "corr_all_levels": {"GBps": round(corr_b / corr_t / 1e9, 1),
                                 "frac": round(corr_b / corr_t / 1e9 / HBM_PEAK_GBPS, 4),
                                 "us_per_direction": round(corr_t * 1e6, 2)},
-            "per_kernel": {k: {"us": round(per[k] * 1e6, 2), "GBps": round(gbps(k), 1)}
+            "per_kernel": {k: {"us": round(per[k] * 1e6, 2), "us_hot": round(hot[k] * 1e6, 2),
+                               "us_cold": round(cold[k] * 1e6, 2) if cold else None,
+                               "GBps": round(gbps(k), 1), "frac": round(gbps(k) / HBM_PEAK_GBPS, 4)}
                            for k in sorted(per)},
         }
         try:

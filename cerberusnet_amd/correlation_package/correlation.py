@@ -91,8 +91,8 @@ class CostVolumeConcat(torch.autograd.Function):
     The other tensors are copied into their channel slices (what ``cat`` does for them too);
     backward hands their gradients out as views of the incoming gradient, applies the
     LeakyReLU derivative from the sign of the stored volume and calls the one-launch
-    correlation backward.  The 81 channels of the buffer are an alias this function reads
-    again in backward: the buffer is the module's own and nobody writes those channels."""
+    correlation backward.  The buffer is saved for backward like any output: writing to it in
+    place before backward raises autograd's version error."""
 
     @staticmethod
     def forward(ctx, input1, input2, slope, hyper, *others):
@@ -105,17 +105,21 @@ class CostVolumeConcat(torch.autograd.Function):
         for t, wdt in zip(others, widths):
             buf[:, at:at + wdt].copy_(t)
             at += wdt
-        ctx.save_for_backward(input1, input2)
-        ctx.volume = buf.detach()[:, :oc]     # alias, deliberately outside the version check
+        # the buffer itself is saved (an output: autograd keeps it without a reference cycle), so an
+        # in-place write to it between forward and backward -- which would flip LeakyReLU derivative
+        # signs silently -- trips autograd's version check instead
+        ctx.save_for_backward(input1, input2, buf)
         ctx.hyper, ctx.slope, ctx.widths, ctx.oc = tuple(hyper), slope, widths, oc
         return buf
 
     @staticmethod
     def backward(ctx, grad):
-        input1, input2 = ctx.saved_tensors
-        g = grad[:, :ctx.oc]
-        g = torch.where(ctx.volume > 0, g, g * ctx.slope)
-        g1, g2 = torch.ops.cerberus.correlation_backward(input1, input2, g, *ctx.hyper)
+        input1, input2, buf = ctx.saved_tensors
+        g1 = g2 = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            g = grad[:, :ctx.oc]
+            g = torch.where(buf[:, :ctx.oc] > 0, g, g * ctx.slope)
+            g1, g2 = torch.ops.cerberus.correlation_backward(input1, input2, g, *ctx.hyper)
         outs, at = [], ctx.oc
         for wdt in ctx.widths:
             outs.append(grad[:, at:at + wdt])

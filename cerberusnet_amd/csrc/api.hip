@@ -225,6 +225,16 @@ int cerberus_set_option(const char *key, int value) {
 
 int cerberus_get_option(const char *key, int *value) {
     if (!key || !value) return CERB_EINVAL;
+    // read-only: 1 when the library was built with -DCERB_EXPERIMENTS (the measured-and-rejected
+    // kernel variants the dispatcher never picks exist only in such test builds)
+    if (!strcmp(key, "experiments_build")) {
+#ifdef CERB_EXPERIMENTS
+        *value = 1;
+#else
+        *value = 0;
+#endif
+        return CERB_OK;
+    }
     const int i = find_option(key);
     if (i < 0) return CERB_EINVAL;
     *value = g_option_values[i].load(std::memory_order_relaxed);

@@ -1642,6 +1642,7 @@ __global__ __launch_bounds__(K::THREADS, K::WPS) void corr_bwd_d4_rows_kernel(
 #endif
 }
 
+#ifdef CERB_EXPERIMENTS
 // ============================================================================
 // backward, column-walking variant of the displacement-row streaming kernel
 // ============================================================================
@@ -1809,6 +1810,8 @@ __global__ __launch_bounds__(K::THREADS, 2) void corr_bwd_d4_col_kernel(
     }
 #endif
 }
+
+#endif  // CERB_EXPERIMENTS
 
 // ---- host side -------------------------------------------------------------
 // 16-bit storage is only instantiated for the vector (aligned, W % 4 == 0) path; other
@@ -2018,8 +2021,11 @@ int launch_bwd_rows(const char *name, const void *in1, const void *in2, const vo
     return launch_status();
 }
 
+#ifdef CERB_EXPERIMENTS
 using BwdCol = BwdColCfg<4, 8>;     // 4x64 tiles walked down a column, 8 waves x 4 channels
+#endif
 
+#ifdef CERB_EXPERIMENTS
 template <typename K>
 int launch_bwd_col(const char *name, const void *in1, const void *in2, const void *goutp, void *g1p,
                    void *g2p, const CorrGeom &g, hipStream_t s) {
@@ -2046,6 +2052,8 @@ int launch_bwd_col(const char *name, const void *in1, const void *in2, const voi
                        tiles_y, nrange, ntile, ngroup);
     return launch_status();
 }
+
+#endif
 
 bool fast_config(const CorrGeom &g, int dtype) {
     return (dtype == CERB_F32 || dtype == CERB_F16 || dtype == CERB_BF16) && g.pad == kD &&
@@ -2078,14 +2086,18 @@ int fwd_dispatch(const void *x1, const void *x2, void *o, const CorrGeom &g, flo
                                      std::is_same<T, __half>::value ? CERB_F16 : CERB_BF16, s);
     }
     switch (option(OPT_CORR_FWD_VARIANT)) {  // tuning / test hook
+#ifdef CERB_EXPERIMENTS   // measured and rejected; never picked by the dispatcher (test builds only)
         case 1: return launch_fwd<FwdA2, T>("corr_fwd_d4_8x64", x1, x2, o, g, slope, obs, vec, s);
         case 2: return launch_fwd<FwdA1, T>("corr_fwd_d4_4x64", x1, x2, o, g, slope, obs, vec, s);
+#endif
         case 3: if (g.C % 2 == 0) return launch_fwd<FwdB1, T>("corr_fwd_d4_2x64_s2", x1, x2, o, g, slope, obs, vec, s); break;
         case 4: if (g.C % 4 == 0) return launch_fwd<FwdC1, T>("corr_fwd_d4_1x64_s4", x1, x2, o, g, slope, obs, vec, s); break;
         case 5: if (g.C % 8 == 0) return launch_fwd<FwdD1, T>("corr_fwd_d4_1x32_s8", x1, x2, o, g, slope, obs, vec, s); break;
         case 6: if (g.C % 16 == 0) return launch_fwd<FwdE1, T>("corr_fwd_d4_1x16_s16", x1, x2, o, g, slope, obs, vec, s); break;
         case 7: return launch_fwd<FwdA1b, T>("corr_fwd_d4_4x64_cc4", x1, x2, o, g, slope, obs, vec, s);
+#ifdef CERB_EXPERIMENTS
         case 8: return launch_fwd<FwdA1c, T>("corr_fwd_d4_4x64_cc4x2", x1, x2, o, g, slope, obs, vec, s);
+#endif
         case 9:
             if constexpr (sizeof(T) == 4) {
                 if (vec && dma_ok(g))
@@ -2179,7 +2191,9 @@ int bwd_dispatch(const void *x1, const void *x2, const void *go, void *g1, void 
     }
     switch (option(OPT_CORR_BWD_VARIANT)) {
         case 1: return launch_bwd<BwdWide, T>("corr_bwd_d4_8x64", x1, x2, go, g1, g2, g, vec, s);
+#ifdef CERB_EXPERIMENTS
         case 2: return launch_bwd_g3<BwdG3Wide, T>("corr_bwd_d4_g3_4x64", x1, x2, go, g1, g2, g, vec, s);
+#endif
         case 3: return launch_bwd_g3<BwdG3Wide4, T>("corr_bwd_d4_g3_8x64", x1, x2, go, g1, g2, g, vec, s);
         case 4:
             if constexpr (sizeof(T) == 4) {
@@ -2193,6 +2207,13 @@ int bwd_dispatch(const void *x1, const void *x2, const void *go, void *g1, void 
                     return launch_bwd_dma<BwdDmaNarrow>("corr_bwd_d4_dma_16x32", x1, x2, go, g1, g2, g, s);
             }
             break;
+        case 8:
+            if constexpr (sizeof(T) == 4) {
+                if (vec && dma_ok(g))
+                    return launch_bwd_rows<BwdRows84>("corr_bwd_d4_rows_4x64_cb8", x1, x2, go, g1, g2, g, s);
+            }
+            break;
+#ifdef CERB_EXPERIMENTS   // measured and rejected: test builds only
         case 6:
             if constexpr (sizeof(T) == 4) {
                 if (vec && dma_ok(g))
@@ -2205,16 +2226,16 @@ int bwd_dispatch(const void *x1, const void *x2, const void *go, void *g1, void 
                     return launch_bwd_col<BwdCol>("corr_bwd_d4_col_4x64", x1, x2, go, g1, g2, g, s);
             }
             break;
-        case 7: case 8: case 9:
+        case 7: case 9:
             if constexpr (sizeof(T) == 4) {
                 if (vec && dma_ok(g)) {
-                    const int v = option(OPT_CORR_BWD_VARIANT);
-                    if (v == 7) return launch_bwd_rows<BwdRows44>("corr_bwd_d4_rows_4x64_c16", x1, x2, go, g1, g2, g, s);
-                    if (v == 8) return launch_bwd_rows<BwdRows84>("corr_bwd_d4_rows_4x64_cb8", x1, x2, go, g1, g2, g, s);
+                    if (option(OPT_CORR_BWD_VARIANT) == 7)
+                        return launch_bwd_rows<BwdRows44>("corr_bwd_d4_rows_4x64_c16", x1, x2, go, g1, g2, g, s);
                     return launch_bwd_rows<BwdRows82>("corr_bwd_d4_rows_4x64_cb8_c16", x1, x2, go, g1, g2, g, s);
                 }
             }
             break;
+#endif
         default: break;
     }
     // few tiles (coarse level): the displacement-group kernel puts 3x the wavefronts on the

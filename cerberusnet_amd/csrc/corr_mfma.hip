@@ -231,10 +231,21 @@ __global__ __launch_bounds__(BwdMfmaCfg::THREADS, 2) void corr_bwd_d4_mfma_kerne
         // Software pipeline over the displacement rows: while the MFMAs of row ey run on the A
         // operands already in registers, the band of row ey + 1 is written and read back (LDS
         // executes a wave's operations in order, so the one band-row buffer is enough).
+        // The band rows a lane writes are read by OTHER lanes of its wave: the hardware runs a
+        // wave's LDS operations in order, and the wavefront-scope fence + wave barrier (no
+        // instruction) keeps the compiler from moving the reads above the writes, or the next
+        // band's writes above these reads, whatever it can prove about the addresses.
+        auto wave_lds_fence = [] {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        };
         auto write_band = [&](int eyi) {
+            wave_lds_fence();
 #pragma unroll
             for (int i = 0; i < kND; ++i)
                 if (!(dbg & 8)) my_arow[i] = gv[eyi][i];
+            wave_lds_fence();
         };
         auto read_a = [&](u4v (&a)[K::NSEG]) {
 #pragma unroll
@@ -521,10 +532,17 @@ __global__ __launch_bounds__(K::THREADS, 2) void corr_fwd_d4_mfma_kernel(
             if (dyi == 8 && acc[0][0][0] + acc[K::NSEG - 1][1][3] == 123.f) tt[0] = 1.f;
             continue;
         }
+        // the T tile is written by one set of lanes and read back by another (same wave): fence as
+        // in the backward's band rows (in-order LDS per wave; nothing may cross at compile time)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int s = 0; s < K::NSEG; ++s)
 #pragma unroll
             for (int j = 0; j < 4; ++j) tt[t_slot[j] + 16 * s] = low ? acc[s][0][j] : acc[s][1][j];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         if (dbg & 8) continue;   // no read-back, no stores
         // whole plane rows: lane = (dx sub-plane, pixel); scale, LeakyReLU, one rounding
 #pragma unroll

@@ -28,12 +28,17 @@ class GraphedFlowStep:
     graph is replayed, and the (static) loss tensor and flow lists are returned -- clone them
     if they must survive the next call.  Parameter ``.grad`` tensors are static too.
 
-    Caveat (PyTorch, not this package; measured on ROCm 7.2 / torch 2.10, tools/diag_graph_order.py):
-    a multi-block reduction inside ``loss_fn`` -- e.g. ``f.abs().mean()`` over a whole
-    full-resolution flow -- can replay a WRONG scalar when eager GPU work is interleaved
-    between replays, while the flows and every gradient of the same replay are bit-exact.
-    Reduce in block-sized stages (``f.abs().reshape(-1, 4096).mean(1).mean()``) or read the
-    loss from the returned flows.
+    The returned loss is NOT the scalar the graph computed: with whole-tensor reductions inside
+    ``loss_fn`` -- e.g. ``f.abs().mean()`` over a full-resolution flow, which is what the UnFlow
+    terms are -- the captured scalar came back WRONG (10.48 expected; 8.06, 13.70, 5.64 ... seen)
+    once eager GPU work ran between replays, while every flow and every gradient of the same
+    replay stayed bit-exact (ROCm 7.2 / torch 2.10, tools/diag_graph_order.py: with and without
+    the fused concat / LeakyReLU / upsample ops).  The cause has not been found: the same
+    reductions captured WITHOUT this package's head (tools/diag_graph_mean.py: plain tensors, a
+    convolution + backward, eager work interleaved) replay correctly, so it is not PyTorch's
+    reduction alone.  ``__call__`` therefore evaluates ``loss_fn`` again, eagerly and without
+    autograd, on the flows the replay wrote (exact: tests); the captured scalar stays readable as
+    ``captured_loss`` and an xfail test keeps the defect visible.
 
     The optimizer, if given, must be graph-capturable (e.g. ``torch.optim.Adam(...,
     capturable=True)``).  ``bidirectional=False`` captures the forward direction only.
@@ -71,7 +76,8 @@ class GraphedFlowStep:
 
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
-            self.loss, self.flows_fw, self.flows_bw = self._step(set_to_none=True)
+            self.captured_loss, self.flows_fw, self.flows_bw = self._step(set_to_none=True)
+        self.loss = self.captured_loss
         # the gradient tensors the graph writes (graph-pool memory): kept here and re-attached
         # on every call, so that an outside ``zero_grad(set_to_none=True)`` or an eager step in
         # between cannot leave ``p.grad`` pointing somewhere the replay does not write
@@ -108,6 +114,11 @@ class GraphedFlowStep:
         self.graph.replay()
         for p, g in zip(self.params, self.param_grads):
             p.grad = g
+        # The loss is re-evaluated EAGERLY on the flows the replay has just written (a few tiny
+        # kernels) instead of trusting the captured scalar: see the class docstring.  The
+        # captured one stays available as ``captured_loss``.
+        with torch.no_grad():
+            self.loss = self.loss_fn(list(self.flows_fw) + list(self.flows_bw))
         return self.loss, self.flows_fw, self.flows_bw
 
     def input_gradients(self):

@@ -237,6 +237,14 @@ def _flow_for(img, flow):
     return flow.to(dtype=img.dtype).contiguous()
 
 
+def _check_aligned16(t, what, name):
+    """The warp kernels read the context / workspace header as int4 (ABI v4: CERB_EINVAL otherwise).
+    torch's caching allocator hands out 512-byte aligned blocks; a sliced or re-viewed tensor may not be."""
+    if t is not None and t.numel() and t.data_ptr() % 16:
+        raise RuntimeError("%s: the warp %s must be 16-byte aligned (got an address ending in 0x%x): "
+                           "pass the tensor the forward returned, not a slice of it" % (what, name, t.data_ptr() % 16))
+
+
 def _ctx_header_bytes(B, H, W):
     """warp.hip ctx_header_bytes: one int4 tap range per 2 x 32 pixel strip."""
     return B * ((H + 1) // 2) * ((W + 31) // 32) * 16
@@ -251,8 +259,10 @@ def _flow_warp_run(image, flow, pad_mode, interp_mode, want_ctx, what):
     B, C, H, W = img.shape
     lib = _lib.get()
     ctx_bytes = lib.cerberus_flow_warp_context_bytes(B, H, W) if want_ctx else 0
-    # int64 elements: 8-byte aligned whatever the allocator's sub-block offset
+    # int64 elements; the kernels need 16-byte alignment (checked below: the caching allocator gives 512)
     ctx = torch.empty((ctx_bytes + 7) // 8, dtype=torch.int64, device=img.device) if want_ctx else None
+    if want_ctx:
+        _check_aligned16(ctx, what, "context")
     if out.numel() == 0:
         return out, ctx
     with torch.cuda.device(img.device):
@@ -302,6 +312,7 @@ def _flow_warp_backward_run(image, flow, context, grad_out, pad_mode, interp_mod
         if (context.device != img.device or not context.is_contiguous()
                 or context.numel() * context.element_size() < ctx_bytes):
             raise RuntimeError("%s: context does not belong to this image/flow shape" % what)
+        _check_aligned16(context, what, "context")
         ctx_ptr = context.data_ptr()
     # device scratch in which the tiled grad_image builds its context when the forward saved
     # none (caching allocator: no sync, graph-capturable; stream-ordered reuse keeps it
@@ -310,6 +321,7 @@ def _flow_warp_backward_run(image, flow, context, grad_out, pad_mode, interp_mod
     if need_image and context is None:
         ws_bytes = lib.cerberus_flow_warp_backward_workspace_bytes(B, C, H, W)
         ws = torch.empty((ws_bytes + 7) // 8, dtype=torch.int64, device=img.device)
+        _check_aligned16(ws, what, "workspace")
     with torch.cuda.device(img.device):
         rc = lib.cerberus_flow_warp_backward(
             img.data_ptr(), flo.data_ptr(), go.data_ptr(),

@@ -133,6 +133,62 @@ def test_graphed_flow_step_equals_eager():
         torch.backends.cudnn.deterministic = det
 
 
+def _graphed_plain_mean_setup():
+    from cerberusnet_amd.graphs import GraphedFlowStep
+    torch.manual_seed(5)
+    head = build("FlowEstimatorLite").to(DEV)
+    shapes = [(2, c, 8 * 2 ** l, 16 * 2 ** l) for l, c in enumerate(reversed(CHANS))]
+    mk = lambda: [torch.randn(s, device=DEV) for s in shapes]
+    loss_fn = lambda flows: sum(f.abs().mean() for f in flows)      # the natural (UnFlow-style) loss
+    p1, p2 = mk(), mk()
+    return head, mk, loss_fn, GraphedFlowStep(head, loss_fn, p1, p2)
+
+
+def _eager_loss(head, loss_fn, p1, p2):
+    with torch.no_grad():
+        fw = head((None, p1), (None, p2))
+        bw = head((None, p2), (None, p1))
+        return loss_fn(list(fw) + list(bw)).clone()
+
+
+def test_graphed_flow_step_returns_the_right_loss_for_a_plain_mean():
+    """with the natural loss -- whole-tensor means, PyTorch's multi-block
+    reduction -- the scalar a replay computed came back wrong once eager work ran between
+    replays.  GraphedFlowStep now evaluates the loss eagerly on the flows the replay wrote: the
+    returned value must equal the eager step's for new inputs, with eager steps interleaved."""
+    det = torch.backends.cudnn.deterministic
+    torch.backends.cudnn.deterministic = True
+    try:
+        head, mk, loss_fn, step = _graphed_plain_mean_setup()
+        for _ in range(4):
+            p1, p2 = mk(), mk()
+            loss, _, _ = step(p1, p2)
+            got = loss.detach().clone()
+            want = _eager_loss(head, loss_fn, p1, p2)     # also the interleaved eager work
+            assert torch.equal(got, want), (float(got), float(want))
+    finally:
+        torch.backends.cudnn.deterministic = det
+
+
+@pytest.mark.xfail(strict=False, reason="the loss scalar computed INSIDE the replayed graph comes back wrong "
+                   "after interleaved eager work (tools/diag_graph_order.py; cause not found, not reproduced without "
+                   "this package's head: tools/diag_graph_mean.py); GraphedFlowStep does not return it")
+def test_graphed_flow_step_captured_loss_scalar_known_defect():
+    """Keeps the defect visible: `captured_loss` is the scalar the graph itself reduced."""
+    det = torch.backends.cudnn.deterministic
+    torch.backends.cudnn.deterministic = True
+    try:
+        head, mk, loss_fn, step = _graphed_plain_mean_setup()
+        for _ in range(4):
+            p1, p2 = mk(), mk()
+            step(p1, p2)
+            got = step.captured_loss.detach().clone()
+            want = _eager_loss(head, loss_fn, p1, p2)
+            assert torch.equal(got, want), (float(got), float(want))
+    finally:
+        torch.backends.cudnn.deterministic = det
+
+
 @pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
 def test_head_under_autocast_runs_the_16bit_kernels(golden, dt):
     """AMP (BASELINE config 5): under torch.autocast the convolutions hand 16-bit features to the

@@ -10,7 +10,8 @@ DEV = "cuda:0"
 torch.backends.cudnn.deterministic = True
 cfg = sys.argv[1] if len(sys.argv) > 1 else "default"
 kw = {"default": {}, "nocat": {"fuse_concat": False}, "noleaky": {"fuse_leaky": False, "fuse_concat": False},
-      "torch": {"correlation_backend": "torch"}}[cfg]
+      "torch": {"correlation_backend": "torch"}, "noupsample": {"fuse_upsample": False},
+      "plain": {"fuse_upsample": False, "fuse_leaky": False, "fuse_concat": False}}[cfg]
 torch.manual_seed(3)
 head = build("FlowEstimatorLite", **kw).to(DEV)
 shapes = [(2, c, 8 * 2 ** l, 16 * 2 ** l) for l, c in enumerate(reversed(CHANS))]
@@ -42,7 +43,7 @@ for trial in range(4):
     loss, fw, bw = step(p1, p2)
     if "sync" in sys.argv:
         torch.cuda.synchronize()
-    g = (loss.clone(), [f.clone() for f in fw], [f.clone() for f in bw])
+    g = (step.captured_loss.clone(), [f.clone() for f in fw], [f.clone() for f in bw])   # the scalar the GRAPH reduced
     if "noeager" in sys.argv and trial == 0:
         e = g
     else:
