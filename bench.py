@@ -414,12 +414,19 @@ def head_step_mode(args, device, rank, world, dist):
     params = [p for p in head.parameters() if p.requires_grad]
     loss_fn = lambda flows: sum(f.abs().mean() for f in flows)
 
+    if args.stack_directions:
+        # PWCNetHead.forward_both: [f1; f2] against [f2; f1], one pass of the head on 2B items
+        sa = [torch.cat([x, y], 0) for x, y in zip(p1, p2)]
+        sb = [torch.cat([y, x], 0) for x, y in zip(p1, p2)]
+
     def step():
         for p in params:
             p.grad = None
-        fw = model((None, p1), (None, p2))
-        bw = model((None, p2), (None, p1))
-        loss_fn(list(fw) + list(bw)).backward()
+        if args.stack_directions:
+            flows = model((None, sa), (None, sb))
+        else:
+            flows = list(model((None, p1), (None, p2))) + list(model((None, p2), (None, p1)))
+        loss_fn(list(flows)).backward()
 
     def fence():
         torch.cuda.synchronize()
@@ -454,7 +461,8 @@ def head_step_mode(args, device, rank, world, dist):
                         "both flow directions, loss, backward; the correlation / warp / flow-upsample ops are this "
                         "package's HIP kernels, the convolutions MIOpen's" % (nparam, args.width, args.height, B),
             "pairs_per_gpu": B, "levels_CHW": [list(x) for x in levels],
-            "launch": "eager",
+            "launch": "eager" + (", both directions stacked into one pass of the head (PWCNetHead.forward_both)"
+                                 if args.stack_directions else ", the head called once per direction"),
             "sharding": ("DistributedDataParallel over RCCL (64 MB buckets, static graph): %.1f MB of gradients "
                          "all-reduced inside every step, overlapped with backward" % (4e-6 * nparam)
                          if world > 1 else "one rank"),
@@ -464,7 +472,7 @@ def head_step_mode(args, device, rank, world, dist):
     }
     if world == 1:
         from cerberusnet_amd.graphs import GraphedFlowStep
-        gstep = GraphedFlowStep(head, loss_fn, p1, p2)
+        gstep = GraphedFlowStep(head, loss_fn, p1, p2)    # (the two-call form)
         for _ in range(5):
             gstep.graph.replay()
         torch.cuda.synchronize()
@@ -513,6 +521,8 @@ def main():
                          "head: one training step of the whole flow head (PWCNetHead, FlowEstimatorLite) on the same "
                          "pyramid -- both directions, loss, backward -- under DistributedDataParallel when N > 1, so the "
                          "gradient all-reduce runs inside the step it can hide behind")
+    ap.add_argument("--stack-directions", action="store_true",
+                    help="--step head: run both flow directions as one stacked pass (PWCNetHead.forward_both)")
     ap.add_argument("--no-cold", action="store_true", help="skip the cold (HBM-resident inputs) per-kernel pass")
     ap.add_argument("--bwd-variant", type=int, default=0, help="experiments: option corr_bwd_variant")
     ap.add_argument("--fwd-variant", type=int, default=0, help="experiments: option corr_fwd_variant")

@@ -9,28 +9,41 @@
 // gradOutput values of a pixel either sit in 162 registers (2 waves/SIMD) or are re-read per
 // channel slice, and one round of workgroups runs its phases in lock-step.
 // Here a lane owns a 4-pixel STRIP and a wavefront owns whole image rows (W = 256: one row per
-// wave, 64 strips), so the horizontal neighbours of a strip are the neighbouring LANES:
+// wave, 64 strips; W = 128 / 64: 2 / 4 rows), so the horizontal neighbours of a strip are the
+// neighbouring LANES:
 //   * x rows go global -> registers, one 16-byte load per lane, channel and row; the left and
 //     right neighbour strips of the 12-float window come from v_mov_b32_dpp (wave_shr:1 /
-//     wave_shl:1, bound_ctrl): at W = 256 the wave's ends ARE the image's ends, and the zero a
-//     DPP shift fills in is the reference's zero padding -- no halo, no LDS for x at all;
+//     wave_shl:1 or row_shr:1 / row_shl:1, bound_ctrl): a row's ends ARE the image's ends, and
+//     the zero a DPP shift fills in is the reference's zero padding -- no halo, no LDS for x.
+//     (DPP on the FMA itself runs at half rate on gfx950 -- tools/ubench/dpp_probe.hip -- so the
+//     shift is 8 moves per channel row, shared by the 72 FMAs of two output rows.)
 //   * a lane accumulates NR = 2 vertically adjacent output rows x CW = 4 channels (32
 //     accumulators): the x row of step s serves dy = s-4 of the upper and dy = s-5 of the lower
-//     row, so a wave reads 10 rows for 2 (5x from L2 instead of 9x);
-//   * gradOutput is streamed, never held: step s needs 2 x 9 planes of one image row (18 KB).
-//     They arrive by LDS-DMA two steps ahead in a ring of three slots, shared by the 8 waves of
-//     the workgroup (8 x 4 = 32 channels): gradOutput is read ONCE per side whatever C, and a
-//     lane fetches the 4 values of (row, dx) just in time -- one ds_read_b128 per 16 FMAs;
+//     row, so a wave reads 10 rows for 2;
+//   * a workgroup walks its ten x rows CYCLICALLY, starting where its neighbours are (step
+//     (t - y0) mod 10 at time t): the five workgroups whose windows hold an image row fetch it in
+//     the same time step -- one L2 miss, four hits.  In natural order they fetch it two steps
+//     apart and the 2 x 3.2 MB an XCD moves in two steps do not fit its 4 MiB L2: FETCH_SIZE
+//     175 MB instead of 94 MB per launch (algorithmic reads: 76 MB);
+//   * gradOutput is streamed, never held: a step needs 2 x 9 planes of one image row (18 KB).
+//     They arrive by LDS-DMA three steps ahead in a ring of four slots, shared by the 8 waves of
+//     the workgroup (8 x 4 = 32 channels), and a lane fetches the 4 values of (row, dx) just in
+//     time -- one ds_read_b128 per 16 FMAs;
 //   * side 2 (gI2) is the same arithmetic on the flipped plane index with the gradOutput row
-//     read SHIFTED by ex: every LDS row carries a 16-byte halo of zeros on both sides and the
-//     lane reads at its cell + 4*ex bytes (an unaligned ds_read_b128): taps outside the row read
-//     exact zeros, as the reference skips them;
-//   * ~110 VGPRs -> 4 waves/SIMD (2 workgroups of 8 waves per CU at the 32 x 128 x 256 level);
-//     waves of one workgroup meet at ONE barrier per step, loads of step s+1 / DMAs of step s+2
-//     are in flight under the FMAs of step s.
+//     read SHIFTED by ex on the global side of the DMA (a dword-aligned 16-byte read per lane);
+//     the |ex| taps that fall outside the image row are zeroed in LDS once the row has landed,
+//     so they read exact zeros, as the reference skips them.  (An unaligned ds_read_b128 would
+//     do the shift on the LDS side, and works, but runs ~15x slower than an aligned one.)
+//   * a wave requests the x row of step t+2 and the planes of step t+3 AFTER its FMAs of step t:
+//     the ~130 cycles a vector-memory instruction takes to issue when a whole CU issues at once
+//     are spread over the waves' staggered arrivals at the step's one barrier;
+//   * 120 VGPRs -> 4 waves/SIMD (2 workgroups of 8 waves per CU at the 32 x 128 x 256 level).
 // The FMAs, LDS reads and their waits are inline asm in program order (hipcc hoists every LDS
 // read of an unrolled step to its top and spills otherwise); global loads, DMAs
-// and DPP moves are builtins the compiler counts and pads itself.
+// and DPP moves are builtins the compiler counts and pads itself.  Every wave issues the same
+// number of vector-memory instructions per step unconditionally, so that count is exact.
+// Where the time goes (4 pairs of 32 x 128 x 256, tools/stamp_strip.py): the ten steps are
+// 84 % VALU-busy at the 2.35 cycles a v_fmac_f32 takes with 4 waves per SIMD.
 #include <atomic>
 #include <type_traits>
 #include <utility>

@@ -139,3 +139,22 @@ class PWCNetHead(nn.Module):
         if self.upsample:
             flows = [self._upsample(f, 4) for f in flows]
         return flows[::-1]
+
+    def forward_both(self, im1_pyr, im2_pyr):
+        """Both flow directions in ONE pass: what ``cerberus.py:131,135`` computes with two calls of
+        the head on swapped inputs, ``(flows_1to2, flows_2to1) == (self(im1_pyr, im2_pyr),
+        self(im2_pyr, im1_pyr))``.  The two directions are stacked along the batch axis
+        (``[f1; f2]`` against ``[f2; f1]``): every op of the head -- the hot-path kernels and the
+        convolutions -- runs once on 2B items instead of twice on B, which halves the launches and
+        doubles the workgroups per launch (the coarse pyramid levels are latency-bound: their
+        kernels take 0.70-0.85x the time per pair at twice the batch).  Batch
+        items never interact in any op of the head, so the values are those of the two separate
+        calls (bit for bit where both batch sizes dispatch to the same kernels).  Costs one
+        concatenation of each level's features per frame order; an encoder that runs both frames
+        as one batch already holds ``[f1; f2]``."""
+        feats1, feats2 = im1_pyr[1], im2_pyr[1]
+        b = feats1[0].size(0)
+        a = [torch.cat([x, y], dim=0) for x, y in zip(feats1, feats2)]
+        sw = [torch.cat([y, x], dim=0) for x, y in zip(feats1, feats2)]
+        flows = self.forward((None, a), (None, sw))
+        return [f[:b] for f in flows], [f[b:] for f in flows]

@@ -65,3 +65,17 @@ def test_constructor_defaults_follow_reference():
     assert head.conv_1x1[0][0].in_channels == 24 and head.conv_1x1[3][0].in_channels == 8
     with pytest.raises(NotImplementedError):
         PWCNetHead(CHANS, flow_est_network=dict(type="Nope"))
+
+
+def test_forward_both_equals_the_two_separate_calls_on_cpu(golden):
+    """forward_both (both directions stacked along the batch axis) == the two calls of
+    cerberus.py:131,135, on the explicit torch backend (CPU wiring test)."""
+    g = golden("pwchead_lite")
+    head = build("FlowEstimatorLite", correlation_backend="torch").eval()
+    p1, p2 = pyramids(g)
+    with torch.no_grad():
+        fw, bw = head.forward_both((None, p1), (None, p2))
+        fw2, bw2 = head((None, p1), (None, p2)), head((None, p2), (None, p1))
+    for a, b in zip(fw + bw, list(fw2) + list(bw2)):
+        assert a.shape == b.shape
+        assert rel_err(a.numpy(), b.numpy()) < 1e-5

@@ -133,6 +133,38 @@ def test_graphed_flow_step_equals_eager():
         torch.backends.cudnn.deterministic = det
 
 
+def test_forward_both_equals_the_two_separate_calls(golden):
+    """both flow directions stacked along the batch axis in one pass of the head
+    (``forward_both``) against the two calls ``cerberus.py:131,135`` makes -- flows of both
+    directions, and the parameter gradients of a loss over both -- and against the flows the
+    REFERENCE head produced (golden fixture) for the 1 -> 2 direction."""
+    det = torch.backends.cudnn.deterministic
+    torch.backends.cudnn.deterministic = True
+    try:
+        g = golden("pwchead_lite")
+        head = build("FlowEstimatorLite").to(DEV)
+        p1, p2 = pyramids(g, DEV)
+        for p in head.parameters():
+            p.grad = None
+        fw, bw = head.forward_both((None, p1), (None, p2))
+        sum((f * f).mean() for f in fw + bw).backward()
+        grads_both = [p.grad.clone() for p in head.parameters()]
+        for p in head.parameters():
+            p.grad = None
+        fw2 = head((None, p1), (None, p2))
+        bw2 = head((None, p2), (None, p1))
+        sum((f * f).mean() for f in list(fw2) + list(bw2)).backward()
+        for a, b in zip(fw + bw, list(fw2) + list(bw2)):
+            assert a.shape == b.shape
+            assert rel_err(a.detach().cpu().numpy(), b.detach().cpu().numpy()) < 1e-5
+        for a, p in zip(grads_both, head.parameters()):
+            assert l2_err(a.cpu().numpy(), p.grad.cpu().numpy()) < 2e-3
+        for i, f in enumerate(fw):
+            assert rel_err(f.detach().cpu().numpy(), g["flow_%d" % i]) < 1e-4
+    finally:
+        torch.backends.cudnn.deterministic = det
+
+
 def _graphed_plain_mean_setup():
     from cerberusnet_amd.graphs import GraphedFlowStep
     torch.manual_seed(5)
