@@ -5,16 +5,18 @@
 # WRITE_SIZE do not fit one pass on gfx950: MI355X_MICROARCH.md, rocprofv3 PMC slots).
 set -u
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-TAG=${1:-r02}
+TAG=${1:-r03}
 COMMIT=${2:-unknown}
 OUT=gpurun_out/profiles
 mkdir -p $OUT
 # 1. the default bench command under the profiler: per kernel symbol and per (kernel, grid)
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/_stats -- python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline > $OUT/${TAG}_bench_under_rocprof.json 2> $OUT/_stats.err
+# (--no-cold --probe-steps 2: the per-kernel probe passes add only two launches per kernel, so the
+# per-(kernel, grid) averages of this trace are IN-STEP durations: 200 step replays against 2 probes)
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/_stats -- python3 bench.py --steps 200 --warmup 5 --no-cpu-baseline --no-cold --probe-steps 2 > $OUT/${TAG}_bench_under_rocprof.json 2> $OUT/_stats.err
 cp "$(find $OUT/_stats -name '*kernel_stats.csv' | head -1)" $OUT/${TAG}_kernel_stats.csv
 python3 tools/trace_by_grid.py "$(find $OUT/_stats -name '*kernel_trace.csv' | head -1)" > $OUT/${TAG}_kernel_trace_by_grid.csv
 # 1b. BASELINE config 5 (fp16, 2048x1024 pyramid): the matrix-core correlation kernels
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/_c5 -- python3 bench.py --dtype f16 --width 2048 --height 1024 --steps 20 --warmup 3 --no-cpu-baseline > $OUT/${TAG}_bench_under_rocprof_config5_f16.json 2> $OUT/_c5.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/_c5 -- python3 bench.py --dtype f16 --width 2048 --height 1024 --steps 100 --warmup 3 --no-cpu-baseline --no-cold --probe-steps 2 > $OUT/${TAG}_bench_under_rocprof_config5_f16.json 2> $OUT/_c5.err
 cp "$(find $OUT/_c5 -name '*kernel_stats.csv' | head -1)" $OUT/${TAG}_kernel_stats_config5_f16.csv
 python3 tools/trace_by_grid.py "$(find $OUT/_c5 -name '*kernel_trace.csv' | head -1)" > $OUT/${TAG}_kernel_trace_by_grid_config5_f16.csv
 # 2. every pyramid level on its own (one symbol serves several levels with different grids)
