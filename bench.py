@@ -210,8 +210,8 @@ def per_kernel_times(wl, reps, cold=True):
              its inputs from HBM, as it does inside the step.  The roofline fractions use this one."""
     ops = torch.ops.cerberus
     lv = wl.dirs[0]
-    if "warped" not in lv[-1]:
-        wl.step()
+    if any("warped" not in t for t in lv):
+        wl._direction(lv, [])
     kern = dict(wl.kernels())
 
     def calls_for(t, l):

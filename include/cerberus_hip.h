@@ -188,10 +188,14 @@ int cerberus_area_resize(const void *src, void *dst, int64_t planes, int H, int 
  *                          16 channel groups, 14 = the matrix-core kernel (fp16 / bf16 storage,
  *                          C <= 64; auto uses it for 16 < C <= 64)
  *   "corr_bwd_variant"   : 0 = auto, 1 = all 81 displacements per lane (register-staged),
- *                          2/3 = three displacement groups, 4 / 5 = LDS-DMA with the 8x64 /
- *                          16x32 tile (fp32, W % 4 == 0), 6..9 = displacement-row streaming
- *                          (4 configurations), 10 = the same walking down a column of tiles,
- *                          11 = the matrix-core kernel (fp16 / bf16 storage; auto uses it)
+ *                          3 = three displacement groups, 4 / 5 = LDS-DMA with the 8x64 /
+ *                          16x32 tile (fp32, W % 4 == 0), 8 = displacement-row streaming,
+ *                          11 = the matrix-core kernel (fp16 / bf16 storage; auto uses it),
+ *                          12 = whole image rows per wavefront (fp32, W in {256, 128, 64}; auto uses
+ *                          it on 256-wide maps with >= 192 workgroups); 2, 6, 7, 9, 10 (and forward
+ *                          1, 2, 8) are measured-and-rejected variants that exist only in
+ *                          -DCERB_EXPERIMENTS test builds (otherwise: auto)
+ *   "experiments_build"  : read-only (cerberus_get_option): 1 in a -DCERB_EXPERIMENTS build
  *   "corr_bwd_cslice"    : 0 = auto, else channels per backward workgroup (the matrix-core
  *                          backward reads it as the number of tiles a workgroup walks down)
  *   "corr_no_mfma"       : 1 = fp16 / bf16 storage never takes the matrix-core kernels: the vector
