@@ -209,7 +209,7 @@ struct StripBwd {
     // the nine (j, dx) blocks of output row j: 4 gradOutput values just in time, 16 FMAs each
     template <int J>
     __device__ __forceinline__ void row_blocks(const float (&win)[K::CW][12], unsigned lds_cur) {
-        constexpr int DEPTH = 2;                              // reads in flight
+        constexpr int DEPTH = 2;                              // reads in flight (3: no gain, 7 more VGPRs)
         f4 gq[DEPTH + 1];
         auto issue = [&](auto bc) {
             constexpr int dx = decltype(bc)::value;

@@ -279,3 +279,27 @@ def test_graphed_inference_equals_eager_eval():
             run([t[:, :1] for t in p1], p2)
     finally:
         torch.backends.cudnn.deterministic = det
+
+
+def test_onnx_export_carries_the_reference_custom_nodes(golden, tmp_path):
+    """SURVEY 8(f)-4 (export half): the head exports with the reference's custom node types --
+    ``cerberus::correlation`` with its six integer attributes and ``torch::grid_sampler``
+    (onnx_export.py:18-28) -- one correlation per pyramid level, one sampler per warped level.
+    (No onnx package in this image: the serialized graph is searched for the node and attribute names.)"""
+    from cerberusnet_amd.utilities.onnx_export import export_flow_head
+    g = golden("pwchead_lite")
+    head = build("FlowEstimatorLite", fuse_concat=False, fuse_upsample=False).to(DEV)
+    p1, p2 = pyramids(g, DEV)
+    path = str(tmp_path / "head.onnx")
+    try:
+        export_flow_head(head, [t.detach() for t in p1], [t.detach() for t in p2], path)
+    except (ImportError, ModuleNotFoundError) as exc:      # the legacy exporter wants the onnx package on some builds
+        pytest.skip("torch.onnx.export unavailable here: %r" % (exc,))
+    blob = open(path, "rb").read()
+    assert blob.count(b"correlation") >= 4 and b"cerberus" in blob
+    assert blob.count(b"grid_sampler") >= 3
+    for attr in (b"pad_size", b"kernel_size", b"max_displacement", b"stride1", b"stride2", b"corr_multiply",
+                 b"interpolation_mode", b"padding_mode", b"align_corners"):
+        assert attr in blob, attr
+    with pytest.raises(ValueError, match="fuse_concat"):
+        export_flow_head(build("FlowEstimatorLite").to(DEV), p1, p2, path)

@@ -15,6 +15,10 @@ mkdir -p $OUT
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/_stats -- python3 bench.py --steps 200 --warmup 5 --no-cpu-baseline --no-cold --probe-steps 2 > $OUT/${TAG}_bench_under_rocprof.json 2> $OUT/_stats.err
 cp "$(find $OUT/_stats -name '*kernel_stats.csv' | head -1)" $OUT/${TAG}_kernel_stats.csv
 python3 tools/trace_by_grid.py "$(find $OUT/_stats -name '*kernel_trace.csv' | head -1)" > $OUT/${TAG}_kernel_trace_by_grid.csv
+# 1a. the same step on ONE stream (--serial-directions): with two streams a kernel's duration includes the time it
+# shares the GPU with the other direction's kernel; this trace has every kernel alone on the chip, inside the step
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/_serial -- python3 bench.py --steps 200 --warmup 5 --no-cpu-baseline --no-cold --probe-steps 2 --serial-directions > $OUT/${TAG}_bench_under_rocprof_serial.json 2> $OUT/_serial.err
+python3 tools/trace_by_grid.py "$(find $OUT/_serial -name '*kernel_trace.csv' | head -1)" > $OUT/${TAG}_kernel_trace_by_grid_serial.csv
 # 1b. BASELINE config 5 (fp16, 2048x1024 pyramid): the matrix-core correlation kernels
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/_c5 -- python3 bench.py --dtype f16 --width 2048 --height 1024 --steps 100 --warmup 3 --no-cpu-baseline --no-cold --probe-steps 2 > $OUT/${TAG}_bench_under_rocprof_config5_f16.json 2> $OUT/_c5.err
 cp "$(find $OUT/_c5 -name '*kernel_stats.csv' | head -1)" $OUT/${TAG}_kernel_stats_config5_f16.csv
@@ -61,5 +65,5 @@ json.dump(res, open("%s/%s_fetch_size_calibration.json" % (out, tag), "w"), inde
 print(json.dumps(res, indent=1))
 PY
 fi
-rm -rf $OUT/_stats $OUT/_c5 $OUT/_l? $OUT/_pmc_* $OUT/_calib $OUT/*.err $OUT/_calib.out
+rm -rf $OUT/_stats $OUT/_serial $OUT/_c5 $OUT/_l? $OUT/_pmc_* $OUT/_calib $OUT/*.err $OUT/_calib.out
 ls -la $OUT
