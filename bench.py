@@ -125,27 +125,43 @@ class Workload:
                 out += [("warp_fwd_L%d" % l, wf), ("warp_bwd_L%d" % l, wb)]
         return out
 
-    def _direction(self, lv, keep):
+    def _direction(self, lv, keep, skip=None):
+        """`skip`: label of ONE launch to leave out (per-kernel in-step timing by difference); the tensors
+        it would have produced are taken from an earlier full pass (`warped`, `ctx`) or replaced by a
+        tensor of the same shape (the gradient fed to the warp backward)."""
         ops = torch.ops.cerberus
         # forward, coarse to fine
         for l, t in enumerate(lv):
             # training forward: the warp also saves its backward context (sample positions),
             # as autograd's save_for_backward does for grid_sample in the reference
             if l > 0:
-                t["warped"], t["ctx"] = ops.flow_warp_ctx(t["f2"], t["flow"], 1, 0)
+                if skip != "warp_fwd_L%d" % l:
+                    t["warped"], t["ctx"] = ops.flow_warp_ctx(t["f2"], t["flow"], 1, 0)
             else:
                 t["warped"] = t["f2"]
-            t["out"] = ops.correlation(t["f1"], t["warped"], *CORR_P)
+            if skip != "corr_fwd_L%d" % l:
+                t["out"] = ops.correlation(t["f1"], t["warped"], *CORR_P)
         # backward, fine to coarse
         for l in reversed(range(len(lv))):
             t = lv[l]
-            g1, g2 = ops.correlation_backward(t["f1"], t["warped"], t["gout"], *CORR_P)
-            keep.append(g1)
+            if skip != "corr_bwd_L%d" % l:
+                g1, g2 = ops.correlation_backward(t["f1"], t["warped"], t["gout"], *CORR_P)
+                keep.append(g1)
+            else:
+                g2 = t["f1"]
             if l > 0:
-                keep += ops.flow_warp_backward_ctx(t["f2"], t["flow"], t["ctx"], g2, 1, 0,
-                                                   True, True)
+                if skip != "warp_bwd_L%d" % l:
+                    keep += ops.flow_warp_backward_ctx(t["f2"], t["flow"], t["ctx"], g2, 1, 0,
+                                                       True, True)
             else:
                 keep.append(g2)
+
+    def serial_step(self, skip=None):
+        """Both directions on the current stream; `skip` leaves one launch of direction 0 out."""
+        keep = []
+        for i, lv in enumerate(self.dirs):
+            self._direction(lv, keep, skip if i == 0 else None)
+        return keep
 
     def step(self, streams=None):
         """One step.  The two flow directions are independent (cerberus.py:131,135 run the
@@ -243,6 +259,95 @@ def per_kernel_times(wl, reps, cold=True):
         del copies, per_label
         torch.cuda.empty_cache()
     return hot, cold_t
+
+
+STEP_ORDER = None   # labels of the launches of one direction, in _direction()'s order (filled by step_order())
+
+
+def step_order(nlevels):
+    fwd, bwd = [], []
+    for l in range(nlevels):
+        if l > 0:
+            fwd.append("warp_fwd_L%d" % l)
+        fwd.append("corr_fwd_L%d" % l)
+    for l in reversed(range(nlevels)):
+        bwd.append("corr_bwd_L%d" % l)
+        if l > 0:
+            bwd.append("warp_bwd_L%d" % l)
+    return fwd + bwd
+
+
+def trace_child(args, device):
+    """Hidden mode (--trace-child): replay the whole step on ONE stream a number of times and exit.
+    The parent runs this under `rocprofv3 --kernel-trace` and reads the kernel durations."""
+    dtype = {"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16}[args.dtype]
+    wl = Workload(args.pairs, args.width, args.height, device, args.flow, False, 1, dtype)
+    for _ in range(3):
+        wl.serial_step()
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        wl.serial_step()
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        keep = wl.serial_step()  # noqa: F841
+    for _ in range(args.steps):
+        g.replay()
+    torch.cuda.synchronize()
+
+
+def in_step_times(args, nlevels, replays=60):
+    """Seconds per launch INSIDE the step, from the profiler: a child process replays the whole step on
+    one stream (every kernel alone on the chip, caches in the state the step leaves them in) under
+    `rocprofv3 --kernel-trace`; the hot-path kernels of its trace come in blocks of 2 x 14 in the step's
+    launch order, which identifies the level of each.  Returns ({label: seconds}, info) or (None, reason)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(prof):
+        return None, "rocprofv3 not found"
+    order = step_order(nlevels)
+    out = tempfile.mkdtemp(prefix="cerb_trace_", dir="/tmp")
+    cmd = [prof, "--kernel-trace", "--output-format", "csv", "-d", out, "--", sys.executable,
+           os.path.abspath(__file__), "--trace-child", "--steps", str(replays), "--pairs", str(args.pairs),
+           "--width", str(args.width), "--height", str(args.height), "--dtype", args.dtype, "--flow", args.flow]
+    if args.no_mfma:
+        cmd.append("--no-mfma")
+    try:
+        env = dict(os.environ, TMPDIR="/tmp")
+        subprocess.run(cmd, cwd="/tmp", env=env, timeout=300, check=True, stdout=subprocess.DEVNULL,
+                       stderr=subprocess.DEVNULL)
+        paths = glob.glob(out + "/**/*kernel_trace.csv", recursive=True)
+        if not paths:
+            return None, "no kernel trace written"
+        rows = []
+        for r in csv.DictReader(open(paths[0])):
+            n = r["Kernel_Name"]
+            if any(k in n for k in ("corr_fwd", "corr_bwd", "warp_fwd", "warp_bwd")):
+                rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"]), n))
+        rows.sort()
+        per_step = 2 * len(order)
+        if len(rows) < 10 * per_step or len(rows) % per_step:
+            return None, "unexpected launch count %d in the trace" % len(rows)
+        rows = rows[-(replays - 10) * per_step:]            # graph replays only, the first ten dropped
+        acc = {k: [] for k in order}
+        for i, (_, dur, name) in enumerate(rows):
+            label = order[(i % per_step) % len(order)]
+            if label.split("_L")[0] not in name.replace("corr_bwd_d4", "corr_bwd").replace("corr_fwd_d4", "corr_fwd"):
+                return None, "trace order mismatch at %d: %s vs %s" % (i, label, name[:60])
+            acc[label].append(dur * 1e-9)
+        return ({k: float(np.mean(v)) for k, v in acc.items()},
+                {"source": "rocprofv3 --kernel-trace of a child replaying the step on one stream",
+                 "launches_per_label": len(acc[order[0]])})
+    except Exception as exc:  # the headline must not depend on the profiler
+        return None, repr(exc)[:200]
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
 
 
 def torch_gpu_reference(wl, budget_s=4.0):
@@ -523,6 +628,7 @@ def main():
                          "gradient all-reduce runs inside the step it can hide behind")
     ap.add_argument("--stack-directions", action="store_true",
                     help="--step head: run both flow directions as one stacked pass (PWCNetHead.forward_both)")
+    ap.add_argument("--trace-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-cold", action="store_true", help="skip the cold (HBM-resident inputs) per-kernel pass")
     ap.add_argument("--bwd-variant", type=int, default=0, help="experiments: option corr_bwd_variant")
     ap.add_argument("--fwd-variant", type=int, default=0, help="experiments: option corr_fwd_variant")
@@ -551,6 +657,9 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)  # RCCL
 
+    if args.trace_child:
+        trace_child(args, device)
+        return
     if args.step == "head":
         if args.dtype != "f32":
             raise SystemExit("--step head runs in fp32")
@@ -693,9 +802,14 @@ def main():
     # gaps between them) and the replay is bracketed by HIP events on the launch stream.
     if rank == 0:
         hot, cold = per_kernel_times(wl, max(2, args.probe_steps), cold=not args.no_cold)
-        # the roofline figures use the COLD launch time (inputs from HBM, as inside the step) where it
-        # was measured; "us_hot" (same tensors replayed, Infinity-Cache resident) is reported beside it
-        per = cold if cold else hot
+        instep, instep_info = ((None, "skipped") if (args.no_cold or args.fuse_directions or args.chains > 1)
+                               else in_step_times(args, len(wl.levels)))
+        # The roofline figures use the IN-STEP launch time (the profiler's kernel durations while the whole
+        # step replays on one stream: caches in the state the step leaves them in); "us_hot" (one launch
+        # replayed on the same tensors, HIP events: Infinity-Cache resident) and "us_cold" (inputs from
+        # HBM, HIP events) bracket it and are reported beside it.  Without the in-step pass (--no-cold,
+        # or no rocprofv3): cold if measured, else hot.
+        per = instep if instep else (cold if cold else hot)
         kern = dict(wl.kernels())
         gbps = lambda k: kern[k] / per[k] / 1e9
         # dominant kernel = the longest single launch of the step, over ALL kernels; the longest
@@ -729,9 +843,13 @@ def main():
             "frac": round(gbps(dominant) / HBM_PEAK_GBPS, 4), "traffic": traffic,
             "traffic_source": traffic_src, "kernel": dominant,
             "avg_us": round(per[dominant] * 1e6, 2), "algorithmic_bytes": kern[dominant],
-            "timing": ("cold: every launch of the timed graph works on its own copy of the tensors, > 256 MiB "
+            "timing": ("in-step: kernel durations from a rocprofv3 kernel trace of the whole step replayed on one stream "
+                       "(a child process of this run), %d launches per kernel" % instep_info["launches_per_label"]
+                       if instep else
+                       "cold: every launch of the timed graph works on its own copy of the tensors, > 256 MiB "
                        "(the Infinity Cache) apart" if cold else
                        "hot: one launch replayed on the same tensors (Infinity-Cache resident)"),
+            "in_step": instep_info,
             "dominant_any": dominant,
             "dominant_corr": {"kernel": dom_corr, "avg_us": round(per[dom_corr] * 1e6, 2),
                               "GBps": round(gbps(dom_corr), 1),
@@ -745,6 +863,7 @@ def main():
                                 "us_per_direction": round(corr_t * 1e6, 2)},
             "per_kernel": {k: {"us": round(per[k] * 1e6, 2), "us_hot": round(hot[k] * 1e6, 2),
                                "us_cold": round(cold[k] * 1e6, 2) if cold else None,
+                               "us_in_step": round(instep[k] * 1e6, 2) if instep else None,
                                "GBps": round(gbps(k), 1), "frac": round(gbps(k) / HBM_PEAK_GBPS, 4)}
                            for k in sorted(per)},
         }
