@@ -319,7 +319,10 @@ def in_step_times(args, nlevels, replays=60):
     if args.no_mfma:
         cmd.append("--no-mfma")
     try:
-        env = dict(os.environ, TMPDIR="/tmp")
+        env = {k: v for k, v in os.environ.items()
+               if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK",
+                            "LOCAL_WORLD_SIZE", "ROLE_RANK", "ROLE_WORLD_SIZE", "TORCHELASTIC_RUN_ID")}
+        env["TMPDIR"] = "/tmp"
         subprocess.run(cmd, cwd="/tmp", env=env, timeout=300, check=True, stdout=subprocess.DEVNULL,
                        stderr=subprocess.DEVNULL)
         paths = glob.glob(out + "/**/*kernel_trace.csv", recursive=True)
@@ -632,6 +635,7 @@ def main():
     ap.add_argument("--no-cold", action="store_true", help="skip the cold (HBM-resident inputs) per-kernel pass")
     ap.add_argument("--bwd-variant", type=int, default=0, help="experiments: option corr_bwd_variant")
     ap.add_argument("--fwd-variant", type=int, default=0, help="experiments: option corr_fwd_variant")
+    ap.add_argument("--bwd-cslice", type=int, default=0, help="experiments: option corr_bwd_cslice")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -645,11 +649,12 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no CPU path exists for the product)")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if args.no_mfma or args.bwd_variant or args.fwd_variant:
+    if args.no_mfma or args.bwd_variant or args.fwd_variant or args.bwd_cslice:
         from cerberusnet_amd import _lib as _cerb_lib
         _cerb_lib.set_option("corr_no_mfma", int(args.no_mfma))
         _cerb_lib.set_option("corr_bwd_variant", args.bwd_variant)
         _cerb_lib.set_option("corr_fwd_variant", args.fwd_variant)
+        _cerb_lib.set_option("corr_bwd_cslice", args.bwd_cslice)
     dist = None
     if world > 1 or os.environ.get("CERB_FORCE_DIST") == "1":  # the latter: 1-rank RCCL self-test
         import torch.distributed as dist
@@ -802,7 +807,7 @@ def main():
     # gaps between them) and the replay is bracketed by HIP events on the launch stream.
     if rank == 0:
         hot, cold = per_kernel_times(wl, max(2, args.probe_steps), cold=not args.no_cold)
-        instep, instep_info = ((None, "skipped") if (args.no_cold or args.fuse_directions or args.chains > 1)
+        instep, instep_info = ((None, "skipped") if (args.no_cold or args.fuse_directions or args.chains > 1 or world > 1)
                                else in_step_times(args, len(wl.levels)))
         # The roofline figures use the IN-STEP launch time (the profiler's kernel durations while the whole
         # step replays on one stream: caches in the state the step leaves them in); "us_hot" (one launch
@@ -849,7 +854,7 @@ def main():
                        "cold: every launch of the timed graph works on its own copy of the tensors, > 256 MiB "
                        "(the Infinity Cache) apart" if cold else
                        "hot: one launch replayed on the same tensors (Infinity-Cache resident)"),
-            "in_step": instep_info,
+            "in_step": instep_info if instep else {"unavailable": instep_info},
             "dominant_any": dominant,
             "dominant_corr": {"kernel": dom_corr, "avg_us": round(per[dom_corr] * 1e6, 2),
                               "GBps": round(gbps(dom_corr), 1),

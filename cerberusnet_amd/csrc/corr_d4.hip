@@ -2176,15 +2176,20 @@ int bwd_dispatch(const void *x1, const void *x2, const void *go, void *g1, void 
         return launch_bwd<BwdNarrow, T>("corr_bwd_d4_16x32", x1, x2, go, g1, g2, g, vec, s);
     }
     if constexpr (sizeof(T) == 4) {
-        // whole image rows per wavefront, neighbours by DPP (corr_strip.hip): forced by 12
         // whole image rows per wavefront, horizontal neighbours by DPP (corr_strip.hip).  Ten
         // barrier-separated steps per workgroup make it latency-bound on small problems: it is
-        // the default where the 256-wide level fills the chip (>= 0.75 eight-wave workgroups per
-        // CU: 31.6 vs 38.1 us at 4 pairs of 32 x 128 x 256, 20.4 vs 25.0 at two, 18.1 vs 16.2 at one);
-        // variant 12 forces it on every shape it supports.
+        // the default where a level has enough eight-wave workgroups for the chip -- 256-wide:
+        // 31.6 vs 38.1 us at 4 pairs of 32 x 128 x 256, 20.4 vs 25.0 at two, 18.1 vs 16.2 at one;
+        // 128- and 64-wide (2 / 4 rows per wavefront): a tie or a small loss launch by launch
+        // (21.0 vs 21.3, 18.5 vs 16.4 us) but 2.9 % more pairs/s in the whole step (0.3765 vs
+        // 0.3875 ms, three alternating runs: it leaves LDS and L2 to the other stream's kernel).
+        // Variant 12 forces it on every shape it supports, 13 keeps it off the 64-wide maps.
         const int v = option(OPT_CORR_BWD_VARIANT);
-        const int64_t strip_wgs = static_cast<int64_t>(g.B) * (g.H / 2) * (g.C / 32) * 2;
-        if (vec && dma_ok(g) && (v == 12 || (v == 0 && g.W == 256 && strip_wgs >= 192))) {
+        const int rows_per_wg = g.W == 256 ? 2 : g.W == 128 ? 4 : 8;
+        const int64_t strip_wgs = static_cast<int64_t>(g.B) * (g.H / rows_per_wg) * (g.C / 32) * 2;
+        const bool strip_auto = (g.W == 256 && strip_wgs >= 192) || (g.W == 128 && strip_wgs >= 192) ||
+                                (g.W == 64 && strip_wgs >= 128 && v != 13);
+        if (vec && dma_ok(g) && (v == 12 || ((v == 0 || v == 13) && strip_auto))) {
             const int rc = corr_strip_backward(x1, x2, go, g1, g2, g, s);
             if (rc != CERB_EUNSUPPORTED) return rc;
         }

@@ -71,19 +71,19 @@ __device__ __forceinline__ void static_for(F &&f) {
 
 // SPR  4-pixel strips per image row (W = 4 * SPR); a wave holds RW = 64 / SPR lane-rows
 // NWV  waves per workgroup = channel groups of CW = 4 that share the gradOutput stream
-template <int SPR_, int NWV_, int FLAGS_ = 0>
+template <int SPR_, int NWV_, int FLAGS_ = 0, int CW_ = 4>
 struct StripCfg {
     // timing-experiment flags (-DCERB_ABLATE builds): 1 gradOutput DMA non-temporal, 2 x loads non-temporal, 4 no FMAs,
     // 8 no loads / DMAs, 16 no LDS reads, 32 natural step order, 64 no step barrier, 256 no stores (all but 1, 2, 32: wrong results)
     static constexpr int FLAGS = FLAGS_;
     static constexpr int SPR = SPR_, W = 4 * SPR_, RW = 64 / SPR_;
-    static constexpr int NR = 2, CW = 4, NWV = NWV_, CWG = CW * NWV_;
+    static constexpr int NR = 2, CW = CW_, NWV = NWV_, CWG = CW * NWV_;
     static constexpr int ROWS = NR * RW;                 // image rows per workgroup
     static constexpr int THREADS = 64 * NWV_;
     static constexpr int NSLOT = 4;
     // waves per SIMD the register allocator leaves room for: two 8-wave workgroups per CU on the 256-wide level
     // (one round of 512 workgroups at 4 pairs); the narrower levels have fewer workgroups than that anyway
-    static constexpr int WPS = SPR_ == 64 ? 4 : 2;
+    static constexpr int WPS = (SPR_ == 64 || CW_ < 4) ? 4 : 2;
     static constexpr int PITCH = W * 4;                  // bytes per staged gradOutput row
     static constexpr int ENTRY = RW * PITCH;             // one (j, dx) plane: RW rows
     static constexpr int SLOT = NR * kND * ENTRY;        // one step

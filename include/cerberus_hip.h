@@ -192,7 +192,8 @@ int cerberus_area_resize(const void *src, void *dst, int64_t planes, int H, int 
  *                          16x32 tile (fp32, W % 4 == 0), 8 = displacement-row streaming,
  *                          11 = the matrix-core kernel (fp16 / bf16 storage; auto uses it),
  *                          12 = whole image rows per wavefront (fp32, W in {256, 128, 64}; auto uses
- *                          it on 256-wide maps with >= 192 workgroups); 2, 6, 7, 9, 10 (and forward
+ *                          it where such a map has enough workgroups for the chip; 13 = auto, but not
+ *                          on 64-wide maps); 2, 6, 7, 9, 10 (and forward
  *                          1, 2, 8) are measured-and-rejected variants that exist only in
  *                          -DCERB_EXPERIMENTS test builds (otherwise: auto)
  *   "experiments_build"  : read-only (cerberus_get_option): 1 in a -DCERB_EXPERIMENTS build

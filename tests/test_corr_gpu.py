@@ -506,7 +506,7 @@ def test_dma_pipelines_with_fewer_chunks_than_ring_buffers(C, hw):
     out = run_fwd(x1, x2, (4, 1, 4, 1, 1))
     assert "dma" in _lib.last_kernel(0), _lib.last_kernel(0)
     g1, g2 = run_bwd(x1, x2, go, (4, 1, 4, 1, 1))
-    assert any(k in _lib.last_kernel(1) for k in ("dma", "g3", "rows")), _lib.last_kernel(1)
+    assert any(k in _lib.last_kernel(1) for k in ("dma", "g3", "rows", "strip")), _lib.last_kernel(1)
     ref = oracle.corr_forward_ref(x1, x2, 4, 1, 4, 1, 1)
     r1, r2 = oracle.corr_backward_ref(x1, x2, go, 4, 1, 4, 1, 1)
     assert rel_err(out, ref) < TOL
@@ -821,6 +821,14 @@ def test_strip_backward_is_the_default_where_the_wide_level_fills_the_chip():
     assert _lib.last_kernel(1) == "corr_bwd_d4_strip_w256", _lib.last_kernel(1)
     torch.ops.cerberus.correlation_backward(x1[:1], x2[:1], go[:1], 4, 1, 4, 1, 1, 1)
     assert not _lib.last_kernel(1).startswith("corr_bwd_d4_strip"), _lib.last_kernel(1)
+    # the 128- and 64-wide levels of the benched pyramid at 4 pairs (2 / 4 image rows per wavefront)
+    for (C, H, W), want in (((64, 64, 128), "corr_bwd_d4_strip_w128"), ((128, 32, 64), "corr_bwd_d4_strip_w64")):
+        a, b = dev(hash_uniform((4, C, H, W), 1)), dev(hash_uniform((4, C, H, W), 2))
+        g = dev(hash_uniform((4, 81, H, W), 3))
+        torch.ops.cerberus.correlation_backward(a, b, g, 4, 1, 4, 1, 1, 1)
+        assert _lib.last_kernel(1) == want, _lib.last_kernel(1)
+        torch.ops.cerberus.correlation_backward(a[:1], b[:1], g[:1], 4, 1, 4, 1, 1, 1)
+        assert not _lib.last_kernel(1).startswith("corr_bwd_d4_strip"), _lib.last_kernel(1)
 
 
 @pytest.mark.parametrize("W", [256, 128, 64])
