@@ -907,3 +907,25 @@ def test_config5_16bit_levels_against_the_oracle_at_full_size(lvl, dtype, tol):
     r1, r2 = oracle.corr_backward_ref(a1, a2, ag, *p)
     assert rel_err(g1.double().cpu().numpy(), r1) < tol
     assert rel_err(g2.double().cpu().numpy(), r2) < tol
+
+
+def test_concat_buffer_written_in_place_before_backward_raises():
+    """CostVolumeConcat saves the concatenation buffer for backward like any output; an
+    in-place write to it (which would flip LeakyReLU derivative signs silently) trips autograd's
+    version check, and the correlation backward is skipped when neither input needs a gradient."""
+    from cerberusnet_amd.correlation_package.correlation import cost_volume_concat
+    shp = (1, 8, 10, 20)
+    a = dev(hash_uniform(shp, 1)).requires_grad_(True)
+    b = dev(hash_uniform(shp, 2)).requires_grad_(True)
+    other = dev(hash_uniform((1, 3, 10, 20), 3)).requires_grad_(True)
+    hyper = (4, 1, 4, 1, 1, 1)
+    buf = cost_volume_concat(a, b, [other], hyper, 0.1)
+    buf.mul_(2.0)
+    with pytest.raises(RuntimeError, match="modified by an inplace operation"):
+        buf.sum().backward()
+    buf = cost_volume_concat(a.detach(), b.detach(), [other], hyper, 0.1)
+    before = _lib.last_kernel(1)
+    _lib.set_option("corr_bwd_variant", 0)
+    buf.sum().backward()                       # only `other` needs a gradient
+    assert torch.equal(other.grad, torch.ones_like(other))
+    assert _lib.last_kernel(1) == before       # no correlation backward was launched

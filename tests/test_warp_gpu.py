@@ -532,3 +532,19 @@ def test_area_resize_pyramid_half_errors():
         ca.area_resize(xr, (4, 4)).sum().backward()
     with pytest.raises(RuntimeError, match="no CPU implementation"):
         ca.area_resize(x.cpu(), (4, 4))
+
+
+def test_a_misaligned_context_is_rejected_with_a_clear_message():
+    """ADVICE r2: the warp kernels read the context header as int4 (ABI v4: CERB_EINVAL otherwise);
+    a context re-viewed at an 8-byte offset must be refused by the binding, not at launch time."""
+    shape = (1, 4, 12, 40)
+    img = torch.from_numpy(hash_uniform(shape, 1)).to(DEV)
+    flo = torch.from_numpy(hash_uniform((1, 2, 12, 40), 2, -2.0, 2.0)).to(DEV)
+    go = torch.from_numpy(hash_uniform(shape, 3)).to(DEV)
+    _, ctx = torch.ops.cerberus.flow_warp_ctx(img, flo, 1, 0)
+    assert ctx.data_ptr() % 16 == 0
+    shifted = torch.empty(ctx.numel() + 1, dtype=ctx.dtype, device=DEV)[1:]
+    shifted.copy_(ctx)
+    assert shifted.data_ptr() % 16 == 8
+    with pytest.raises(RuntimeError, match="16-byte aligned"):
+        torch.ops.cerberus.flow_warp_backward_ctx(img, flo, shifted, go, 1, 0, True, True)
