@@ -32,13 +32,15 @@ class GraphedFlowStep:
     ``loss_fn`` -- e.g. ``f.abs().mean()`` over a full-resolution flow, which is what the UnFlow
     terms are -- the captured scalar came back WRONG (10.48 expected; 8.06, 13.70, 5.64 ... seen)
     once eager GPU work ran between replays, while every flow and every gradient of the same
-    replay stayed bit-exact (ROCm 7.2 / torch 2.10, tools/diag_graph_order.py: with and without
-    the fused concat / LeakyReLU / upsample ops).  The cause has not been found: the same
-    reductions captured WITHOUT this package's head (tools/diag_graph_mean.py: plain tensors, a
-    convolution + backward, eager work interleaved) replay correctly, so it is not PyTorch's
-    reduction alone.  ``__call__`` therefore evaluates ``loss_fn`` again, eagerly and without
-    autograd, on the flows the replay wrote (exact: tests); the captured scalar stays readable as
-    ``captured_loss`` and an xfail test keeps the defect visible.
+    replay stayed bit-exact (ROCm 7.2 / torch 2.10, ``tools/diag_graph_order.py``).  It is not
+    this package's kernels: the same happens with the head on STOCK PyTorch ops only
+    (``correlation_backend="torch"``: ``CorrelationTorch`` + ``F.grid_sample`` + MIOpen, run
+    ``tools/diag_graph_order.py torch``), with and without the fused concat / LeakyReLU /
+    upsample ops; a small stand-alone graph of reductions + a convolution + backward
+    (``tools/diag_graph_mean.py``) does NOT show it, so the trigger is somewhere in PyTorch's
+    handling of the larger captured step and is left there.  ``__call__`` evaluates ``loss_fn``
+    again, eagerly and without autograd, on the flows the replay wrote (exact: tests); the
+    captured scalar stays readable as ``captured_loss`` and an xfail test keeps it visible.
 
     The optimizer, if given, must be graph-capturable (e.g. ``torch.optim.Adam(...,
     capturable=True)``).  ``bidirectional=False`` captures the forward direction only.

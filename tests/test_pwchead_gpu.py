@@ -203,8 +203,8 @@ def test_graphed_flow_step_returns_the_right_loss_for_a_plain_mean():
 
 
 @pytest.mark.xfail(strict=False, reason="the loss scalar computed INSIDE the replayed graph comes back wrong "
-                   "after interleaved eager work (tools/diag_graph_order.py; cause not found, not reproduced without "
-                   "this package's head: tools/diag_graph_mean.py); GraphedFlowStep does not return it")
+                   "after interleaved eager work -- also with the head on stock PyTorch ops only "
+                   "(tools/diag_graph_order.py torch), so not this package's kernels; GraphedFlowStep does not return it")
 def test_graphed_flow_step_captured_loss_scalar_known_defect():
     """Keeps the defect visible: `captured_loss` is the scalar the graph itself reduced."""
     det = torch.backends.cudnn.deterministic

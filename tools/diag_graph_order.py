@@ -12,6 +12,15 @@ cfg = sys.argv[1] if len(sys.argv) > 1 else "default"
 kw = {"default": {}, "nocat": {"fuse_concat": False}, "noleaky": {"fuse_leaky": False, "fuse_concat": False},
       "torch": {"correlation_backend": "torch"}, "noupsample": {"fuse_upsample": False},
       "plain": {"fuse_upsample": False, "fuse_leaky": False, "fuse_concat": False}}[cfg]
+if cfg == "torch":
+    # the reference's mesh_grid builds its mesh on the CPU and copies it over (UnFlowLoss.py:11-20): not
+    # capturable.  For this diagnosis only: the same mesh built on the device.
+    import cerberusnet_amd.nnet_models.pwcnet_sfd as _m
+    def _mesh_on_device(B, H, W):
+        ys, xs = torch.meshgrid(torch.arange(H, device=DEV, dtype=torch.float32),
+                                torch.arange(W, device=DEV, dtype=torch.float32), indexing="ij")
+        return torch.stack([xs, ys], 0).unsqueeze(0).repeat(B, 1, 1, 1)
+    _m.mesh_grid = _mesh_on_device
 torch.manual_seed(3)
 head = build("FlowEstimatorLite", **kw).to(DEV)
 shapes = [(2, c, 8 * 2 ** l, 16 * 2 ** l) for l, c in enumerate(reversed(CHANS))]
