@@ -2085,6 +2085,17 @@ int fwd_dispatch(const void *x1, const void *x2, void *o, const CorrGeom &g, flo
             return corr_mfma_forward(x1, x2, o, g, slope, obs,
                                      std::is_same<T, __half>::value ? CERB_F16 : CERB_BF16, s);
     }
+    if constexpr (sizeof(T) == 4) {
+        // coarse levels (W <= 64): independent waves, no loader, one barrier (corr_coarse.hip); 15 forces it
+        // (4 pairs: 7.2 vs 11.6 us at 256 x 16 x 32, 8.3 vs 10.8 us at 128 x 32 x 64; the tile kernels catch up
+        // once a launch has more than ~2000 (row, displacement row) workgroups)
+        const int v = option(OPT_CORR_FWD_VARIANT);
+        const bool coarse_auto = g.W <= 64 && static_cast<int64_t>(g.B) * g.H * kND <= 2048;
+        if (vec && dma_ok(g) && (v == 15 || (v == 0 && coarse_auto))) {
+            const int rc = corr_coarse_forward(x1, x2, o, g, slope, obs, s);
+            if (rc != CERB_EUNSUPPORTED) return rc;
+        }
+    }
     switch (option(OPT_CORR_FWD_VARIANT)) {  // tuning / test hook
 #ifdef CERB_EXPERIMENTS   // measured and rejected; never picked by the dispatcher (test builds only)
         case 1: return launch_fwd<FwdA2, T>("corr_fwd_d4_8x64", x1, x2, o, g, slope, obs, vec, s);
@@ -2167,6 +2178,17 @@ int bwd_dispatch(const void *x1, const void *x2, const void *go, void *g1, void 
         if (vec && dma_ok(g) && option(OPT_CORR_NO_MFMA) == 0 && (v == 0 || v == 11))
             return corr_mfma_backward(x1, x2, go, g1, g2, g,
                                       std::is_same<T, __half>::value ? CERB_F16 : CERB_BF16, s);
+    }
+    if constexpr (sizeof(T) == 4) {
+        // coarse levels (W <= 64): three waves per (output row, gradient, channel set), no loader, one barrier
+        // (corr_coarse.hip).  4 pairs: 6.9 vs 11.9 us at 256 x 16 x 32, 11.4 vs 16.4-18.7 us at 128 x 32 x 64; 8 pairs of
+        // the latter (4096 workgroups): 22.4 vs 20.0 us.  14 forces it, 15 is the dispatch without it.
+        const int v = option(OPT_CORR_BWD_VARIANT);
+        const int64_t coarse_wgs = static_cast<int64_t>(g.B) * 2 * g.H * (g.C / (g.W == 64 ? 16 : 32));
+        if (vec && dma_ok(g) && (v == 14 || (v == 0 && g.W <= 64 && coarse_wgs <= 3072))) {
+            const int rc = corr_coarse_backward(x1, x2, go, g1, g2, g, s);
+            if (rc != CERB_EUNSUPPORTED) return rc;
+        }
     }
     if (g.W <= 32) {
         if constexpr (sizeof(T) == 4) {

@@ -821,10 +821,11 @@ def test_strip_backward_is_the_default_where_the_wide_level_fills_the_chip():
     assert _lib.last_kernel(1) == "corr_bwd_d4_strip_w256", _lib.last_kernel(1)
     torch.ops.cerberus.correlation_backward(x1[:1], x2[:1], go[:1], 4, 1, 4, 1, 1, 1)
     assert not _lib.last_kernel(1).startswith("corr_bwd_d4_strip"), _lib.last_kernel(1)
-    # the 128- and 64-wide levels of the benched pyramid at 4 pairs (2 / 4 image rows per wavefront)
-    for (C, H, W), want in (((64, 64, 128), "corr_bwd_d4_strip_w128"), ((128, 32, 64), "corr_bwd_d4_strip_w64")):
-        a, b = dev(hash_uniform((4, C, H, W), 1)), dev(hash_uniform((4, C, H, W), 2))
-        g = dev(hash_uniform((4, 81, H, W), 3))
+    # the 128-wide level of the benched pyramid at 4 pairs (2 image rows per wavefront); the 64-wide one (4 rows)
+    # once it has more workgroups than the coarse-level kernel likes (8 pairs)
+    for (B, C, H, W), want in (((4, 64, 64, 128), "corr_bwd_d4_strip_w128"), ((8, 128, 32, 64), "corr_bwd_d4_strip_w64")):
+        a, b = dev(hash_uniform((B, C, H, W), 1)), dev(hash_uniform((B, C, H, W), 2))
+        g = dev(hash_uniform((B, 81, H, W), 3))
         torch.ops.cerberus.correlation_backward(a, b, g, 4, 1, 4, 1, 1, 1)
         assert _lib.last_kernel(1) == want, _lib.last_kernel(1)
         torch.ops.cerberus.correlation_backward(a[:1], b[:1], g[:1], 4, 1, 4, 1, 1, 1)
@@ -862,6 +863,100 @@ def test_strip_backward_keeps_nonfinite_values_local(W):
     assert ok1.sum() > ok1.size // 2 and ok2.sum() > ok2.size // 2
     assert rel_err(np.where(ok1, g1, 0), np.where(ok1, r1, 0)) < TOL
     assert rel_err(np.where(ok2, g2, 0), np.where(ok2, r2, 0)) < TOL
+
+
+# ---- round 3: the coarse-level kernels (corr_coarse.hip) -------------------------------------
+COARSE_SHAPES = [(2, 128, 7, 32), (1, 64, 5, 64), (3, 128, 3, 64), (2, 128, 8, 16), (1, 256, 20, 32), (4, 64, 33, 64),
+                 (1, 128, 1, 32)]
+
+
+@pytest.mark.parametrize("shape", COARSE_SHAPES)
+def test_coarse_level_kernels_against_the_oracle(shape):
+    """corr_fwd_d4_coarse_kernel / corr_bwd_d4_coarse_kernel (W = 16 / 32 / 64: channel groups interleaved in
+    the 16-lane DPP rows, lane-swap reduction, gradOutput rows by wave-private LDS-DMA with the second
+    gradient's shift on the global side): forced on maps shorter and taller than the 9-row window, forward
+    with the fused LeakyReLU into a wider buffer, against the C oracle; two launches are bit-identical."""
+    B, C, H, W = shape
+    x1, x2 = hash_uniform(shape, 421), hash_uniform(shape, 422)
+    go = hash_uniform((B, 81, H, W), 423)
+    ref = oracle.corr_forward_ref(x1, x2, 4, 1, 4, 1, 1)
+    r1, r2 = oracle.corr_backward_ref(x1, x2, go, 4, 1, 4, 1, 1)
+    _lib.set_option("corr_fwd_variant", 15)
+    _lib.set_option("corr_bwd_variant", 14)
+    try:
+        out = run_fwd(x1, x2, (4, 1, 4, 1, 1))
+        fname = _lib.last_kernel(0)
+        buf = torch.full((B, 90, H, W), 7.5, device=DEV)
+        torch.ops.cerberus.correlation_leaky_into(buf, dev(x1), dev(x2), 5, 4, 1, 4, 1, 1, 1, 0.1)
+        assert _lib.last_kernel(0) == fname
+        g1, g2 = run_bwd(x1, x2, go, (4, 1, 4, 1, 1))
+        bname = _lib.last_kernel(1)
+        g1b, g2b = run_bwd(x1, x2, go, (4, 1, 4, 1, 1))
+        outb = run_fwd(x1, x2, (4, 1, 4, 1, 1))
+    finally:
+        _lib.set_option("corr_fwd_variant", 0)
+        _lib.set_option("corr_bwd_variant", 0)
+    assert fname == "corr_fwd_d4_coarse_%d" % W and bname == "corr_bwd_d4_coarse_%d" % W, (fname, bname)
+    assert rel_err(out, ref) < TOL
+    got = buf.cpu().numpy()
+    assert rel_err(got[:, 5:86], np.where(ref > 0, ref, ref * np.float32(0.1))) < TOL
+    assert np.all(np.delete(got, np.s_[5:86], axis=1) == 7.5)
+    assert rel_err(g1, r1) < TOL and rel_err(g2, r2) < TOL
+    assert np.array_equal(g1, g1b) and np.array_equal(g2, g2b) and np.array_equal(out, outb)
+
+
+def test_coarse_level_kernels_are_the_default_on_the_coarse_levels_of_the_benched_pyramid():
+    for (B, C, H, W), fw, bw in (((4, 256, 16, 32), "corr_fwd_d4_coarse_32", "corr_bwd_d4_coarse_32"),
+                                 ((4, 128, 32, 64), "corr_fwd_d4_coarse_64", "corr_bwd_d4_coarse_64"),
+                                 ((1, 128, 32, 64), "corr_fwd_d4_coarse_64", "corr_bwd_d4_coarse_64")):
+        a, b = dev(hash_uniform((B, C, H, W), 1)), dev(hash_uniform((B, C, H, W), 2))
+        g = dev(hash_uniform((B, 81, H, W), 3))
+        torch.ops.cerberus.correlation(a, b, 4, 1, 4, 1, 1, 1)
+        torch.ops.cerberus.correlation_backward(a, b, g, 4, 1, 4, 1, 1, 1)
+        assert (_lib.last_kernel(0), _lib.last_kernel(1)) == (fw, bw), (_lib.last_kernel(0), _lib.last_kernel(1))
+    # many pairs per call: the tile / strip kernels again
+    a, b = dev(hash_uniform((8, 128, 32, 64), 1)), dev(hash_uniform((8, 128, 32, 64), 2))
+    torch.ops.cerberus.correlation(a, b, 4, 1, 4, 1, 1, 1)
+    assert "coarse" not in _lib.last_kernel(0), _lib.last_kernel(0)
+    # channel counts the lane layout does not divide: the tile kernels, silently
+    a, b = dev(hash_uniform((1, 24, 8, 32), 1)), dev(hash_uniform((1, 24, 8, 32), 2))
+    torch.ops.cerberus.correlation(a, b, 4, 1, 4, 1, 1, 1)
+    assert "coarse" not in _lib.last_kernel(0), _lib.last_kernel(0)
+
+
+@pytest.mark.parametrize("W", [32, 64])
+def test_coarse_level_kernels_keep_nonfinite_values_local(W):
+    """Zero padding by DPP fill (columns), by a skipped row with the reference's x * 0 (rows) and by the LDS patch
+    of the shifted gradOutput rows: NaN / Inf reach exactly the elements the reference's sums touch, forward and
+    both gradients (0 x Inf = NaN against the padding included, correlation_cuda_kernel.cu:60-75, 150-165)."""
+    H = 12
+    shape = (1, 128, H, W)
+    x1, x2 = hash_uniform(shape, 431), hash_uniform(shape, 432)
+    go = hash_uniform((1, 81, H, W), 433)
+    go[0, 40, 5, 0] = np.nan
+    go[0, 3, 0, W - 1] = np.inf        # top-right corner, tap above the image
+    go[0, 77, H - 1, W - 3] = -np.inf  # bottom row
+    go[0, 9, 6, W // 2] = np.nan
+    x1[0, 3, 4, W - 1] = np.inf        # last pixel of a row: the next row's first strip must not see it
+    x1[0, 100, 0, 2] = np.nan          # top row: displacement rows above the image
+    x2[0, 17, 7, 0] = -np.inf
+    x2[0, 5, 0, W // 3] = np.nan
+    ref = oracle.corr_forward_ref(x1, x2, 4, 1, 4, 1, 1)
+    r1, r2 = oracle.corr_backward_ref(x1, x2, go, 4, 1, 4, 1, 1)
+    _lib.set_option("corr_fwd_variant", 15)
+    _lib.set_option("corr_bwd_variant", 14)
+    try:
+        out = run_fwd(x1, x2, (4, 1, 4, 1, 1))
+        g1, g2 = run_bwd(x1, x2, go, (4, 1, 4, 1, 1))
+        assert "coarse" in _lib.last_kernel(0) and "coarse" in _lib.last_kernel(1)
+    finally:
+        _lib.set_option("corr_fwd_variant", 0)
+        _lib.set_option("corr_bwd_variant", 0)
+    for got, want in ((out, ref), (g1, r1), (g2, r2)):
+        assert np.array_equal(np.isnan(got), np.isnan(want)) and np.array_equal(np.isinf(got), np.isinf(want))
+        ok = np.isfinite(want)
+        assert ok.sum() > ok.size // 2
+        assert rel_err(np.where(ok, got, 0), np.where(ok, want, 0)) < TOL
 
 
 # ---- round 3: the benched configurations against the oracle at FULL size ---------------------
