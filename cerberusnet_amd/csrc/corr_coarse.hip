@@ -42,6 +42,14 @@ constexpr int kND = 2 * kD + 1;
 
 typedef float f4 __attribute__((ext_vector_type(4)));
 
+// n / d for n * d < 2^32 by one multiply-high (the magic number comes from the host): the block -> work item
+// decode has no division by a run-time value on the way to a wave's first load
+struct FastDiv {
+    uint32_t m, d;
+    explicit FastDiv(uint32_t dv) : m(static_cast<uint32_t>(((1ull << 32) + dv - 1) / dv)), d(dv) {}
+    __device__ __forceinline__ uint32_t div(uint32_t n) const { return d == 1 ? n : __umulhi(n, m); }
+};
+
 template <int B, int E, typename F>
 __device__ __forceinline__ void static_for(F &&f) {
     if constexpr (B < E) {
@@ -112,7 +120,7 @@ __device__ __forceinline__ float quad_add(float v) {   // v + v of the lane the 
 template <typename K>
 __global__ __launch_bounds__(K::THREADS, K::NW >= 8 ? 5 : 3) void corr_fwd_d4_coarse_kernel(
     const float *__restrict__ x1, const float *__restrict__ x2, float *__restrict__ out, int C, int H,
-    int cpl, float slope, int64_t out_bstride, int per_xcd) {
+    int cpl, float slope, int64_t out_bstride, unsigned per_xcd, unsigned nitems, FastDiv by_h) {
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) f4 part[];
     constexpr int SPR = K::SPR, W = K::W, CB = K::CB;
@@ -124,15 +132,15 @@ __global__ __launch_bounds__(K::THREADS, K::NW >= 8 ? 5 : 3) void corr_fwd_d4_co
     const int g = (lane >> 4) * K::KI + i16 % K::KI;
 
     COARSE_STAMP(0);
-    // grid = (8 * per_xcd, B): consecutive workgroup ids go round the 8 XCDs, so XCD x takes the
-    // (row, dy) items [x * per_xcd, (x + 1) * per_xcd) of every image -- neighbouring rows, which
-    // share their x2 rows, in the same L2.  No division by a run-time value on the way to the
-    // first load (a wave's first load used to leave 1.2 us after its start, tools/stamp_coarse.py).
-    const int item = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-    if (item >= H * kND) return;
-    const int dy = __builtin_amdgcn_readfirstlane(item % kND);
-    const int y = __builtin_amdgcn_readfirstlane(item / kND);
-    const int b = blockIdx.y;
+    // 8 * per_xcd workgroups: consecutive ids go round the 8 XCDs, so XCD x takes the items
+    // [x * per_xcd, (x + 1) * per_xcd) of the (image, row, dy) list -- at 4 pairs half an image: neighbouring
+    // rows, which share their x2 rows, meet in one L2 (fabric reads 11.1 -> 5.3 MB at 256 x 16 x 32)
+    const unsigned item = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (item >= nitems) return;
+    const unsigned row = item / kND;                           // (b, y)
+    const int dy = __builtin_amdgcn_readfirstlane(item - row * kND);
+    const int b = __builtin_amdgcn_readfirstlane(by_h.div(row));
+    const int y = __builtin_amdgcn_readfirstlane(row - b * H);
     const int y2 = y + dy - kD;
     const int plane = H * W;
     const int64_t obs = out_bstride ? out_bstride : static_cast<int64_t>(kND * kND) * plane;
@@ -163,10 +171,19 @@ __global__ __launch_bounds__(K::THREADS, K::NW >= 8 ? 5 : 3) void corr_fwd_d4_co
 #pragma unroll
         for (int i = 0; i < CB; ++i) {
             xa[set][i] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(r1, live ? v1 + i * plane * 4 : kDead, soff, 0));
-            xw[set][i] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(r2, live ? v2 + i * plane * 4 : kDead, soff, 0));
+            xw[set][i] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(r2, (live && inside) ? v2 + i * plane * 4 : kDead, soff, 0));
         }
     };
+    float zacc[4] = {0.f, 0.f, 0.f, 0.f};
     auto compute = [&](int set) {
+        if (!inside) {
+            // x1 * 0 summed over the channels, as the reference's zero-padded x2 gives it: 0, or NaN where x1 is not finite
+#pragma unroll
+            for (int i = 0; i < CB; ++i)
+#pragma unroll
+                for (int p = 0; p < 4; ++p) zacc[p] = __builtin_fmaf(xa[set][i][p], 0.f, zacc[p]);
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < CB; ++i) {
             const f4 a = xa[set][i], w = xw[set][i];
@@ -183,19 +200,6 @@ __global__ __launch_bounds__(K::THREADS, K::NW >= 8 ? 5 : 3) void corr_fwd_d4_co
                 for (int p = 0; p < 4; ++p) fmac(acc[d][p], a[p], win[p + d]);
         }
     };
-    if (!inside) {
-        // x1 * 0 summed over the channels, as the reference's zero-padded x2 gives it: 0, or NaN where x1 is not finite
-        float z[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int c = 0; c < cpl; ++c) {
-            const f4 a = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(r1, v1, c * plane * 4, 0));
-#pragma unroll
-            for (int p = 0; p < 4; ++p) z[p] = __builtin_fmaf(a[p], 0.f, z[p]);
-        }
-#pragma unroll
-        for (int d = 0; d < kND; ++d)
-#pragma unroll
-            for (int p = 0; p < 4; ++p) acc[d][p] = z[p];
-    } else {
     load(0, 0);
     __builtin_amdgcn_sched_barrier(0);
     load(1, 1);
@@ -217,6 +221,11 @@ __global__ __launch_bounds__(K::THREADS, K::NW >= 8 ? 5 : 3) void corr_fwd_d4_co
         load(1, k + 3);
         __builtin_amdgcn_sched_barrier(0);
     }
+    if (!inside) {
+#pragma unroll
+        for (int d = 0; d < kND; ++d)
+#pragma unroll
+            for (int p = 0; p < 4; ++p) acc[d][p] = zacc[p];
     }
 
     COARSE_STAMP(4);
@@ -262,12 +271,14 @@ __global__ __launch_bounds__(K::THREADS, K::NW >= 8 ? 5 : 3) void corr_fwd_d4_co
 template <typename K>
 int launch_coarse_fwd(const char *name, const void *in1, const void *in2, void *outp, const CorrGeom &g,
                       float slope, int64_t obs, hipStream_t s) {
-    const int per_xcd = (g.H * kND + 7) / 8;
-    if (g.B > 65535) return CERB_EUNSUPPORTED;
+    const int64_t nitems = static_cast<int64_t>(g.B) * g.H * kND;
+    if (nitems * g.H >= (1ll << 32)) return CERB_EUNSUPPORTED;
+    const unsigned per_xcd = static_cast<unsigned>((nitems + 7) / 8);
     note_kernel(0, name);
-    hipLaunchKernelGGL((corr_fwd_d4_coarse_kernel<K>), dim3(8 * per_xcd, g.B), dim3(K::THREADS),
+    hipLaunchKernelGGL((corr_fwd_d4_coarse_kernel<K>), dim3(8 * per_xcd), dim3(K::THREADS),
                        K::LDS_BYTES, s, static_cast<const float *>(in1), static_cast<const float *>(in2),
-                       static_cast<float *>(outp), g.C, g.H, g.C / (K::NW * K::G), slope, obs, per_xcd);
+                       static_cast<float *>(outp), g.C, g.H, g.C / (K::NW * K::G), slope, obs, per_xcd,
+                       static_cast<unsigned>(nitems), FastDiv(static_cast<uint32_t>(g.H)));
     return launch_status();
 }
 
@@ -318,7 +329,8 @@ __device__ __forceinline__ void lds_read16(f4 &dst, unsigned addr) {
 template <typename K>
 __global__ __launch_bounds__(K::THREADS, 4) void corr_bwd_d4_coarse_kernel(
     const float *__restrict__ x1, const float *__restrict__ x2, const float *__restrict__ gout,
-    float *__restrict__ g1, float *__restrict__ g2, int C, int H, int per_xcd) {
+    float *__restrict__ g1, float *__restrict__ g2, int C, int H, unsigned per_xcd, unsigned nitems, FastDiv by_ncs,
+    FastDiv by_h) {
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int SPR = K::SPR, W = K::W, CPL = K::CPL;
@@ -328,12 +340,16 @@ __global__ __launch_bounds__(K::THREADS, 4) void corr_bwd_d4_coarse_kernel(
     const int i16 = lane & 15;
     const int sx = i16 / K::KI;
     const int g = (lane >> 4) * K::KI + i16 % K::KI;
-    // grid = (8 * per_xcd, channel sets, B); x: (row, side) items, XCD x takes a contiguous range of rows
-    const int item = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-    if (item >= 2 * H) return;
-    const int side = item & 1;
-    const int y = item >> 1;
-    const int cs = blockIdx.y, b = blockIdx.z;
+    // 8 * per_xcd workgroups; XCD x takes the items [x * per_xcd, (x + 1) * per_xcd) of the (image, gradient,
+    // row, channel set) list -- at 4 pairs one gradient of one image: its x tensor is read through one L2 only
+    // (fabric reads 19.3 -> 5.6 MB at 256 x 16 x 32)
+    const unsigned item = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (item >= nitems) return;
+    const unsigned yr = by_ncs.div(item);                      // (b, side, y)
+    const int cs = item - yr * by_ncs.d;
+    const unsigned bs = by_h.div(yr);
+    const int y = yr - bs * H;
+    const int side = bs & 1, b = bs >> 1;
     const int plane = H * W;
 
     auto run = [&](auto side_c) {
@@ -471,12 +487,15 @@ __global__ __launch_bounds__(K::THREADS, 4) void corr_bwd_d4_coarse_kernel(
 template <typename K>
 int launch_coarse_bwd(const char *name, const void *in1, const void *in2, const void *goutp, void *g1p, void *g2p,
                       const CorrGeom &g, hipStream_t s) {
-    const int per_xcd = (2 * g.H + 7) / 8, ncs = g.C / K::CSET;
-    if (g.B > 65535 || ncs > 65535) return CERB_EUNSUPPORTED;
+    const int ncs = g.C / K::CSET;
+    const int64_t nitems = static_cast<int64_t>(g.B) * 2 * g.H * ncs;
+    if (nitems * std::max(ncs, g.H) >= (1ll << 32)) return CERB_EUNSUPPORTED;
+    const unsigned per_xcd = static_cast<unsigned>((nitems + 7) / 8);
     note_kernel(1, name);
-    hipLaunchKernelGGL((corr_bwd_d4_coarse_kernel<K>), dim3(8 * per_xcd, ncs, g.B), dim3(K::THREADS), K::LDS_BYTES, s,
+    hipLaunchKernelGGL((corr_bwd_d4_coarse_kernel<K>), dim3(8 * per_xcd), dim3(K::THREADS), K::LDS_BYTES, s,
                        static_cast<const float *>(in1), static_cast<const float *>(in2), static_cast<const float *>(goutp),
-                       static_cast<float *>(g1p), static_cast<float *>(g2p), g.C, g.H, per_xcd);
+                       static_cast<float *>(g1p), static_cast<float *>(g2p), g.C, g.H, per_xcd, static_cast<unsigned>(nitems),
+                       FastDiv(static_cast<uint32_t>(ncs)), FastDiv(static_cast<uint32_t>(g.H)));
     return launch_status();
 }
 
