@@ -6,7 +6,7 @@
 // A coarse level is a few thousand pixels by hundreds of channels (4 x 256 x 16 x 32 at the
 // top of the 1024 x 512 pyramid): 4 MB in, 0.7 MB out, 42 M multiply-adds -- nothing a 256-CU
 // part can be busy with for long.  The tile kernels of corr_d4.hip take 11 us there, and 7.7 us
-// of that is still there with 16 channels (tools/_floor.py): one loader wave per workgroup issues
+// of that is still there with 16 channels (tools/floor_probe.py): one loader wave per workgroup issues
 // every LDS-DMA of its tile, the compute waves sit behind a barrier per chunk, 144 ds_bpermute
 // close the channel groups, and only 128 workgroups exist.  A kernel of independent waves that
 // each issue 16 or 32 loads and store once runs in 2.4-3.2 us here, launch included
