@@ -959,6 +959,39 @@ def test_coarse_level_kernels_keep_nonfinite_values_local(W):
         assert rel_err(np.where(ok, got, 0), np.where(ok, want, 0)) < TOL
 
 
+def test_seeded_random_shape_sweep_coarse_level_kernels_vs_generic():
+    """40 seeded random coarse-level shapes (W = 16 / 32 / 64, many channels, 1..40 rows, 1..5 pairs) through the DEFAULT
+    dispatch against the generic kernels (which the oracle tests pin): forward and both gradients; the coarse kernels
+    must have been among the kernels chosen."""
+    rng = np.random.RandomState(20261003)
+    kernels = set()
+    for trial in range(40):
+        B = int(rng.randint(1, 6))
+        W = int(rng.choice([16, 32, 64]))
+        C = int(rng.choice([64, 128, 192, 256, 320, 96, 48]))
+        H = int(rng.randint(1, 41))
+        shape = (B, C, H, W)
+        x1, x2 = dev(hash_uniform(shape, 3900 + trial)), dev(hash_uniform(shape, 4900 + trial))
+        go = dev(hash_uniform((B, 81, H, W), 5900 + trial))
+        p = (4, 1, 4, 1, 1, 1)
+        out = torch.ops.cerberus.correlation(x1, x2, *p)
+        kernels.add(_lib.last_kernel(0))
+        g1, g2 = torch.ops.cerberus.correlation_backward(x1, x2, go, *p)
+        kernels.add(_lib.last_kernel(1))
+        _lib.set_option("corr_force_generic", 1)
+        try:
+            ref = torch.ops.cerberus.correlation(x1, x2, *p)
+            r1, r2 = torch.ops.cerberus.correlation_backward(x1, x2, go, *p)
+        finally:
+            _lib.set_option("corr_force_generic", 0)
+        for a, b, what in ((out, ref, "out"), (g1, r1, "g1"), (g2, r2, "g2")):
+            scale = float(b.abs().max()) or 1.0
+            assert float((a - b).abs().max()) / scale < TOL, (shape, what, sorted(kernels))
+    for want in ("corr_fwd_d4_coarse_16", "corr_fwd_d4_coarse_32", "corr_fwd_d4_coarse_64",
+                 "corr_bwd_d4_coarse_16", "corr_bwd_d4_coarse_32", "corr_bwd_d4_coarse_64"):
+        assert want in kernels, (want, sorted(kernels))
+
+
 # ---- round 3: the benched configurations against the oracle at FULL size ---------------------
 @pytest.mark.parametrize("lvl", [0, 1, 2, 3])
 def test_config3_batch4_levels_against_the_oracle_at_full_size(lvl):
