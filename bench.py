@@ -8,10 +8,13 @@ N > 1: one process per GPU over RCCL.  Under torchrun (RANK / WORLD_SIZE set) th
 one rank; launched plainly, the parent starts `python -m torch.distributed.run` with N
 children BEFORE it touches the GPU, relays rank 0's JSON line and exits with their code.
 Every rank owns `--pairs` image pairs (weak scaling); there is no data-path collective in
-the ops.  The one exchange of data-parallel training -- the gradient all-reduce of the model
-(137.1 MB fp32 for HRNetV2-W32 + flow head) -- runs INSIDE the timed
-loop as a bucketed RCCL all-reduce on a side stream, overlapped with the step; the line
-carries pairs/s with and without it and the all-reduce bus bandwidth.
+the ops: `value` is the op-only rate of the N ranks.  The one exchange of data-parallel training
+-- the gradient all-reduce of the MODEL's parameters (137.1 MB fp32 for HRNetV2-W32 + flow head,
+BASELINE.md section 3; the ops themselves have no parameters) -- is a side report
+(`gradient_exchange`): the same loop timed again with a bucketed RCCL all-reduce on a side stream
+beside every step, and the all-reduce alone (bus bandwidth).  A 137 MB all-reduce cannot hide
+behind a 0.35 ms step; `--with-exchange` makes it part of `value` anyway, and `--step head` is the
+mode where the gradients belong to the step that is timed (the flow head under DDP).
 
 One "step" = the hot path of one training iteration over a batch of `--pairs`
 image pairs (default 4 per GPU, BASELINE config 4's per-GPU batch; the tensors
@@ -616,8 +619,10 @@ def main():
     ap.add_argument("--probe-steps", type=int, default=20)
     ap.add_argument("--flow", choices=["smooth", "noise"], default="smooth",
                     help="synthetic flow fields fed to the warp (see Workload._flow)")
-    ap.add_argument("--no-exchange", action="store_true",
-                    help="N > 1: leave the gradient all-reduce out of the timed loop")
+    ap.add_argument("--with-exchange", action="store_true",
+                    help="N > 1, --step ops: time `value` WITH the model-sized gradient all-reduce beside every step "
+                         "(default: the op-only rate; the exchange is timed in a second pass and reported beside it)")
+    ap.add_argument("--no-exchange", action="store_true", help="(the default now; accepted for old command lines)")
     ap.add_argument("--grad-mb", type=float, default=GRAD_BYTES / 1e6,
                     help="size of the gradient buffer exchanged per step (MB, fp32)")
     ap.add_argument("--bucket-mb", type=float, default=64.0)
@@ -735,7 +740,7 @@ def main():
             dt = float(t.item())
         return dt
 
-    use_exchange = exchange is not None and not args.no_exchange
+    use_exchange = exchange is not None and args.with_exchange and not args.no_exchange
     elapsed = timed(args.steps, use_exchange)
     extra = {}
     if exchange is not None:
@@ -791,8 +796,10 @@ def main():
                            ", %d streams (one per flow direction%s)" % (
                                len(streams) + 1, " and sub-batch" if args.chains > 1 else "")
                            if streams else ", 1 stream"),
-                "sharding": "image pairs sharded over ranks, no data-path collective in the ops; "
-                            "gradient all-reduce per step: see gradient_exchange" if world > 1 else
+                "sharding": ("image pairs sharded over ranks, no data-path collective in the ops; value = "
+                             + ("the rate WITH the model-sized gradient all-reduce beside every step"
+                                if use_exchange else "the op-only rate (the ops have no parameters)")
+                             + "; see gradient_exchange") if world > 1 else
                             "one rank (image pairs are sharded over ranks when N > 1)",
                 "algorithmic_bytes_per_step": step_bytes,
                 "step_algorithmic_GBps_per_gpu": round(step_bytes * args.steps / elapsed / 1e9, 1),
