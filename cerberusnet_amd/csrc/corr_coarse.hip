@@ -157,10 +157,6 @@ __global__ __launch_bounds__(K::THREADS, K::NW >= 8 ? 5 : 3) void corr_fwd_d4_co
     const int nb = cpl / CB;
 
     float acc[kND][4];
-#pragma unroll
-    for (int d = 0; d < kND; ++d)
-#pragma unroll
-        for (int p = 0; p < 4; ++p) acc[d][p] = 0.f;
     f4 xa[2][CB], xw[2][CB];
     // every batch is requested unconditionally (past the last one: out of range, zeros, no traffic) so
     // that the compiler's count of requests in flight is exact and a wait never covers the batch
@@ -175,7 +171,8 @@ __global__ __launch_bounds__(K::THREADS, K::NW >= 8 ? 5 : 3) void corr_fwd_d4_co
         }
     };
     float zacc[4] = {0.f, 0.f, 0.f, 0.f};
-    auto compute = [&](int set) {
+    auto compute = [&](int set, auto first_c) {
+        constexpr bool FIRST = decltype(first_c)::value;   // the first channel writes the accumulators (no zeroing pass)
         if (!inside) {
             // x1 * 0 summed over the channels, as the reference's zero-padded x2 gives it: 0, or NaN where x1 is not finite
 #pragma unroll
@@ -197,7 +194,10 @@ __global__ __launch_bounds__(K::THREADS, K::NW >= 8 ? 5 : 3) void corr_fwd_d4_co
 #pragma unroll
             for (int d = 0; d < kND; ++d)
 #pragma unroll
-                for (int p = 0; p < 4; ++p) fmac(acc[d][p], a[p], win[p + d]);
+                for (int p = 0; p < 4; ++p) {
+                    if (FIRST && i == 0) asm volatile("v_mul_f32_e32 %0, %1, %2" : "=v"(acc[d][p]) : "v"(a[p]), "v"(win[p + d]));
+                    else fmac(acc[d][p], a[p], win[p + d]);
+                }
         }
     };
     load(0, 0);
@@ -211,12 +211,20 @@ __global__ __launch_bounds__(K::THREADS, K::NW >= 8 ? 5 : 3) void corr_fwd_d4_co
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     COARSE_STAMP(3);
 #endif
-    for (int k = 0; k < nb; k += 2) {
-        compute(0);
+    compute(0, std::true_type{});
+    __builtin_amdgcn_sched_barrier(0);
+    load(0, 2);
+    __builtin_amdgcn_sched_barrier(0);
+    compute(1, std::false_type{});
+    __builtin_amdgcn_sched_barrier(0);
+    load(1, 3);
+    __builtin_amdgcn_sched_barrier(0);
+    for (int k = 2; k < nb; k += 2) {
+        compute(0, std::false_type{});
         __builtin_amdgcn_sched_barrier(0);
         load(0, k + 2);
         __builtin_amdgcn_sched_barrier(0);
-        compute(1);
+        compute(1, std::false_type{});
         __builtin_amdgcn_sched_barrier(0);
         load(1, k + 3);
         __builtin_amdgcn_sched_barrier(0);
@@ -272,7 +280,7 @@ template <typename K>
 int launch_coarse_fwd(const char *name, const void *in1, const void *in2, void *outp, const CorrGeom &g,
                       float slope, int64_t obs, hipStream_t s) {
     const int64_t nitems = static_cast<int64_t>(g.B) * g.H * kND;
-    if (nitems * g.H >= (1ll << 32)) return CERB_EUNSUPPORTED;
+    if (nitems * g.H >= (1ll << 32) || nitems + 8 > 0x7fffffff) return CERB_EUNSUPPORTED;   // FastDiv range, grid size
     const unsigned per_xcd = static_cast<unsigned>((nitems + 7) / 8);
     note_kernel(0, name);
     hipLaunchKernelGGL((corr_fwd_d4_coarse_kernel<K>), dim3(8 * per_xcd), dim3(K::THREADS),
@@ -489,7 +497,7 @@ int launch_coarse_bwd(const char *name, const void *in1, const void *in2, const 
                       const CorrGeom &g, hipStream_t s) {
     const int ncs = g.C / K::CSET;
     const int64_t nitems = static_cast<int64_t>(g.B) * 2 * g.H * ncs;
-    if (nitems * std::max(ncs, g.H) >= (1ll << 32)) return CERB_EUNSUPPORTED;
+    if (nitems * std::max(ncs, g.H) >= (1ll << 32) || nitems + 8 > 0x7fffffff) return CERB_EUNSUPPORTED;   // FastDiv range, grid size
     const unsigned per_xcd = static_cast<unsigned>((nitems + 7) / 8);
     note_kernel(1, name);
     hipLaunchKernelGGL((corr_bwd_d4_coarse_kernel<K>), dim3(8 * per_xcd), dim3(K::THREADS), K::LDS_BYTES, s,
