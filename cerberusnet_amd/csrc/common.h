@@ -160,9 +160,9 @@ int corr_mfma_backward(const void *in1, const void *in2, const void *gout, void 
 int corr_strip_backward(const void *in1, const void *in2, const void *gout, void *gin1, void *gin2,
                         const CorrGeom &g, hipStream_t s);
 
-// fp32 forward for the coarse levels, W = 16 / 32 / 64 (corr_coarse.hip); CERB_EUNSUPPORTED otherwise
+// forward for the coarse levels, W = 16 / 32 / 64, fp32 / fp16 / bf16 storage (corr_coarse.hip); CERB_EUNSUPPORTED otherwise
 int corr_coarse_forward(const void *in1, const void *in2, void *out, const CorrGeom &g, float slope,
-                        int64_t obs, hipStream_t s);
+                        int64_t obs, int dtype, hipStream_t s);
 
 int corr_coarse_backward(const void *in1, const void *in2, const void *gout, void *gin1, void *gin2, const CorrGeom &g,
                          hipStream_t s);

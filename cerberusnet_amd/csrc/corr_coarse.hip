@@ -50,6 +50,53 @@ struct FastDiv {
     __device__ __forceinline__ uint32_t div(uint32_t n) const { return d == 1 ? n : __umulhi(n, m); }
 };
 
+#if defined(__HIP_DEVICE_COMPILE__)
+// four consecutive pixels of storage type T at a byte offset of a buffer resource, as loaded (Px4<T>::raw), and widened
+// to fp32 where they are used -- NOT where they are requested: the conversion would wait for the load (16-bit storage is
+// widened on use and rounded to nearest even once, on store: the arithmetic is fp32 throughout)
+template <typename T> struct Px4 { typedef f4 raw; };
+template <> struct Px4<__half> { typedef unsigned raw __attribute__((ext_vector_type(2))); };
+template <> struct Px4<hip_bfloat16> { typedef unsigned raw __attribute__((ext_vector_type(2))); };
+template <typename T>
+__device__ __forceinline__ typename Px4<T>::raw load_px4(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    if constexpr (sizeof(T) == 4) return __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+    else return __builtin_bit_cast(typename Px4<T>::raw, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
+}
+template <typename T>
+__device__ __forceinline__ f4 widen_px4(typename Px4<T>::raw raw) {
+    if constexpr (sizeof(T) == 4) {
+        return raw;
+    } else if constexpr (std::is_same<T, __half>::value) {
+        // (by 16-bit halves: hipcc 7.2 drops the second dword when a vector ELEMENT is bit-cast to a _Float16 pair)
+        auto h = [](unsigned bits) { return static_cast<float>(__builtin_bit_cast(_Float16, static_cast<unsigned short>(bits))); };
+        return f4{h(raw[0]), h(raw[0] >> 16), h(raw[1]), h(raw[1] >> 16)};
+    } else {
+        return f4{__builtin_bit_cast(float, raw[0] << 16), __builtin_bit_cast(float, raw[0] & 0xffff0000u),
+                  __builtin_bit_cast(float, raw[1] << 16), __builtin_bit_cast(float, raw[1] & 0xffff0000u)};
+    }
+}
+template <typename T>
+__device__ __forceinline__ void store_px4(T *p, f4 v) {
+    if constexpr (sizeof(T) == 4) {
+        __builtin_nontemporal_store(v, reinterpret_cast<f4 *>(p));
+    } else {
+        typedef unsigned u2 __attribute__((ext_vector_type(2)));
+        typedef float f2v __attribute__((ext_vector_type(2)));
+        u2 raw;
+        if constexpr (std::is_same<T, __half>::value) {
+            typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+            raw[0] = __builtin_bit_cast(unsigned, __builtin_convertvector(f2v{v[0], v[1]}, h2));
+            raw[1] = __builtin_bit_cast(unsigned, __builtin_convertvector(f2v{v[2], v[3]}, h2));
+        } else {
+            typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+            raw[0] = __builtin_bit_cast(unsigned, __builtin_convertvector(f2v{v[0], v[1]}, b2));
+            raw[1] = __builtin_bit_cast(unsigned, __builtin_convertvector(f2v{v[2], v[3]}, b2));
+        }
+        __builtin_nontemporal_store(raw, reinterpret_cast<u2 *>(p));
+    }
+}
+#endif
+
 template <int B, int E, typename F>
 __device__ __forceinline__ void static_for(F &&f) {
     if constexpr (B < E) {
@@ -117,9 +164,9 @@ __device__ __forceinline__ float quad_add(float v) {   // v + v of the lane the 
 }
 #endif
 
-template <typename K>
+template <typename K, typename T>
 __global__ __launch_bounds__(K::THREADS, K::NW >= 8 ? 5 : 3) void corr_fwd_d4_coarse_kernel(
-    const float *__restrict__ x1, const float *__restrict__ x2, float *__restrict__ out, int C, int H,
+    const T *__restrict__ x1, const T *__restrict__ x2, T *__restrict__ out, int C, int H,
     int cpl, float slope, int64_t out_bstride, unsigned per_xcd, unsigned nitems, FastDiv by_h) {
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) f4 part[];
@@ -144,30 +191,31 @@ __global__ __launch_bounds__(K::THREADS, K::NW >= 8 ? 5 : 3) void corr_fwd_d4_co
     const int y2 = y + dy - kD;
     const int plane = H * W;
     const int64_t obs = out_bstride ? out_bstride : static_cast<int64_t>(kND * kND) * plane;
-    float *orow = out + b * obs + static_cast<int64_t>(dy * kND) * plane + y * W;
+    T *orow = out + b * obs + static_cast<int64_t>(dy * kND) * plane + y * W;
+    constexpr int E = sizeof(T);   // bytes per stored element
 
     const bool inside = y2 >= 0 && y2 < H;   // else the whole displacement row reads padding
 
-    const int item_bytes = C * plane * 4;
+    const int item_bytes = C * plane * E;
     const __amdgpu_buffer_rsrc_t r1 = uniform_rsrc(x1 + static_cast<int64_t>(b) * C * plane, item_bytes);
     const __amdgpu_buffer_rsrc_t r2 = uniform_rsrc(x2 + static_cast<int64_t>(b) * C * plane, item_bytes);
     const int c0 = (wave * K::G + g) * cpl;
-    const int v1 = ((c0 * H + y) * W + 4 * sx) * 4;
-    const int v2 = ((c0 * H + y2) * W + 4 * sx) * 4;
+    const int v1 = ((c0 * H + y) * W + 4 * sx) * E;
+    const int v2 = ((c0 * H + y2) * W + 4 * sx) * E;
     const int nb = cpl / CB;
 
     float acc[kND][4];
-    f4 xa[2][CB], xw[2][CB];
+    typename Px4<T>::raw xa[2][CB], xw[2][CB];
     // every batch is requested unconditionally (past the last one: out of range, zeros, no traffic) so
     // that the compiler's count of requests in flight is exact and a wait never covers the batch
     // requested just before it
     auto load = [&](int set, int k) {
-        const int soff = __builtin_amdgcn_readfirstlane(k * CB * plane * 4);
+        const int soff = __builtin_amdgcn_readfirstlane(k * CB * plane * E);
         const bool live = k < nb;
 #pragma unroll
         for (int i = 0; i < CB; ++i) {
-            xa[set][i] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(r1, live ? v1 + i * plane * 4 : kDead, soff, 0));
-            xw[set][i] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(r2, (live && inside) ? v2 + i * plane * 4 : kDead, soff, 0));
+            xa[set][i] = load_px4<T>(r1, live ? v1 + i * plane * E : kDead, soff);
+            xw[set][i] = load_px4<T>(r2, (live && inside) ? v2 + i * plane * E : kDead, soff);
         }
     };
     float zacc[4] = {0.f, 0.f, 0.f, 0.f};
@@ -176,14 +224,16 @@ __global__ __launch_bounds__(K::THREADS, K::NW >= 8 ? 5 : 3) void corr_fwd_d4_co
         if (!inside) {
             // x1 * 0 summed over the channels, as the reference's zero-padded x2 gives it: 0, or NaN where x1 is not finite
 #pragma unroll
-            for (int i = 0; i < CB; ++i)
+            for (int i = 0; i < CB; ++i) {
+                const f4 a = widen_px4<T>(xa[set][i]);
 #pragma unroll
-                for (int p = 0; p < 4; ++p) zacc[p] = __builtin_fmaf(xa[set][i][p], 0.f, zacc[p]);
+                for (int p = 0; p < 4; ++p) zacc[p] = __builtin_fmaf(a[p], 0.f, zacc[p]);
+            }
             return;
         }
 #pragma unroll
         for (int i = 0; i < CB; ++i) {
-            const f4 a = xa[set][i], w = xw[set][i];
+            const f4 a = widen_px4<T>(xa[set][i]), w = widen_px4<T>(xw[set][i]);
             float win[12];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -266,7 +316,7 @@ __global__ __launch_bounds__(K::THREADS, K::NW >= 8 ? 5 : 3) void corr_fwd_d4_co
         f4 q = s0 * inv;
 #pragma unroll
         for (int p = 0; p < 4; ++p) q[p] = q[p] > 0.f ? q[p] : q[p] * slope;
-        __builtin_nontemporal_store(q, reinterpret_cast<f4 *>(orow + (t / SPR) * plane + (t % SPR) * 4));
+        store_px4<T>(orow + (t / SPR) * plane + (t % SPR) * 4, q);
     }
     COARSE_STAMP(6);
 #ifdef CERB_STAMP
@@ -276,20 +326,19 @@ __global__ __launch_bounds__(K::THREADS, K::NW >= 8 ? 5 : 3) void corr_fwd_d4_co
 #endif
 }
 
-template <typename K>
+template <typename K, typename T>
 int launch_coarse_fwd(const char *name, const void *in1, const void *in2, void *outp, const CorrGeom &g,
                       float slope, int64_t obs, hipStream_t s) {
     const int64_t nitems = static_cast<int64_t>(g.B) * g.H * kND;
     if (nitems * g.H >= (1ll << 32) || nitems + 8 > 0x7fffffff) return CERB_EUNSUPPORTED;   // FastDiv range, grid size
     const unsigned per_xcd = static_cast<unsigned>((nitems + 7) / 8);
     note_kernel(0, name);
-    hipLaunchKernelGGL((corr_fwd_d4_coarse_kernel<K>), dim3(8 * per_xcd), dim3(K::THREADS),
-                       K::LDS_BYTES, s, static_cast<const float *>(in1), static_cast<const float *>(in2),
-                       static_cast<float *>(outp), g.C, g.H, g.C / (K::NW * K::G), slope, obs, per_xcd,
+    hipLaunchKernelGGL((corr_fwd_d4_coarse_kernel<K, T>), dim3(8 * per_xcd), dim3(K::THREADS),
+                       K::LDS_BYTES, s, static_cast<const T *>(in1), static_cast<const T *>(in2),
+                       static_cast<T *>(outp), g.C, g.H, g.C / (K::NW * K::G), slope, obs, per_xcd,
                        static_cast<unsigned>(nitems), FastDiv(static_cast<uint32_t>(g.H)));
     return launch_status();
 }
-
 
 // ============================================================================
 // backward
@@ -517,18 +566,31 @@ extern "C" int cerberus_debug_coarse_stamps(void *dst, int bytes) {
 
 // fp32, vector-aligned tensors, an item below 2 GiB (the caller has checked): W = 16 / 32 / 64 and
 // C a multiple of the lane layout's channel count; CERB_EUNSUPPORTED otherwise
-int corr_coarse_forward(const void *in1, const void *in2, void *out, const CorrGeom &g, float slope,
-                        int64_t obs, hipStream_t s) {
+template <typename T>
+static int coarse_forward_t(const void *in1, const void *in2, void *out, const CorrGeom &g, float slope, int64_t obs,
+                            hipStream_t s) {
     // eight waves x two-channel batches: 7.6 / 9.0 us alone at the two coarse levels of the 1024 x 512 pyramid, 4 pairs
     // (four waves x four-channel batches: 7.2 / 8.3), but 2 % more pairs/s in the two-stream step: 86 instead of 121
     // VGPRs leave the other direction's kernel its wave slots
     using K16 = CoarseFwdCfg<4, 4, 2>;
     using K32 = CoarseFwdCfg<8, 8, 2>;
     using K64 = CoarseFwdCfg<16, 8, 2>;
-    if (g.W == 64 && g.C % K64::CMULT == 0) return launch_coarse_fwd<K64>("corr_fwd_d4_coarse_64", in1, in2, out, g, slope, obs, s);
-    if (g.W == 32 && g.C % K32::CMULT == 0) return launch_coarse_fwd<K32>("corr_fwd_d4_coarse_32", in1, in2, out, g, slope, obs, s);
-    if (g.W == 16 && g.C % K16::CMULT == 0) return launch_coarse_fwd<K16>("corr_fwd_d4_coarse_16", in1, in2, out, g, slope, obs, s);
+    if (g.W == 64 && g.C % K64::CMULT == 0) return launch_coarse_fwd<K64, T>("corr_fwd_d4_coarse_64", in1, in2, out, g, slope, obs, s);
+    if (g.W == 32 && g.C % K32::CMULT == 0) return launch_coarse_fwd<K32, T>("corr_fwd_d4_coarse_32", in1, in2, out, g, slope, obs, s);
+    if (g.W == 16 && g.C % K16::CMULT == 0) return launch_coarse_fwd<K16, T>("corr_fwd_d4_coarse_16", in1, in2, out, g, slope, obs, s);
     return CERB_EUNSUPPORTED;
+}
+
+// vector-aligned tensors (16 bytes fp32, 8 bytes 16-bit storage), an item below 2 GiB (the caller has checked):
+// W = 16 / 32 / 64 and C a multiple of the lane layout's channel count; CERB_EUNSUPPORTED otherwise
+int corr_coarse_forward(const void *in1, const void *in2, void *out, const CorrGeom &g, float slope,
+                        int64_t obs, int dtype, hipStream_t s) {
+    switch (dtype) {
+        case CERB_F32: return coarse_forward_t<float>(in1, in2, out, g, slope, obs, s);
+        case CERB_F16: return coarse_forward_t<__half>(in1, in2, out, g, slope, obs, s);
+        case CERB_BF16: return coarse_forward_t<hip_bfloat16>(in1, in2, out, g, slope, obs, s);
+        default: return CERB_EUNSUPPORTED;
+    }
 }
 
 // fp32 backward for the coarse levels, same preconditions as the forward

@@ -2085,14 +2085,16 @@ int fwd_dispatch(const void *x1, const void *x2, void *o, const CorrGeom &g, flo
             return corr_mfma_forward(x1, x2, o, g, slope, obs,
                                      std::is_same<T, __half>::value ? CERB_F16 : CERB_BF16, s);
     }
-    if constexpr (sizeof(T) == 4) {
-        // coarse levels (W <= 64): independent waves, no loader, one barrier (corr_coarse.hip); 15 forces it
-        // (4 pairs: 7.2 vs 11.6 us at 256 x 16 x 32, 8.3 vs 10.8 us at 128 x 32 x 64; the tile kernels catch up
-        // once a launch has more than ~2000 (row, displacement row) workgroups)
+    {
+        // coarse levels (W <= 64): independent waves, no loader, one barrier (corr_coarse.hip); 15 forces it, 16 keeps it off
+        // (4 pairs: 7.5 vs 11.6 us at 256 x 16 x 32, 8.9 vs 10.8 us at 128 x 32 x 64; the tile kernels catch up
+        // once a launch has more than ~2000 (row, displacement row) workgroups).  16-bit storage: the same kernel
+        // with the loads widened (the matrix-core kernel above keeps 16 < C <= 64)
         const int v = option(OPT_CORR_FWD_VARIANT);
         const bool coarse_auto = g.W <= 64 && static_cast<int64_t>(g.B) * g.H * kND <= 2048;
         if (vec && dma_ok(g) && (v == 15 || (v == 0 && coarse_auto))) {
-            const int rc = corr_coarse_forward(x1, x2, o, g, slope, obs, s);
+            const int dt = sizeof(T) == 4 ? CERB_F32 : std::is_same<T, __half>::value ? CERB_F16 : CERB_BF16;
+            const int rc = corr_coarse_forward(x1, x2, o, g, slope, obs, dt, s);
             if (rc != CERB_EUNSUPPORTED) return rc;
         }
     }

@@ -905,6 +905,41 @@ def test_coarse_level_kernels_against_the_oracle(shape):
     assert np.array_equal(g1, g1b) and np.array_equal(g2, g2b) and np.array_equal(out, outb)
 
 
+@pytest.mark.parametrize("dtype,tol", [(torch.float16, 2e-3), (torch.bfloat16, 1.6e-2)])
+@pytest.mark.parametrize("shape", [(2, 128, 7, 32), (1, 128, 12, 64), (2, 128, 8, 16), (4, 256, 32, 64)])
+def test_coarse_level_forward_with_16bit_storage_against_the_oracle(dtype, tol, shape):
+    """fp16 / bf16 storage through the coarse-level forward (loads widened on use, fp32 arithmetic, one rounding on
+    store), fused LeakyReLU into a wider 16-bit buffer: against the fp64 oracle on the rounded inputs, as the default
+    dispatch picks it (config 5's coarsest level is the last shape) and forced."""
+    B, C, H, W = shape
+    x1 = torch.from_numpy(hash_uniform(shape, 441)).to(dtype)
+    x2 = torch.from_numpy(hash_uniform(shape, 442)).to(dtype)
+    p = (4, 1, 4, 1, 1)
+    ref = oracle.corr_forward_ref(x1.double().numpy(), x2.double().numpy(), *p)
+    out = torch.ops.cerberus.correlation(x1.to(DEV), x2.to(DEV), *p, 1)
+    assert _lib.last_kernel(0) == "corr_fwd_d4_coarse_%d" % W, _lib.last_kernel(0)
+    assert out.dtype == dtype
+    assert rel_err(out.double().cpu().numpy(), ref) < tol
+    buf = torch.full((B, 90, H, W), 7.5, device=DEV, dtype=dtype)
+    _lib.set_option("corr_fwd_variant", 15)
+    try:
+        torch.ops.cerberus.correlation_leaky_into(buf, x1.to(DEV), x2.to(DEV), 5, *p, 1, 0.1)
+        assert _lib.last_kernel(0) == "corr_fwd_d4_coarse_%d" % W, _lib.last_kernel(0)
+    finally:
+        _lib.set_option("corr_fwd_variant", 0)
+    got = buf.double().cpu().numpy()
+    assert rel_err(got[:, 5:86], np.where(ref > 0, ref, ref * 0.1)) < tol
+    assert np.all(np.delete(got, np.s_[5:86], axis=1) == 7.5)
+    # the vector kernels it replaces agree to the output rounding
+    _lib.set_option("corr_fwd_variant", 16)
+    try:
+        old = torch.ops.cerberus.correlation(x1.to(DEV), x2.to(DEV), *p, 1)
+        assert "coarse" not in _lib.last_kernel(0)
+    finally:
+        _lib.set_option("corr_fwd_variant", 0)
+    assert rel_err(out.double().cpu().numpy(), old.double().cpu().numpy()) < tol
+
+
 def test_coarse_level_kernels_are_the_default_on_the_coarse_levels_of_the_benched_pyramid():
     for (B, C, H, W), fw, bw in (((4, 256, 16, 32), "corr_fwd_d4_coarse_32", "corr_bwd_d4_coarse_32"),
                                  ((4, 128, 32, 64), "corr_fwd_d4_coarse_64", "corr_bwd_d4_coarse_64"),
