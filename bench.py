@@ -657,6 +657,8 @@ def main():
     ap.add_argument("--bwd-variant", type=int, default=0, help="experiments: option corr_bwd_variant")
     ap.add_argument("--fwd-variant", type=int, default=0, help="experiments: option corr_fwd_variant")
     ap.add_argument("--bwd-cslice", type=int, default=0, help="experiments: option corr_bwd_cslice")
+    ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
+                    help="experiments: set a library tuning option (include/cerberus_hip.h), repeatable")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -676,6 +678,10 @@ def main():
         _cerb_lib.set_option("corr_bwd_variant", args.bwd_variant)
         _cerb_lib.set_option("corr_fwd_variant", args.fwd_variant)
         _cerb_lib.set_option("corr_bwd_cslice", args.bwd_cslice)
+    for kv in args.option:
+        from cerberusnet_amd import _lib as _cerb_lib
+        name, _, val = kv.partition("=")
+        _cerb_lib.set_option(name, int(val))
     dist = None
     if world > 1 or os.environ.get("CERB_FORCE_DIST") == "1":  # the latter: 1-rank RCCL self-test
         import torch.distributed as dist
