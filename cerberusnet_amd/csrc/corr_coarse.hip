@@ -11,7 +11,7 @@
 // close the channel groups, and only 128 workgroups exist.  A kernel of independent waves that
 // each issue 16 or 32 loads and store once runs in 2.4-3.2 us here, launch included
 // (tools/ubench/launch_floor.hip).  So this kernel has no loader, no ring and ONE barrier:
-//   * a workgroup = one output row (b, y) x one displacement row dy; its NW waves split the
+//   * a workgroup = one output row (b, y) x one displacement row dy; its NW = 4 waves split the
 //     channels, and the 64 lanes of a wave are G = 64 / SPR channel groups x SPR four-pixel
 //     strips (SPR = W / 4), so a lane owns C / (NW * G) channels of one strip;
 //   * x1[c][y] and x2[c][y+dy-4] go global -> registers, one 16-byte load each per lane and
@@ -569,12 +569,14 @@ extern "C" int cerberus_debug_coarse_stamps(void *dst, int bytes) {
 template <typename T>
 static int coarse_forward_t(const void *in1, const void *in2, void *out, const CorrGeom &g, float slope, int64_t obs,
                             hipStream_t s) {
-    // eight waves x two-channel batches: 7.6 / 9.0 us alone at the two coarse levels of the 1024 x 512 pyramid, 4 pairs
-    // (four waves x four-channel batches: 7.2 / 8.3), but 2 % more pairs/s in the two-stream step: 86 instead of 121
-    // VGPRs leave the other direction's kernel its wave slots
+    // four waves x four-channel batches: 7.2 / 8.3 us alone at the two coarse levels of the 1024 x 512 pyramid, 4 pairs
+    // (eight waves x two-channel batches: 7.6 / 9.0 -- the fixed work per wave is then as large as its FMAs).  With the
+    // two directions' streams started together the 8-wave layout was 2 % better in the step (86 vs 121 VGPRs); since the
+    // second stream forks one launch late (bench.py) the two are level there (6 alternating runs) and the 4-wave one is
+    // 0.8 % ahead on one stream
     using K16 = CoarseFwdCfg<4, 4, 2>;
-    using K32 = CoarseFwdCfg<8, 8, 2>;
-    using K64 = CoarseFwdCfg<16, 8, 2>;
+    using K32 = CoarseFwdCfg<8, 4, 4>;
+    using K64 = CoarseFwdCfg<16, 4, 4>;
     if (g.W == 64 && g.C % K64::CMULT == 0) return launch_coarse_fwd<K64, T>("corr_fwd_d4_coarse_64", in1, in2, out, g, slope, obs, s);
     if (g.W == 32 && g.C % K32::CMULT == 0) return launch_coarse_fwd<K32, T>("corr_fwd_d4_coarse_32", in1, in2, out, g, slope, obs, s);
     if (g.W == 16 && g.C % K16::CMULT == 0) return launch_coarse_fwd<K16, T>("corr_fwd_d4_coarse_16", in1, in2, out, g, slope, obs, s);
