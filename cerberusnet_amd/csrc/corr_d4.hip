@@ -2088,10 +2088,10 @@ int fwd_dispatch(const void *x1, const void *x2, void *o, const CorrGeom &g, flo
     {
         // coarse levels (W <= 64): independent waves, no loader, one barrier (corr_coarse.hip); 15 forces it, 16 keeps it off
         // (4 pairs: 7.5 vs 11.6 us at 256 x 16 x 32, 8.9 vs 10.8 us at 128 x 32 x 64; the tile kernels catch up
-        // once a launch has more than ~2000 (row, displacement row) workgroups).  16-bit storage: the same kernel
+        // once a launch has more than ~2500 (row, displacement row) workgroups).  16-bit storage: the same kernel
         // with the loads widened (the matrix-core kernel above keeps 16 < C <= 64)
         const int v = option(OPT_CORR_FWD_VARIANT);
-        const bool coarse_auto = g.W <= 64 && static_cast<int64_t>(g.B) * g.H * kND <= 2048;
+        const bool coarse_auto = g.W <= 64 && static_cast<int64_t>(g.B) * g.H * kND <= 2560;   // 8 pairs of 128 x 32 x 64: 12.5 vs 13.0 us
         if (vec && dma_ok(g) && (v == 15 || (v == 0 && coarse_auto))) {
             const int dt = sizeof(T) == 4 ? CERB_F32 : std::is_same<T, __half>::value ? CERB_F16 : CERB_BF16;
             const int rc = corr_coarse_forward(x1, x2, o, g, slope, obs, dt, s);
@@ -2184,10 +2184,11 @@ int bwd_dispatch(const void *x1, const void *x2, const void *go, void *g1, void 
     if constexpr (sizeof(T) == 4) {
         // coarse levels (W <= 64): three waves per (output row, gradient, channel set), no loader, one barrier
         // (corr_coarse.hip).  4 pairs: 6.9 vs 11.9 us at 256 x 16 x 32, 11.4 vs 16.4-18.7 us at 128 x 32 x 64; 8 pairs of
-        // the latter (4096 workgroups): 22.4 vs 20.0 us.  14 forces it, 15 is the dispatch without it.
+        // the latter (4096 workgroups, since the items are chunked over the XCDs by image): 18.9 vs 20.0 us.  14 forces it, 15 is the
+        // dispatch without it.
         const int v = option(OPT_CORR_BWD_VARIANT);
         const int64_t coarse_wgs = static_cast<int64_t>(g.B) * 2 * g.H * (g.C / (g.W == 64 ? 16 : 32));
-        if (vec && dma_ok(g) && (v == 14 || (v == 0 && g.W <= 64 && coarse_wgs <= 3072))) {
+        if (vec && dma_ok(g) && (v == 14 || (v == 0 && g.W <= 64 && coarse_wgs <= 4096))) {
             const int rc = corr_coarse_backward(x1, x2, go, g1, g2, g, s);
             if (rc != CERB_EUNSUPPORTED) return rc;
         }

@@ -188,7 +188,7 @@ int cerberus_area_resize(const void *src, void *dst, int64_t planes, int H, int 
  *                          16 channel groups, 14 = the matrix-core kernel (fp16 / bf16 storage,
  *                          C <= 64; auto uses it for 16 < C <= 64), 15 = the coarse-level kernel (fp32,
  *                          W = 16 / 32 / 64 and a channel count its lane layout divides: corr_coarse.hip;
- *                          auto uses it there up to ~2000 (row, displacement row) workgroups), 16 = auto
+ *                          auto uses it there up to 2560 (row, displacement row) workgroups), 16 = auto
  *                          without it
  *   "corr_bwd_variant"   : 0 = auto, 1 = all 81 displacements per lane (register-staged),
  *                          3 = three displacement groups, 4 / 5 = LDS-DMA with the 8x64 /
@@ -197,7 +197,7 @@ int cerberus_area_resize(const void *src, void *dst, int64_t planes, int H, int 
  *                          12 = whole image rows per wavefront (fp32, W in {256, 128, 64}; auto uses
  *                          it where such a map has enough workgroups for the chip; 13 = auto, but not
  *                          on 64-wide maps), 14 = the coarse-level kernel (fp32, W = 16 / 32 / 64,
- *                          corr_coarse.hip; auto uses it there up to 3072 workgroups), 15 = auto without
+ *                          corr_coarse.hip; auto uses it there up to 4096 workgroups), 15 = auto without
  *                          it; 2, 6, 7, 9, 10 (and forward
  *                          1, 2, 8) are measured-and-rejected variants that exist only in
  *                          -DCERB_EXPERIMENTS test builds (otherwise: auto)

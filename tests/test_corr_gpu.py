@@ -822,8 +822,8 @@ def test_strip_backward_is_the_default_where_the_wide_level_fills_the_chip():
     torch.ops.cerberus.correlation_backward(x1[:1], x2[:1], go[:1], 4, 1, 4, 1, 1, 1)
     assert not _lib.last_kernel(1).startswith("corr_bwd_d4_strip"), _lib.last_kernel(1)
     # the 128-wide level of the benched pyramid at 4 pairs (2 image rows per wavefront); the 64-wide one (4 rows)
-    # once it has more workgroups than the coarse-level kernel likes (8 pairs)
-    for (B, C, H, W), want in (((4, 64, 64, 128), "corr_bwd_d4_strip_w128"), ((8, 128, 32, 64), "corr_bwd_d4_strip_w64")):
+    # once it has more workgroups than the coarse-level kernel likes (16 pairs)
+    for (B, C, H, W), want in (((4, 64, 64, 128), "corr_bwd_d4_strip_w128"), ((16, 128, 32, 64), "corr_bwd_d4_strip_w64")):
         a, b = dev(hash_uniform((B, C, H, W), 1)), dev(hash_uniform((B, C, H, W), 2))
         g = dev(hash_uniform((B, 81, H, W), 3))
         torch.ops.cerberus.correlation_backward(a, b, g, 4, 1, 4, 1, 1, 1)
@@ -950,7 +950,7 @@ def test_coarse_level_kernels_are_the_default_on_the_coarse_levels_of_the_benche
         torch.ops.cerberus.correlation_backward(a, b, g, 4, 1, 4, 1, 1, 1)
         assert (_lib.last_kernel(0), _lib.last_kernel(1)) == (fw, bw), (_lib.last_kernel(0), _lib.last_kernel(1))
     # many pairs per call: the tile / strip kernels again
-    a, b = dev(hash_uniform((8, 128, 32, 64), 1)), dev(hash_uniform((8, 128, 32, 64), 2))
+    a, b = dev(hash_uniform((16, 128, 32, 64), 1)), dev(hash_uniform((16, 128, 32, 64), 2))
     torch.ops.cerberus.correlation(a, b, 4, 1, 4, 1, 1, 1)
     assert "coarse" not in _lib.last_kernel(0), _lib.last_kernel(0)
     # channel counts the lane layout does not divide: the tile kernels, silently
