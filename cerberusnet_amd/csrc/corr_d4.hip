@@ -2087,7 +2087,7 @@ int fwd_dispatch(const void *x1, const void *x2, void *o, const CorrGeom &g, flo
     }
     {
         // coarse levels (W <= 64): independent waves, no loader, one barrier (corr_coarse.hip); 15 forces it, 16 keeps it off
-        // (4 pairs: 7.5 vs 11.6 us at 256 x 16 x 32, 8.9 vs 10.8 us at 128 x 32 x 64; the tile kernels catch up
+        // (4 pairs: 7.0 vs 11.6 us at 256 x 16 x 32, 8.1 vs 10.8 us at 128 x 32 x 64; the tile kernels catch up
         // once a launch has more than ~2500 (row, displacement row) workgroups).  16-bit storage: the same kernel
         // with the loads widened (the matrix-core kernel above keeps 16 < C <= 64)
         const int v = option(OPT_CORR_FWD_VARIANT);
