@@ -314,6 +314,25 @@ def trace_child(args, device):
     torch.cuda.synchronize()
 
 
+_PROFILER_PREFIXES = ("ROCP_", "ROCPROF", "ROCPROFILER_", "ROCTRACER_", "ROCTX_", "HSA_TOOLS_", "ROCPROFV3_",
+                      "OMNIPERF_", "ROCPROFSYS_")
+
+
+def _is_profiler_variable(name):
+    return name.startswith(_PROFILER_PREFIXES) or name in ("LD_PRELOAD", "HSA_TOOLS_LIB")
+
+
+def profiler_in_environment(environ=None):
+    """True when this process was started by rocprofv3 / rocprof (tool library preloaded or registered)."""
+    env = os.environ if environ is None else environ
+    if any(env.get(k) for k in ("ROCP_TOOL_LIBRARIES", "ROCP_TOOL_LIB", "HSA_TOOLS_LIB", "ROCPROFILER_REGISTER_FORCE_LOAD")):
+        return True
+    if any(k.startswith(("ROCPROF_", "ROCPROFILER_", "ROCPROFV3_")) and env.get(k) for k in env):
+        return True
+    pre = env.get("LD_PRELOAD", "")
+    return any(t in pre for t in ("rocprof", "roctracer", "rocprofiler", "roctx"))
+
+
 def in_step_times(args, nlevels, replays=60):
     """Seconds per launch INSIDE the step, from the profiler: a child process replays the whole step on
     one stream (every kernel alone on the chip, caches in the state the step leaves them in) under
@@ -327,6 +346,12 @@ def in_step_times(args, nlevels, replays=60):
     prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(prof):
         return None, "rocprofv3 not found"
+    # never start a profiler from inside a profiled process.  An outer rocprofv3 (or any
+    # preloaded tool) has already initialised the GPU in THIS process, and its environment would make
+    # the inner launcher initialise it before exec'ing the child -- the exec-after-GPU-init hop that
+    # takes a box of this pool down.
+    if profiler_in_environment():
+        return None, "already under a profiler (preload / rocprofiler variables present): in-step pass skipped"
     order = step_order(nlevels)
     out = tempfile.mkdtemp(prefix="cerb_trace_", dir="/tmp")
     cmd = [prof, "--kernel-trace", "--output-format", "csv", "-d", out, "--", sys.executable,
@@ -337,7 +362,8 @@ def in_step_times(args, nlevels, replays=60):
     try:
         env = {k: v for k, v in os.environ.items()
                if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK",
-                            "LOCAL_WORLD_SIZE", "ROLE_RANK", "ROLE_WORLD_SIZE", "TORCHELASTIC_RUN_ID")}
+                            "LOCAL_WORLD_SIZE", "ROLE_RANK", "ROLE_WORLD_SIZE", "TORCHELASTIC_RUN_ID")
+               and not _is_profiler_variable(k)}
         env["TMPDIR"] = "/tmp"
         subprocess.run(cmd, cwd="/tmp", env=env, timeout=300, check=True, stdout=subprocess.DEVNULL,
                        stderr=subprocess.DEVNULL)

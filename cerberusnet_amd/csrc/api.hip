@@ -25,7 +25,9 @@ const char *const g_option_names[OPT_COUNT] = {
 #endif
 };
 std::atomic<int> g_option_values[OPT_COUNT];
-thread_local const char *t_last_kernel[2] = {"none", "none"};
+// process-wide (diagnostics): autograd runs the backward on its own thread, and the caller that asks
+// "which kernel ran" sits on another one; names are string literals, so a relaxed pointer store is enough
+std::atomic<const char *> g_last_kernel[2] = {{"none"}, {"none"}};
 
 int find_option(const char *key) {
     for (int i = 0; i < OPT_COUNT; ++i)
@@ -37,7 +39,7 @@ bool dtype_ok(int dtype) { return dtype >= CERB_F32 && dtype <= CERB_F64; }
 }  // namespace
 
 int option(OptId id) { return g_option_values[id].load(std::memory_order_relaxed); }
-void note_kernel(int which, const char *name) { t_last_kernel[which & 1] = name; }
+void note_kernel(int which, const char *name) { g_last_kernel[which & 1].store(name, std::memory_order_relaxed); }
 }  // namespace cerb
 
 using namespace cerb;
@@ -241,6 +243,6 @@ int cerberus_get_option(const char *key, int *value) {
     return CERB_OK;
 }
 
-const char *cerberus_last_kernel(int which) { return t_last_kernel[which & 1]; }
+const char *cerberus_last_kernel(int which) { return g_last_kernel[which & 1].load(std::memory_order_relaxed); }
 
 }  // extern "C"

@@ -218,8 +218,9 @@ int cerberus_area_resize(const void *src, void *dst, int64_t planes, int H, int 
 int cerberus_set_option(const char *key, int value);
 int cerberus_get_option(const char *key, int *value);
 
-/* Name of the kernel variant the most recent correlation forward / backward on
- * this thread dispatched to (for tests and the bench's roofline report). */
+/* Name of the kernel variant the most recent correlation forward / backward of this PROCESS
+ * dispatched to, whichever thread issued it (autograd runs backward on its own thread); for
+ * tests and the bench's roofline report. */
 const char *cerberus_last_kernel(int which /*0 = forward, 1 = backward*/);
 
 #ifdef __cplusplus

@@ -38,3 +38,23 @@ def test_cpu_baseline_reports_min_and_median_per_shape():
             assert row[what + "_iters"] >= 3
     pair_s = 2e-3 * sum(r["per_shape_ms"]["L%d" % l]["fwd_bwd_ms_median"] for l in range(2))
     assert np.isclose(r["value"], 1.0 / pair_s, rtol=1e-3)
+
+
+def test_in_step_pass_refuses_to_nest_profilers():
+    """under an outer rocprofv3 the bench must not start its own profiler child, and the
+    child's environment never inherits tool / preload variables."""
+    assert not bench.profiler_in_environment({"PATH": "/usr/bin", "LD_PRELOAD": ""})
+    assert bench.profiler_in_environment({"ROCP_TOOL_LIBRARIES": "/opt/rocm/lib/librocprofiler-sdk-tool.so"})
+    assert bench.profiler_in_environment({"LD_PRELOAD": "/opt/rocm/lib/librocprofiler-sdk-tool.so.0"})
+    assert bench.profiler_in_environment({"ROCPROF_OUTPUT_PATH": "/tmp/x"})
+    for name in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "ROCPROF_OUTPUT_PATH", "HSA_TOOLS_LIB", "ROCPROFILER_LOG_LEVEL"):
+        assert bench._is_profiler_variable(name), name
+    assert not bench._is_profiler_variable("HSA_ENABLE_IPC_MODE_LEGACY")
+    os.environ["ROCP_TOOL_LIBRARIES"] = "x.so"
+    try:
+        class A:
+            pairs, width, height, dtype, flow, no_mfma = 4, 1024, 512, "f32", "smooth", False
+        times, why = bench.in_step_times(A(), 4)
+        assert times is None and "profiler" in why
+    finally:
+        del os.environ["ROCP_TOOL_LIBRARIES"]

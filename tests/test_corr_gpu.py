@@ -1072,6 +1072,57 @@ def test_config5_16bit_levels_against_the_oracle_at_full_size(lvl, dtype, tol):
     assert rel_err(g2.double().cpu().numpy(), r2) < tol
 
 
+def _oracle_per_item(fn, *arrays):
+    """The single-threaded C oracle on every batch item in its own host thread (ctypes releases
+    the GIL; batch items never interact, correlation_cuda_kernel.cu:35,105,181)."""
+    from concurrent.futures import ThreadPoolExecutor
+    B = arrays[0].shape[0]
+    with ThreadPoolExecutor(max_workers=B) as ex:
+        parts = list(ex.map(lambda b: fn(*[a[b:b + 1] for a in arrays]), range(B)))
+    if isinstance(parts[0], tuple):
+        return tuple(np.concatenate([p[i] for p in parts], 0) for i in range(len(parts[0])))
+    return np.concatenate(parts, 0)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float16, 2e-3), (torch.bfloat16, 1.6e-2)])
+@pytest.mark.parametrize("lvl", [0, 1, 2, 3])
+def test_config5_16bit_levels_at_the_benched_batch_against_the_oracle(lvl, dtype, tol):
+    """the dispatcher switches kernels on the batch (coarse / strip workgroup-count
+    thresholds), so the kernels `bench.py --dtype f16 --width 2048 --height 1024` times at 4 pairs are
+    not all the ones the B = 1 test above runs.  Here: the benched call itself -- 4 pairs, default
+    dispatch, full tensors -- against the fp64 oracle on the rounded inputs, every item; and the kernel
+    the dispatcher took must be the one bench.py's Workload dispatches for the same level (same shapes,
+    same dtype, same options: read back through cerberus_last_kernel from both)."""
+    C, H, W = CONFIG5_PYRAMID_2048x1024[lvl]
+    shp = (4, C, H, W)
+    x1 = torch.from_numpy(hash_uniform(shp, 71)).to(dtype)
+    x2 = torch.from_numpy(hash_uniform(shp, 72)).to(dtype)
+    go = torch.from_numpy(hash_uniform((4, 81, H, W), 73)).to(dtype)
+    p = (4, 1, 4, 1, 1)
+    out = torch.ops.cerberus.correlation(x1.to(DEV), x2.to(DEV), *p, 1)
+    fwd_name = _lib.last_kernel(0)
+    g1, g2 = torch.ops.cerberus.correlation_backward(x1.to(DEV), x2.to(DEV), go.to(DEV), *p, 1)
+    bwd_name = _lib.last_kernel(1)
+    # what the benchmark's own workload object dispatches at this level (pairs = 4)
+    import bench
+    wl = bench.Workload(4, 2048, 1024, torch.device(DEV), "smooth", False, 1, dtype)
+    assert tuple(wl.levels[lvl]) == (C, H, W)
+    t = wl.dirs[0][lvl]
+    torch.ops.cerberus.correlation(t["f1"], t["f2"], *bench.CORR_P)
+    assert _lib.last_kernel(0) == fwd_name, (_lib.last_kernel(0), fwd_name)
+    torch.ops.cerberus.correlation_backward(t["f1"], t["f2"], t["gout"], *bench.CORR_P)
+    assert _lib.last_kernel(1) == bwd_name, (_lib.last_kernel(1), bwd_name)
+    del wl, t
+    a1, a2, ag = x1.double().numpy(), x2.double().numpy(), go.double().numpy()
+    ref = _oracle_per_item(lambda a, b: oracle.corr_forward_ref(a, b, *p), a1, a2)
+    r1, r2 = _oracle_per_item(lambda a, b, g: oracle.corr_backward_ref(a, b, g, *p), a1, a2, ag)
+    o, h1, h2 = (v.double().cpu().numpy() for v in (out, g1, g2))
+    for b in range(4):
+        assert rel_err(o[b], ref[b]) < tol, (b, fwd_name)
+        assert rel_err(h1[b], r1[b]) < tol, (b, bwd_name)
+        assert rel_err(h2[b], r2[b]) < tol, (b, bwd_name)
+
+
 def test_concat_buffer_written_in_place_before_backward_raises():
     """CostVolumeConcat saves the concatenation buffer for backward like any output; an
     in-place write to it (which would flip LeakyReLU derivative signs silently) trips autograd's

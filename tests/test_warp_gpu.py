@@ -65,21 +65,45 @@ def test_against_torch_cpu_oracle(shape, pad):
 
 @pytest.mark.parametrize("lvl", [1, 2, 3])
 def test_fullsize_feature_warps(lvl):
-    """Config-3 feature-warp shapes (levels 1-3), B=1 vs the torch-CPU oracle and
-    B=4 batch-independence; flows in [-6, 6) px so borders are hit."""
+    """Config-3 feature-warp shapes (levels 1-3) at the benched batch of 4: EVERY item's output,
+    grad_image (the fixed-point tile path) and grad_flow against the torch-CPU oracle
+    (UnFlowLoss.py:83-94 + autograd), plus batch-independence bit for bit; flows in [-6, 6) px so
+    borders are hit."""
     C, H, W = W32_PYRAMID_1024x512[lvl]
     img = hash_uniform((4, C, H, W), 4)
     flo = hash_uniform((4, 2, H, W), 5, -6.0, 6.0)
     go = hash_uniform((4, C, H, W), 6)
-    ref, rgi, rgf = oracle.flow_warp_grads_ref(torch.from_numpy(img[:1]),
-                                               torch.from_numpy(flo[:1]),
-                                               torch.from_numpy(go[:1]), "border")
+    ref, rgi, rgf = oracle.flow_warp_grads_ref(torch.from_numpy(img), torch.from_numpy(flo),
+                                               torch.from_numpy(go), "border")
     out, gi, gf = hip_warp_with_grads(img, flo, go, "border")
-    assert rel_err(out[:1], ref.numpy()) < TOL
-    assert rel_err(gi[:1], rgi.numpy()) < TOL
-    assert rel_err(gf[:1], rgf.numpy()) < TOL
-    o1, _, f1 = hip_warp_with_grads(img[3:], flo[3:], go[3:], "border")
+    for b in range(4):
+        assert rel_err(out[b], ref[b].numpy()) < TOL, b
+        assert rel_err(gi[b], rgi[b].numpy()) < TOL, b
+        assert rel_err(gf[b], rgf[b].numpy()) < TOL, b
+    o1, i1, f1 = hip_warp_with_grads(img[3:], flo[3:], go[3:], "border")
     assert np.array_equal(o1[0], out[3]) and np.array_equal(f1[0], gf[3])
+    assert np.array_equal(i1[0], gi[3])
+
+
+@pytest.mark.parametrize("lvl", [1, 2, 3])
+def test_fullsize_feature_warps_smooth_flow_as_benched(lvl):
+    """The same shapes with the flow field bench.py feeds (a coarse field upsampled x8 + a
+    +-0.25 px residual: what PWCNetHead produces): the tile workgroups of the backward then see
+    shifted, not scattered, source regions -- the branch the benchmark times.  All 4 items."""
+    import torch.nn.functional as F
+    C, H, W = W32_PYRAMID_1024x512[lvl]
+    img = hash_uniform((4, C, H, W), 14)
+    coarse = torch.from_numpy(hash_uniform((4, 2, max(2, H // 8), max(2, W // 8)), 15, -6.0, 6.0))
+    flo = F.interpolate(coarse, size=(H, W), mode="bilinear", align_corners=True)
+    flo = (flo + torch.from_numpy(hash_uniform((4, 2, H, W), 115, -0.25, 0.25))).contiguous().numpy()
+    go = hash_uniform((4, C, H, W), 16)
+    ref, rgi, rgf = oracle.flow_warp_grads_ref(torch.from_numpy(img), torch.from_numpy(flo),
+                                               torch.from_numpy(go), "border")
+    out, gi, gf = hip_warp_with_grads(img, flo, go, "border")
+    for b in range(4):
+        assert rel_err(out[b], ref[b].numpy()) < TOL, b
+        assert rel_err(gi[b], rgi[b].numpy()) < TOL, b
+        assert rel_err(gf[b], rgf[b].numpy()) < TOL, b
 
 
 def test_rgb_loss_warps_and_reflection_nearest_modes():
@@ -364,9 +388,11 @@ def test_nonfinite_grad_out_reaches_the_same_elements_as_the_oracle():
 
 
 @pytest.mark.parametrize("dt,tol", [(torch.float16, 2e-3), (torch.bfloat16, 1.6e-2)])
-@pytest.mark.parametrize("shape", [(1, 8, 20, 30), (1, 32, 256, 512)])
+@pytest.mark.parametrize("shape", [(1, 8, 20, 30), (1, 32, 256, 512), (4, 32, 256, 512),
+                                   (4, 64, 128, 256), (4, 128, 64, 128)])
 def test_half_backward_is_tiled_deterministic_and_matches_the_oracle(dt, tol, shape):
-    """Config 5 (fp16 mixed precision, 2048x1024: the finest feature warp is 32x256x512): the
+    """Config 5 (fp16 mixed precision, 2048x1024: the feature warps are 128x64x128, 64x128x256 and
+    32x256x512, benched at 4 pairs): the
     16-bit backward takes the owner-computes tiles (fp32 fixed-point accumulation, 16-bit I/O),
     not a 16-bit CAS loop on global memory.  Against the torch-CPU oracle run in fp32 on the same
     16-bit inputs; bit-reproducible run to run; equal (to 16-bit rounding) to the scatter path."""
