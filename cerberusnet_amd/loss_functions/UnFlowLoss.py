@@ -14,7 +14,7 @@ import torch
 
 from .. import ops as _ops
 
-__all__ = ["flow_warp", "mesh_grid", "norm_grid", "area_resize"]
+__all__ = ["flow_warp", "mesh_grid", "norm_grid", "area_resize", "unFlowLoss"]
 
 
 def area_resize(image, size):
@@ -54,3 +54,109 @@ def flow_warp(image, flow12, pad='border', mode='bilinear'):
         # autograd's save_for_backward is to grid_sample in the reference)
         return torch.ops.cerberus.flow_warp_ctx(image, flow12, *modes)[0]
     return torch.ops.cerberus.flow_warp(image, flow12, *modes)
+
+
+# ---- the photometric flow loss: a CALLER of the warp (host model of the hot path) ---------------
+def _torch_flow_warp(image, flow12, pad="border", mode="bilinear"):
+    """The reference op sequence (:83-94) in stock torch ops -- CPU wiring tests only."""
+    import torch.nn.functional as F
+    b, _, h, w = image.size()
+    grid = norm_grid(mesh_grid(b, h, w).type_as(image) + flow12)
+    return F.grid_sample(image, grid, mode=mode, padding_mode=pad, align_corners=False)
+
+
+def _ssim_distance(x, y):
+    """(1 - SSIM) / 2 on 3x3 windows with reflection padding, clamped to [0, 1]
+    (``loss_functions.py:47-77``)."""
+    import torch.nn.functional as F
+    pool = lambda t: F.avg_pool2d(F.pad(t, (1, 1, 1, 1), mode="reflect"), 3, 1)
+    c1, c2 = 0.01 ** 2, 0.03 ** 2
+    mu_x, mu_y = pool(x), pool(y)
+    var_x = pool(x ** 2) - mu_x ** 2
+    var_y = pool(y ** 2) - mu_y ** 2
+    cov = pool(x * y) - mu_x * mu_y
+    num = (2 * mu_x * mu_y + c1) * (2 * cov + c2)
+    den = (mu_x ** 2 + mu_y ** 2 + c1) * (var_x + var_y + c2)
+    return torch.clamp((1 - num / den) / 2, 0, 1)
+
+
+def _edge_aware_smoothness(flow, image, alpha, degree):
+    """First / second order smoothness of the flow, damped across image edges (:162-187)."""
+    dx = lambda t: t[:, :, :, 1:] - t[:, :, :, :-1]
+    dy = lambda t: t[:, :, 1:] - t[:, :, :-1]
+    wx = torch.exp(-dx(image).abs().mean(1, keepdim=True) * alpha)
+    wy = torch.exp(-dy(image).abs().mean(1, keepdim=True) * alpha)
+    if degree == 1:
+        return ((wx * dx(flow).abs() / 2.).mean() + (wy * dy(flow).abs() / 2).mean()) / 2.
+    if degree == 2:
+        return ((wx[:, :, :, 1:] * dx(dx(flow)).abs()).mean() +
+                (wy[:, :, 1:, :] * dy(dy(flow)).abs()).mean()) / 2.
+    raise NotImplementedError(degree)
+
+
+class unFlowLoss(torch.nn.Module):
+    """Counterpart of ``unFlowLoss`` (:189-322) for the terms the Cerberus configs use: L1 and SSIM
+    photometric terms on the image pair warped by the predicted flow at every pyramid scale,
+    edge-aware smoothness, forward / backward consistency.  Same constructor keywords, same
+    ``forward(predictions, targets)`` with ``predictions['flow'|'flow_b']`` (lists, full resolution
+    first) and ``targets['l_img'|'l_seq']``.  The census ("ternary") term and the occlusion masks
+    (dead code in the reference, :285-297: the mask is all ones) are not built.
+
+    ``backend='hip'`` (default): the two warps per scale are ``cerberus::flow_warp`` and the area
+    resizes of the targets ``cerberus::area_resize``; ``'torch'``: stock ops, CPU tests only."""
+
+    def __init__(self, weight=1.0, weights=None, consistency=True, back_occ_only=False,
+                 backend="hip", **kwargs):
+        super().__init__()
+        weights = weights or {"l1": 0.15, "ssim": 0.85}
+        if "ternary" in weights:
+            raise NotImplementedError("the census (ternary) term is outside the hot-path scope")
+        self.weight = weight
+        self.l1_weight = weights.get("l1")
+        self.ssim_weight = weights.get("ssim")
+        self.smooth_args = kwargs.get("smooth", {"degree": 2, "alpha": 0.2, "weighting": 75.0})
+        self.w_sm_scales = kwargs.get("w_sm_scales", [1.0, 0.0, 0.0, 0.0, 0.0])
+        self.w_wrp_scales = kwargs.get("w_wrp_scales", [1.0, 1.0, 1.0, 1.0, 0.0])
+        self.consistency = consistency
+        self.back_occ_only = back_occ_only
+        if backend not in ("hip", "torch"):
+            raise ValueError("backend must be 'hip' or 'torch'")
+        self.backend = backend
+
+    def _resize(self, image, size):
+        if self.backend == "hip":
+            return area_resize(image, size)
+        return torch.nn.functional.interpolate(image, size, mode="area")
+
+    def _warp(self, image, flow):
+        return flow_warp(image, flow, pad="border") if self.backend == "hip" \
+            else _torch_flow_warp(image, flow, pad="border")
+
+    def loss_photometric(self, im_orig, im_recons):
+        terms = []
+        if self.l1_weight is not None:
+            terms.append(self.l1_weight * (im_orig - im_recons).abs())
+        if self.ssim_weight is not None:
+            terms.append(self.ssim_weight * _ssim_distance(im_recons, im_orig))
+        return sum(t.mean() for t in terms)          # (/ mean of the all-ones mask = 1)
+
+    def forward(self, predictions, targets):
+        total_warp, total_smooth, s = 0., 0., 1.
+        for i, (f12, f21) in enumerate(zip(predictions["flow"], predictions["flow_b"])):
+            if self.w_wrp_scales[i] == 0:
+                continue
+            size = tuple(f12.shape[2:])
+            im1 = self._resize(targets["l_img"], size)
+            im2 = self._resize(targets["l_seq"], size)
+            if i == 0:
+                s = min(size)
+            warp = self.loss_photometric(im1, self._warp(im2, f12))
+            smooth = _edge_aware_smoothness(f12 / s, im1, self.smooth_args["alpha"],
+                                            self.smooth_args["degree"])
+            if self.consistency:
+                warp = (warp + self.loss_photometric(im2, self._warp(im1, f21))) / 2.
+                smooth = (smooth + _edge_aware_smoothness(f21 / s, im2, self.smooth_args["alpha"],
+                                                          self.smooth_args["degree"])) / 2.
+            total_warp = total_warp + warp * self.w_wrp_scales[i]
+            total_smooth = total_smooth + smooth * self.w_sm_scales[i]
+        return self.weight * (total_warp + self.smooth_args["weighting"] * total_smooth)

@@ -1,3 +1,3 @@
-from .UnFlowLoss import flow_warp, mesh_grid, norm_grid
+from .UnFlowLoss import flow_warp, mesh_grid, norm_grid, unFlowLoss
 
-__all__ = ["flow_warp", "mesh_grid", "norm_grid"]
+__all__ = ["flow_warp", "mesh_grid", "norm_grid", "unFlowLoss"]

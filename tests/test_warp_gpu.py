@@ -82,7 +82,11 @@ def test_fullsize_feature_warps(lvl):
         assert rel_err(gf[b], rgf[b].numpy()) < TOL, b
     o1, i1, f1 = hip_warp_with_grads(img[3:], flo[3:], go[3:], "border")
     assert np.array_equal(o1[0], out[3]) and np.array_equal(f1[0], gf[3])
-    assert np.array_equal(i1[0], gi[3])
+    # grad_image: one image alone takes 8-row tiles at the finest level, four take 16-row tiles; the
+    # fixed-point scale is chosen per (tile, 8-channel group), so the two runs round the same integer
+    # sums at scales up to 2^-29 of the group maximum apart: equal to well below one fp32 ulp of the
+    # maximum, not bit for bit
+    assert rel_err(i1[0], gi[3]) < 1e-7
 
 
 @pytest.mark.parametrize("lvl", [1, 2, 3])
