@@ -11,7 +11,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # CERBERUS_HIP_LIB: another build of the same library (e.g. a -DCERB_EXPERIMENTS / -DCERB_STAMP test build)
 LIB_PATH = os.environ.get("CERBERUS_HIP_LIB") or os.path.join(_HERE, "lib", "libcerberus_hip.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _lock = threading.Lock()
 _lib = None

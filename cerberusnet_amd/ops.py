@@ -245,11 +245,6 @@ def _check_aligned16(t, what, name):
                            "pass the tensor the forward returned, not a slice of it" % (what, name, t.data_ptr() % 16))
 
 
-def _ctx_header_bytes(B, H, W):
-    """warp.hip ctx_header_bytes: one int4 tap range per 2 x 32 pixel strip."""
-    return B * ((H + 1) // 2) * ((W + 31) // 32) * 16
-
-
 def _flow_warp_run(image, flow, pad_mode, interp_mode, want_ctx, what):
     _warp_check(image, flow, what)
     code = _dtype_code(image, what)
@@ -286,7 +281,8 @@ def _flow_warp_ctx_cuda(image, flow, pad_mode, interp_mode):
 
 def _flow_warp_ctx_meta(image, flow, pad_mode, interp_mode):
     B, _, H, W = image.shape
-    n = (_ctx_header_bytes(B, H, W) + B * 2 * H * W * 4 + 7) // 8
+    # the size function is host arithmetic of the library itself (no device involved): one definition
+    n = (_lib.get().cerberus_flow_warp_context_bytes(B, H, W) + 7) // 8
     return torch.empty_like(image), image.new_empty((n,), dtype=torch.int64)
 
 
