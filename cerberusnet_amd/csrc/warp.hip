@@ -498,6 +498,18 @@ struct StageWindow {
     }
 };
 
+#ifdef CERB_STAMP
+// diagnostic build only (-DCERB_STAMP): s_memtime at the phase boundaries of the first 64 tile
+// workgroups, fetched with cerberus_debug_stamps(); never compiled into the product
+__device__ unsigned long long g_stamps[64][16];
+#define CERB_STAMP_AT(k)                                                         \
+    do {                                                                         \
+        if (threadIdx.x == 0 && blockIdx.x < 64) g_stamps[blockIdx.x][k] = __builtin_readcyclecounter(); \
+    } while (0)
+#else
+#define CERB_STAMP_AT(k) do {} while (0)
+#endif
+
 // ---- the lists role (see the context layout above) ----------------------------------------------------
 // Workgroup of NW wavefronts; wave w owns block rows w*R .. w*R+R-1 (R = ceil(TH / NW)), lane = column.
 template <typename F, int TH, int NW>
@@ -512,6 +524,7 @@ __device__ __forceinline__ void lists_role(const F *__restrict__ flow, void *__r
     const int b = role_id / nblk, blk = role_id % nblk;
     const int tx = blk % tiles_x, ty = blk / tiles_x;
     const int plane_px = H * W;
+    CERB_STAMP_AT(0);
     int u[R], v[R], pv[R];
     float fx[R], fy[R];
     bool valid[R];
@@ -543,7 +556,9 @@ __device__ __forceinline__ void lists_role(const F *__restrict__ flow, void *__r
         const int d = wave_minmax<false>(vmin), e = wave_minmax<true>(vmax);
         if (lane == 0) { box[wave * 4] = a; box[wave * 4 + 1] = c; box[wave * 4 + 2] = d; box[wave * 4 + 3] = e; }
     }
+    for (int i = tid; i < 9 * 16; i += NW * 64) tab[i] = 0;   // (target tiles the block does not reach stay empty)
     __syncthreads();
+    CERB_STAMP_AT(1);
     umin = kExtEmptyLo; umax = kExtEmptyHi; vmin = kExtEmptyLo; vmax = kExtEmptyHi;
 #pragma unroll
     for (int w = 0; w < NW; ++w) {
@@ -569,19 +584,29 @@ __device__ __forceinline__ void lists_role(const F *__restrict__ flow, void *__r
     for (int i = tid; i < pw * prow; i += NW * 64) plane[i] = 0;
     // ---- records per (target tile k, block row): ballots ----
     int cnt_mine = 0;
+    unsigned member[R];                              // bit k: the pixel is a source of target tile k
 #pragma unroll
-    for (int r = 0; r < R; ++r) cnt_mine += valid[r] ? 1 : 0;
-#pragma unroll
-    for (int k = 0; k < 9; ++k) {
-        const int kx = bx + k % 3, ky = by + k / 3;
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const int lx = u[r] - kx * TW, ly = v[r] - ky * TH;
-            const bool has = valid[r] && kx < tiles_x && ky < tiles_y && lx >= 0 && lx <= TW && ly >= 0 && ly <= TH;
-            const unsigned long long m = __ballot(has);
-            if (lane == 0 && wave * R + r < TH) tab[k * 16 + wave * R + r] = __popcll(m);
-        }
+    for (int r = 0; r < R; ++r) {
+        cnt_mine += valid[r] ? 1 : 0;
+        // columns: tile u / TW (when it exists) and the one before it when u sits on its ring; rows likewise
+        const int ax = (u[r] >> 6) - bx, ay = (v[r] >> SH) - by;
+        unsigned mx = (u[r] >> 6) < tiles_x ? 1u << ax : 0u, my = (v[r] >> SH) < tiles_y ? 1u << ay : 0u;
+        if ((u[r] & (TW - 1)) == 0 && u[r] > 0) mx |= 1u << (ax - 1);
+        if ((v[r] & (TH - 1)) == 0 && v[r] > 0) my |= 1u << (ay - 1);
+        // (bits 0..2 each: the block reaches at most 3 x 3 tiles, checked above) -> 9-bit mask, k = ky * 3 + kx
+        member[r] = valid[r] ? (mx & 7u) * ((my & 1u) | ((my & 2u) << 2) | ((my & 4u) << 4)) : 0u;
     }
+    const int nkx = ex - bx + 1, nky = ey - by + 1;    // uniform: the target tiles that can be non-empty
+    for (int ky = 0; ky < nky; ++ky)
+        for (int kx = 0; kx < nkx; ++kx) {
+            const int k = ky * 3 + kx;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const unsigned long long m = __ballot((member[r] >> k) & 1u);
+                if (lane == 0 && wave * R + r < TH) tab[k * 16 + wave * R + r] = __popcll(m);
+            }
+        }
+    CERB_STAMP_AT(2);
     __syncthreads();                                 // plane zeroed, counts published
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -596,15 +621,17 @@ __device__ __forceinline__ void lists_role(const F *__restrict__ flow, void *__r
     // start of every sub-list: sum of the counts of the lower target tiles
     int *kstart = tab + 9 * 16;                      // [10]
     if (tid < 9) {
-        int sum = 0;
+        int c[TH], sum = 0;
+#pragma unroll
+        for (int r = 0; r < TH; ++r) c[r] = tab[tid * 16 + r];   // (all reads in flight, then the prefix in registers)
 #pragma unroll
         for (int r = 0; r < TH; ++r) {               // counts -> exclusive prefix over the block rows, in place
-            const int c = tab[tid * 16 + r];
             tab[tid * 16 + r] = sum;
-            sum += c;
+            sum += c[r];
         }
         kstart[tid] = sum;                           // records for target tile `tid`
     }
+    CERB_STAMP_AT(3);
     __syncthreads();                                 // density adds done, per-tile counts known
     int counts[9], total = 0;
 #pragma unroll
@@ -628,21 +655,22 @@ __device__ __forceinline__ void lists_role(const F *__restrict__ flow, void *__r
         for (int k = 0; k < 9; ++k) hdr[6 + k] = counts[k];
         hdr[15] = 0;
     }
+    CERB_STAMP_AT(4);
     if (overflow) return;
     // ---- the records, ordered by (target tile, block row, lane) ----
     int kbase = 0;
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
-        const int kx = bx + k % 3, ky = by + k / 3;
-        if (counts[k] != 0) {
+        if (counts[k] != 0) {                        // uniform
+            const int kx = bx + k % 3, ky = by + k / 3;
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const int row = wave * R + r;
-                const int lx = u[r] - kx * TW, ly = v[r] - ky * TH;
-                const bool has = valid[r] && kx < tiles_x && ky < tiles_y && lx >= 0 && lx <= TW && ly >= 0 && ly <= TH;
+                const bool has = (member[r] >> k) & 1u;
                 const unsigned long long m = __ballot(has);
                 const int before = tab[k * 16 + min(row, TH - 1)];   // records of this sub-list in lower block rows
                 if (has) {
+                    const int lx = u[r] - kx * TW, ly = v[r] - ky * TH;
                     const int idx = kbase + before + __popcll(m & ((1ull << lane) - 1ull));
                     rec[idx] = make_int4(pv[r], ly * PW + lx, __float_as_int(fx[r]), __float_as_int(fy[r]));
                 }
@@ -650,6 +678,7 @@ __device__ __forceinline__ void lists_role(const F *__restrict__ flow, void *__r
         }
         kbase += counts[k];
     }
+    CERB_STAMP_AT(5);
 #endif
 }
 
@@ -1124,17 +1153,6 @@ __device__ __forceinline__ void flow_role_tile_direct(
     st(gf + plane, my * sy / static_cast<float>(H - 1) * 2.0f);
 }
 
-#ifdef CERB_STAMP
-// diagnostic build only (-DCERB_STAMP): s_memtime at the phase boundaries of the first 64 tile
-// workgroups, fetched with cerberus_debug_stamps(); never compiled into the product
-__device__ unsigned long long g_stamps[64][16];
-#define CERB_STAMP_AT(k)                                                         \
-    do {                                                                         \
-        if (threadIdx.x == 0 && blockIdx.x < 64) g_stamps[blockIdx.x][k] = __builtin_readcyclecounter(); \
-    } while (0)
-#else
-#define CERB_STAMP_AT(k) do {} while (0)
-#endif
 
 constexpr int kTileW = 64;
 static_assert(kTileW == kListTileW, "the lists are built for the backward's tile width");
@@ -1149,6 +1167,8 @@ __global__ __launch_bounds__(256, 4) void warp_bwd_tile_kernel(
     T *__restrict__ gimage, F *__restrict__ gflow, int B, int C, int H, int W,
     int tiles_x, int tiles_y, int nrange, int crange, int ntile_blocks, int pad_mode,
     int flow_staged, int flow_sub, int use_lists) {
+    const bool option_range_major = use_lists & 2;   // (experiments: the round-3 block order)
+    use_lists &= 1;
     constexpr int TW = kTileW, PW = TileGeom<TH>::PW, PS = TileGeom<TH>::PS;
     constexpr int NP = CW / 2;                       // channel pairs = planes of 64-bit slots
     static_assert(CW % 2 == 0, "channels are accumulated in pairs");
@@ -1244,19 +1264,23 @@ __global__ __launch_bounds__(256, 4) void warp_bwd_tile_kernel(
     }
 
     // -------------------------------- TILE workgroup --------------------------------
-    // (channel range, tile) with the tile fastest inside one XCD's contiguous share: spatial
-    // neighbours of one channel range (shared gradOutput halo lines) meet in one L2
+    // (image, tile row, tile column, channel range) with the RANGE fastest: an XCD's contiguous share is then a
+    // spatial region of one image with all its channel ranges -- the same region its share of the FLOW
+    // workgroups covers (also image-major, row-major), so that gradOutput, which both roles read, goes over
+    // the fabric once and is found in the XCD's L2 the second time (round 3: range-major tiles, the two
+    // roles of a region on different XCDs, gradOutput fetched twice: 1.41x the algorithmic bytes)
     int bid = xcd_chunk(blockIdx.x, ntile_blocks);
+    const int range = option_range_major ? bid / (ntile_blocks / nrange) : bid % nrange;
+    bid = option_range_major ? bid % (ntile_blocks / nrange) : bid / nrange;
     const int tx = bid % tiles_x; bid /= tiles_x;
     const int ty = bid % tiles_y; bid /= tiles_y;
-    const int b = bid % B;
-    const int range = bid / B;
+    const int b = bid;
     const int tx0 = tx * TW, ty0 = ty * TH;
     const int tx1 = min(tx0 + TW, W) - 1, ty1 = min(ty0 + TH, H) - 1;   // last pixel of the tile
     const int c_begin = range * crange, c_end = min(C, c_begin + crange);
     const float *pos = ctx_pos(ctx, B, H, W) + static_cast<int64_t>(b) * 2 * plane;
-    (void)nrange;
 
+    CERB_STAMP_AT(0);
     int n = 0, xs = 0, ys = 0, rw = 1;
     T *dst = gimage + static_cast<int64_t>(b) * C * plane;
     const T *go = gout + static_cast<int64_t>(b) * C * plane;
@@ -1382,14 +1406,58 @@ __global__ __launch_bounds__(256, 4) void warp_bwd_tile_kernel(
         }
     };
     // the group's tile -> global memory; accumulators back to zero for the next group
+    // Stores of one dword per lane are issue-bound (MI355X_MICROARCH.md, "store tail": ~7 B/clk/CU); a thread
+    // that owns four neighbouring elements of a row stores 16 bytes per channel instead: a quarter of the
+    // store instructions (level 3: the write-out phase 6.1k -> ~3k cycles of the workgroup's 35k).
+    const bool wide = W % 4 == 0 && (reinterpret_cast<uintptr_t>(gimage) & 15) == 0 && plane % 4 == 0;
     auto write_out = [&](int c0, int cw, float unscale, bool nonfinite) {
         const int npair = (cw + 1) / 2;
+        const bool last = c0 + CW >= c_end;          // nothing accumulates after the last group
+        if (wide) {
+            for (int i = tid; i < npair * TH * (TW / 4); i += 256) {
+                const int q = i / (TH * (TW / 4)), rem = i % (TH * (TW / 4));
+                const int yy = rem / (TW / 4), xx = (rem % (TW / 4)) * 4;
+                const int slot = q * PS + (yy + 1) * PW + xx + 1;
+                long long v[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = acc[slot + k];
+                if (!last) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) acc[slot + k] = 0;
+                }
+                if (ty0 + yy < H && tx0 + xx < W) {      // (W % 4 == 0: the four columns are in or out together)
+                    float ra[4], rb[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int lo = static_cast<int>(v[k]);
+                        const int hi = static_cast<int>((v[k] - lo) >> 32);
+                        ra[k] = nonfinite ? __int_as_float(lo) : static_cast<float>(lo) * unscale;
+                        rb[k] = nonfinite ? __int_as_float(static_cast<int>(v[k] >> 32)) : static_cast<float>(hi) * unscale;
+                    }
+                    T *d = dst + static_cast<int64_t>(c0 + 2 * q) * plane + (ty0 + yy) * W + tx0 + xx;
+                    if constexpr (sizeof(T) == 4) {
+                        *reinterpret_cast<float4 *>(d) = make_float4(ra[0], ra[1], ra[2], ra[3]);
+                        if (2 * q + 1 < cw) *reinterpret_cast<float4 *>(d + plane) = make_float4(rb[0], rb[1], rb[2], rb[3]);
+                    } else {
+                        T ta[4], tb[4];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) { st(&ta[k], ra[k]); st(&tb[k], rb[k]); }
+                        uint2 pa, pb;
+                        __builtin_memcpy(&pa, ta, 8);
+                        __builtin_memcpy(&pb, tb, 8);
+                        *reinterpret_cast<uint2 *>(d) = pa;
+                        if (2 * q + 1 < cw) *reinterpret_cast<uint2 *>(d + plane) = pb;
+                    }
+                }
+            }
+            return;
+        }
         for (int i = tid; i < npair * TH * TW; i += 256) {
             const int q = i / (TH * TW), rem = i % (TH * TW);
             const int yy = rem / TW, xx = rem % TW;
             const int slot = q * PS + (yy + 1) * PW + xx + 1;
             const long long v = acc[slot];
-            acc[slot] = 0;
+            if (!last) acc[slot] = 0;
             if (ty0 + yy < H && tx0 + xx < W) {
                 const int lo = static_cast<int>(v);
                 const int hi = static_cast<int>((v - lo) >> 32);
@@ -1409,13 +1477,18 @@ __global__ __launch_bounds__(256, 4) void warp_bwd_tile_kernel(
     // headroom bits (an element's density is the sum of what each block piles onto it).  Any flagged block,
     // a tiling mismatch or more sources than the registers hold -> the scan below, as before.
     constexpr int kCap = (NP * PS * 8) / 16 < 256 * NS ? (NP * PS * 8) / 16 : 256 * NS;
-    constexpr int kMaxSeg = 32;
-    __shared__ int4 segs[kMaxSeg];   // {first record, records, start in the tile's list, -}
+    // the tile's list = the contributing blocks' sub-lists, each padded to whole 16-entry chunks so that a thread
+    // finds its record with ONE table read (list position >> 4 -> {first record of the chunk, live entries})
+    constexpr int kMaxSeg = 32, kChunk = 16, kMaxChunks = kCap / kChunk;
+    __shared__ int2 chunks[kMaxChunks];
     {
         const int nblk = tiles_x * tiles_y;
         const int *lh = ctx_list_hdr(ctx, B, H, W) + static_cast<int64_t>(b) * nblk * kListHdrInts;
         const int4 *lr = ctx_list_rec(ctx, B, H, W) + static_cast<int64_t>(b) * nblk * list_cap(TH);
         if (tid < 4) red[2][tid] = tid == 3 && !use_lists ? 1 : 0;
+        static_assert((NP * PS) % 2 == 0, "accumulators are zeroed 16 bytes at a time");
+        if (use_lists)   // (the scan path borrows this LDS for its list first and zeroes it later)
+            for (int i = tid; i < NP * PS / 2; i += 256) reinterpret_cast<int4 *>(acc)[i] = make_int4(0, 0, 0, 0);
         __syncthreads();
         for (int f = tid; f < (use_lists ? nblk : 0); f += 256) {
             const int4 *hp = reinterpret_cast<const int4 *>(lh + f * kListHdrInts);
@@ -1433,16 +1506,19 @@ __global__ __launch_bounds__(256, 4) void warp_bwd_tile_kernel(
                     cnt = q == k ? c[q] : cnt;
                 }
                 if (cnt > 0) {
-                    const int slot = atomicAdd(&red[2][0], 1);
-                    const int start = atomicAdd(&red[2][1], cnt);
-                    atomicAdd(&red[2][2], min(h1.x, 0x00ffffff));
-                    if (slot < kMaxSeg) segs[slot] = make_int4(f * list_cap(TH) + before, cnt, start, 0);
+                    const int nch = (cnt + kChunk - 1) / kChunk;
+                    atomicAdd(&red[2][0], 1);
+                    const int start = atomicAdd(&red[2][1], nch);  // in chunks
+                    atomicAdd(&red[2][2], (h1.x >> 8) + 1);        // 24.8, rounded up: 32 blocks of 2048 sources fit
+                    for (int q = 0; q < nch && start + q < kMaxChunks; ++q)
+                        chunks[start + q] = make_int2(f * list_cap(TH) + before + q * kChunk, min(kChunk, cnt - q * kChunk));
                 }
             }
         }
         __syncthreads();
-        const int nseg = red[2][0], count = red[2][1], dsum = red[2][2], bad = red[2][3];
-        if (!bad && nseg <= kMaxSeg && count <= kCap) {
+        const int nseg = red[2][0], nchunks = red[2][1], dsum = red[2][2], bad = red[2][3];
+        const int count = nchunks * kChunk;                        // list positions, padding included
+        if (!bad && nseg <= kMaxSeg && nchunks <= kMaxChunks) {
             CERB_STAMP_AT(1);
             Src src[NS];
             float g[NS][CW];
@@ -1450,28 +1526,22 @@ __global__ __launch_bounds__(256, 4) void warp_bwd_tile_kernel(
 #pragma unroll
             for (int j = 0; j < NS; ++j) {
                 const int e = j * 256 + tid;
-                const bool have = e < count;
-                int ridx = 0;
-                if (j < ns)
-                    for (int q = 0; q < nseg; ++q) {
-                        const int4 sg = segs[q];
-                        if (e >= sg.z && e < sg.z + sg.y) ridx = sg.x + (e - sg.z);
-                    }
-                const int4 v = lr[have ? ridx : 0];
+                const int2 ch = chunks[min(e / kChunk, kMaxChunks - 1)];
+                const bool have = e < count && (e % kChunk) < ch.y;
+                const int4 v = lr[have ? ch.x + e % kChunk : 0];
                 src[j].pv = have ? v.x : 0;
                 src[j].o = have ? v.y : -1;
                 src[j].fx = __int_as_float(v.z);
                 src[j].fy = __int_as_float(v.w);
             }
             CERB_STAMP_AT(2);
-            static_assert((NP * PS) % 2 == 0, "accumulators are zeroed 16 bytes at a time");
-            for (int i = tid; i < NP * PS / 2; i += 256) reinterpret_cast<int4 *>(acc)[i] = make_int4(0, 0, 0, 0);
 #pragma unroll
             for (int j = 0; j < NS; ++j)
                 if (j < ns) load_g(src[j], c_begin, g[j]);
             CERB_STAMP_AT(3);
+            CERB_STAMP_AT(4);
             // 2^S >= the tile's largest tap density (16.16 sums of the contributing blocks' bounds)
-            const int sbits = max(0, 32 - __clz(max(dsum, 1)) - 16);
+            const int sbits = max(0, 32 - __clz(max(dsum, 1)) - 8);
             for (int c0 = c_begin; c0 < c_end; c0 += CW) {
                 const int cw = min(CW, c_end - c0);
                 int gb = 0;
@@ -1502,7 +1572,6 @@ __global__ __launch_bounds__(256, 4) void warp_bwd_tile_kernel(
         __syncthreads();   // red[] is reused by the scan
     }
 
-    CERB_STAMP_AT(0);
     // ---- scan region ----
     // The context holds one signed tap-displacement range per 64-pixel strip.  A strip
     // matters to this tile only if its pixels displaced by its OWN range can reach the tile;
@@ -1875,7 +1944,8 @@ static int launch_tiles(const void *image, const void *gout, const void *ctx, vo
                        static_cast<const T *>(image), static_cast<const T *>(gout), ctx,
                        static_cast<T *>(gimage), static_cast<F *>(gflow), B,
                        C, H, W, tiles_x, tiles_y, nrange, crange, static_cast<int>(tile_blocks),
-                       pad_mode, flow_staged ? 1 : 0, flow_sub, option(OPT_WARP_NO_LISTS) ? 0 : 1);
+                       pad_mode, flow_staged ? 1 : 0, flow_sub,
+                       (option(OPT_WARP_NO_LISTS) & 1 ? 0 : 1) | (option(OPT_WARP_NO_LISTS) & 2));
     return launch_status();
 }
 
