@@ -76,7 +76,6 @@ enum OptId {
     OPT_WARP_TILE_H,
     OPT_WARP_FORCE_SCATTER,
     OPT_WARP_STAGED,
-    OPT_WARP_NO_LISTS,
 #ifdef CERB_ABLATE
     OPT_DEBUG_ABLATE,   // timing-ablation mask: exists in -DCERB_ABLATE builds only
 #endif

@@ -151,53 +151,8 @@ constexpr int kExtEmptyLo = 0x3fffffff, kExtEmptyHi = -0x3fffffff;
 __host__ __device__ inline int64_t ctx_header_bytes(int B, int H, int W) {
     return static_cast<int64_t>(B) * Strips(H, W).per_image() * 4 * sizeof(int);
 }
-// Round 4: SOURCE LISTS.  Everything the grad_image tiles of the backward used to re-derive from the
-// positions on every call and for every channel range -- which pixels feed a tile, where their taps land in
-// it, how many taps pile up on one element -- depends on the flow only, and the forward has every pixel's
-// position in registers anyway.  So the forward's launch carries a second kind of workgroup (lists_role):
-// one per TH x 64 block of DESTINATION pixels (the same tiling as the backward's grad_image tiles).  It
-// sorts its pixels by the tile(s) their taps land in -- at most 3 x 3 tiles from a base tile, else the block
-// is flagged and the backward falls back to scanning the positions -- and writes one sub-list per target
-// tile, in a fixed order (tile index, block row, lane): no global atomics, nothing to zero, deterministic.
-//   int   hdr[B * nblk][16]     {magic | TH, base tile x, base tile y, flags, density bound (16.16),
-//                                total records, records for target tile k = 0 .. 8, 0}
-//   int4  rec[B * nblk][cap]    {pixel index in the image, offset in the tile's padded accumulator plane,
-//                                tap fraction x, tap fraction y} (the backward's `Src`), sub-lists back to back
-// The areas are sized for the 8-row tiling (the larger of the two): cap = 2 records per pixel of a block.
-constexpr int kListHdrInts = 16;
-constexpr int kListMagic = 0x4c530000;
-constexpr int kListTileW = 64;                       // == kTileW (static_assert below)
-__host__ __device__ inline int list_cap(int th) { return 2 * th * kListTileW; }
-__host__ __device__ inline int64_t ctx_lists_offset(int B, int H, int W) {
-    const int64_t o = ctx_header_bytes(B, H, W) + static_cast<int64_t>(B) * 2 * H * W * sizeof(float);
-    return (o + 15) & ~int64_t(15);
-}
-__host__ __device__ inline int64_t list_blocks8(int B, int H, int W) {   // blocks of the 8-row tiling
-    return static_cast<int64_t>(B) * ((W + kListTileW - 1) / kListTileW) * ((H + 7) / 8);
-}
 __host__ __device__ inline int64_t ctx_bytes(int B, int H, int W) {
-    return ctx_lists_offset(B, H, W) + list_blocks8(B, H, W) * (kListHdrInts * 4 + list_cap(8) * 16);
-}
-__host__ __device__ __forceinline__ int *ctx_list_hdr(void *ctx, int B, int H, int W) {
-    return reinterpret_cast<int *>(static_cast<char *>(ctx) + ctx_lists_offset(B, H, W));
-}
-__host__ __device__ __forceinline__ const int *ctx_list_hdr(const void *ctx, int B, int H, int W) {
-    return reinterpret_cast<const int *>(static_cast<const char *>(ctx) + ctx_lists_offset(B, H, W));
-}
-__host__ __device__ __forceinline__ int4 *ctx_list_rec(void *ctx, int B, int H, int W) {
-    return reinterpret_cast<int4 *>(static_cast<char *>(ctx) + ctx_lists_offset(B, H, W) +
-                                    list_blocks8(B, H, W) * kListHdrInts * 4);
-}
-__host__ __device__ __forceinline__ const int4 *ctx_list_rec(const void *ctx, int B, int H, int W) {
-    return reinterpret_cast<const int4 *>(static_cast<const char *>(ctx) + ctx_lists_offset(B, H, W) +
-                                          list_blocks8(B, H, W) * kListHdrInts * 4);
-}
-// rows per grad_image tile: 16, 8 on small maps (twice the workgroups, a smaller region per workgroup);
-// the forward builds its lists for the tiling the backward will use
-static inline int tile_rows(int B, int H, int W) {
-    const int th_opt = option(OPT_WARP_TILE_H);
-    if (th_opt == 8 || th_opt == 16) return th_opt;
-    return static_cast<int64_t>(B) * H * W <= 64 * 128 * 4 ? 8 : 16;
+    return ctx_header_bytes(B, H, W) + static_cast<int64_t>(B) * 2 * H * W * sizeof(float);
 }
 __host__ __device__ __forceinline__ float *ctx_pos(void *ctx, int B, int H, int W) {
     return reinterpret_cast<float *>(static_cast<char *>(ctx) + ctx_header_bytes(B, H, W));
@@ -234,17 +189,6 @@ __device__ __forceinline__ int tap_index(float f) {
     return min(max(static_cast<int>(f), -(1 << 24)), 1 << 24);
 }
 
-// source lists of one TH x 64 block of destination pixels (defined below the staged forward's helpers)
-template <typename F, int TH, int NW>
-__device__ __forceinline__ void lists_role(const F *__restrict__ flow, void *__restrict__ ctx, unsigned *plane, int plane_cap,
-                           int *tab, int role_id, int B, int H, int W, int pad_mode);
-constexpr int kRolePlane = 6144;                 // u32 cells of the role's density plane (kernels without a window)
-constexpr int kRoleTab = 9 * 16 + 16 + 64;       // ints of the role's LDS tables
-// workgroups of the lists role in a forward / context launch
-__host__ __device__ inline int list_role_blocks(int B, int H, int W, int th) {
-    return B * ((W + kListTileW - 1) / kListTileW) * ((H + th - 1) / th);
-}
-
 // Grid: 1-D over the B * strips-per-image pixel strips, one per workgroup.  T: image / output
 // storage type, F: flow type
 // (F = float with a 16-bit image keeps full flow precision: the reference's grid_sample runs
@@ -252,15 +196,8 @@ __host__ __device__ inline int list_role_blocks(int B, int H, int W, int th) {
 template <typename T, typename F, bool PAIR, int kCg>
 __global__ __launch_bounds__(kPix * kCg) void warp_fwd_kernel(
     const T *__restrict__ image, const F *__restrict__ flow, T *__restrict__ out,
-    void *__restrict__ ctx, int B, int C, int H, int W, int pad_mode, int interp, int nrole, int list_th) {
+    void *__restrict__ ctx, int B, int C, int H, int W, int pad_mode, int interp) {
     using A = typename Acc<T>::type;
-    if (static_cast<int>(blockIdx.x) < nrole) {      // the context's source lists (nrole = 0 without a context)
-        __shared__ unsigned role_plane[kRolePlane];
-        __shared__ int role_tab[kRoleTab];
-        if (list_th == 8) lists_role<F, 8, kCg>(flow, ctx, role_plane, kRolePlane, role_tab, blockIdx.x, B, H, W, pad_mode);
-        else lists_role<F, 16, kCg>(flow, ctx, role_plane, kRolePlane, role_tab, blockIdx.x, B, H, W, pad_mode);
-        return;
-    }
     const int64_t plane = static_cast<int64_t>(H) * W;
     const int lane = threadIdx.x & (kPix - 1);
     const int cg = threadIdx.x / kPix;
@@ -268,9 +205,8 @@ __global__ __launch_bounds__(kPix * kCg) void warp_fwd_kernel(
     const int spp = strips.per_image();
     const int64_t nstrips = static_cast<int64_t>(B) * spp;
     TapRange range;
-    const int nwork = gridDim.x - nrole;
-    const int first = xcd_chunk(blockIdx.x - nrole, nwork);
-    for (int64_t strip = first; strip < nstrips; strip += nwork) {
+    const int first = xcd_chunk(blockIdx.x, gridDim.x);
+    for (int64_t strip = first; strip < nstrips; strip += gridDim.x) {
         const int b = static_cast<int>(strip / spp);
         int x, y;
         if (!strips.pixel(static_cast<int>(strip % spp), lane, H, W, x, y)) continue;
@@ -498,211 +434,20 @@ struct StageWindow {
     }
 };
 
-#ifdef CERB_STAMP
-// diagnostic build only (-DCERB_STAMP): s_memtime at the phase boundaries of the first 64 tile
-// workgroups, fetched with cerberus_debug_stamps(); never compiled into the product
-__device__ unsigned long long g_stamps[64][16];
-#define CERB_STAMP_AT(k)                                                         \
-    do {                                                                         \
-        if (threadIdx.x == 0 && blockIdx.x < 64) g_stamps[blockIdx.x][k] = __builtin_readcyclecounter(); \
-    } while (0)
-#else
-#define CERB_STAMP_AT(k) do {} while (0)
-#endif
-
-// ---- the lists role (see the context layout above) ----------------------------------------------------
-// Workgroup of NW wavefronts; wave w owns block rows w*R .. w*R+R-1 (R = ceil(TH / NW)), lane = column.
-template <typename F, int TH, int NW>
-__device__ __forceinline__ void lists_role(const F *__restrict__ flow, void *__restrict__ ctx, unsigned *plane, int plane_cap,
-                           int *tab, int role_id, int B, int H, int W, int pad_mode) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    constexpr int TW = kListTileW, R = (TH + NW - 1) / NW, PW = TW + 2;
-    constexpr int SH = TH == 16 ? 4 : 3;
-    static_assert(TH == 8 || TH == 16, "tile rows");
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH, nblk = tiles_x * tiles_y;
-    const int b = role_id / nblk, blk = role_id % nblk;
-    const int tx = blk % tiles_x, ty = blk / tiles_x;
-    const int plane_px = H * W;
-    CERB_STAMP_AT(0);
-    int u[R], v[R], pv[R];
-    float fx[R], fy[R];
-    bool valid[R];
-    int umin = kExtEmptyLo, umax = kExtEmptyHi, vmin = kExtEmptyLo, vmax = kExtEmptyHi;
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const int row = wave * R + r;
-        const int x = tx * TW + lane, y = ty * TH + row;
-        const bool live = row < TH && x < W && y < H;
-        pv[r] = live ? y * W + x : 0;
-        const F *fl = flow + static_cast<int64_t>(b) * 2 * plane_px + pv[r];
-        const Coord<float> cx = source_coord<float>(x, static_cast<float>(ld(fl)), W, pad_mode);
-        const Coord<float> cy = source_coord<float>(y, static_cast<float>(ld(fl + plane_px)), H, pad_mode);
-        const float x0f = floorf(cx.pos), y0f = floorf(cy.pos);
-        fx[r] = cx.pos - x0f;
-        fy[r] = cy.pos - y0f;
-        u[r] = tap_index(x0f) + 1;
-        v[r] = tap_index(y0f) + 1;
-        // a source: its north-west tap lies in [-1, W-1] x [-1, H-1] (some tap column and some tap row inside)
-        valid[r] = live && u[r] >= 0 && u[r] <= W && v[r] >= 0 && v[r] <= H;
-        if (valid[r]) {
-            umin = min(umin, u[r]); umax = max(umax, u[r]);
-            vmin = min(vmin, v[r]); vmax = max(vmax, v[r]);
-        }
-    }
-    int *box = tab + 9 * 16 + 16;                  // [NW][4]
-    {
-        const int a = wave_minmax<false>(umin), c = wave_minmax<true>(umax);
-        const int d = wave_minmax<false>(vmin), e = wave_minmax<true>(vmax);
-        if (lane == 0) { box[wave * 4] = a; box[wave * 4 + 1] = c; box[wave * 4 + 2] = d; box[wave * 4 + 3] = e; }
-    }
-    for (int i = tid; i < 9 * 16; i += NW * 64) tab[i] = 0;   // (target tiles the block does not reach stay empty)
-    __syncthreads();
-    CERB_STAMP_AT(1);
-    umin = kExtEmptyLo; umax = kExtEmptyHi; vmin = kExtEmptyLo; vmax = kExtEmptyHi;
-#pragma unroll
-    for (int w = 0; w < NW; ++w) {
-        umin = min(umin, box[w * 4]); umax = max(umax, box[w * 4 + 1]);
-        vmin = min(vmin, box[w * 4 + 2]); vmax = max(vmax, box[w * 4 + 3]);
-    }
-    umin = __builtin_amdgcn_readfirstlane(umin); umax = __builtin_amdgcn_readfirstlane(umax);
-    vmin = __builtin_amdgcn_readfirstlane(vmin); vmax = __builtin_amdgcn_readfirstlane(vmax);
-    int *hdr = ctx_list_hdr(ctx, B, H, W) + static_cast<int64_t>(role_id) * kListHdrInts;
-    int4 *rec = ctx_list_rec(ctx, B, H, W) + static_cast<int64_t>(role_id) * list_cap(TH);
-    const bool none = umin > umax;
-    // tiles a tap coordinate u (= x0 + 1) belongs to: u / TW, and the tile before it when u sits on its ring
-    auto lo_tile = [](int c, int sh, int mask) { return (c >> sh) - ((c & mask) == 0 && c > 0 ? 1 : 0); };
-    const int bx = none ? 0 : lo_tile(umin, 6, TW - 1), by = none ? 0 : lo_tile(vmin, SH, TH - 1);
-    const int ex = none ? 0 : min(umax >> 6, tiles_x - 1), ey = none ? 0 : min(vmax >> SH, tiles_y - 1);
-    const int pw = none ? 1 : umax - umin + 2, prow = none ? 1 : vmax - vmin + 2;
-    bool overflow = ex - bx > 2 || ey - by > 2 || static_cast<int64_t>(pw) * prow > plane_cap;
-    if (overflow) {                                  // uniform: the backward scans the positions instead
-        if (tid == 0) { hdr[0] = kListMagic | TH; hdr[1] = bx; hdr[2] = by; hdr[3] = 1; hdr[4] = 0; hdr[5] = 0; }
-        return;
-    }
-    // ---- density plane: the four tap weights of every source, 16.16 ----
-    for (int i = tid; i < pw * prow; i += NW * 64) plane[i] = 0;
-    // ---- records per (target tile k, block row): ballots ----
-    int cnt_mine = 0;
-    unsigned member[R];                              // bit k: the pixel is a source of target tile k
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        cnt_mine += valid[r] ? 1 : 0;
-        // columns: tile u / TW (when it exists) and the one before it when u sits on its ring; rows likewise
-        const int ax = (u[r] >> 6) - bx, ay = (v[r] >> SH) - by;
-        unsigned mx = (u[r] >> 6) < tiles_x ? 1u << ax : 0u, my = (v[r] >> SH) < tiles_y ? 1u << ay : 0u;
-        if ((u[r] & (TW - 1)) == 0 && u[r] > 0) mx |= 1u << (ax - 1);
-        if ((v[r] & (TH - 1)) == 0 && v[r] > 0) my |= 1u << (ay - 1);
-        // (bits 0..2 each: the block reaches at most 3 x 3 tiles, checked above) -> 9-bit mask, k = ky * 3 + kx
-        member[r] = valid[r] ? (mx & 7u) * ((my & 1u) | ((my & 2u) << 2) | ((my & 4u) << 4)) : 0u;
-    }
-    const int nkx = ex - bx + 1, nky = ey - by + 1;    // uniform: the target tiles that can be non-empty
-    for (int ky = 0; ky < nky; ++ky)
-        for (int kx = 0; kx < nkx; ++kx) {
-            const int k = ky * 3 + kx;
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const unsigned long long m = __ballot((member[r] >> k) & 1u);
-                if (lane == 0 && wave * R + r < TH) tab[k * 16 + wave * R + r] = __popcll(m);
-            }
-        }
-    CERB_STAMP_AT(2);
-    __syncthreads();                                 // plane zeroed, counts published
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        if (!valid[r]) continue;
-        const float ax = 1.0f - fx[r], ay = 1.0f - fy[r];
-        unsigned *d = plane + (v[r] - vmin) * pw + (u[r] - umin);
-        atomicAdd(d, static_cast<unsigned>(__float2int_rn(ax * ay * 65536.f)));
-        atomicAdd(d + 1, static_cast<unsigned>(__float2int_rn(fx[r] * ay * 65536.f)));
-        atomicAdd(d + pw, static_cast<unsigned>(__float2int_rn(ax * fy[r] * 65536.f)));
-        atomicAdd(d + pw + 1, static_cast<unsigned>(__float2int_rn(fx[r] * fy[r] * 65536.f)));
-    }
-    // start of every sub-list: sum of the counts of the lower target tiles
-    int *kstart = tab + 9 * 16;                      // [10]
-    if (tid < 9) {
-        int c[TH], sum = 0;
-#pragma unroll
-        for (int r = 0; r < TH; ++r) c[r] = tab[tid * 16 + r];   // (all reads in flight, then the prefix in registers)
-#pragma unroll
-        for (int r = 0; r < TH; ++r) {               // counts -> exclusive prefix over the block rows, in place
-            tab[tid * 16 + r] = sum;
-            sum += c[r];
-        }
-        kstart[tid] = sum;                           // records for target tile `tid`
-    }
-    CERB_STAMP_AT(3);
-    __syncthreads();                                 // density adds done, per-tile counts known
-    int counts[9], total = 0;
-#pragma unroll
-    for (int k = 0; k < 9; ++k) { counts[k] = kstart[k]; total += counts[k]; }
-    unsigned dm = 0;
-    for (int i = tid; i < pw * prow; i += NW * 64) dm = max(dm, plane[i]);
-    int dmi = wave_minmax<true>(static_cast<int>(min(dm, 0x3fffffffu)));
-    int nv = cnt_mine;
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) nv += __shfl_xor(nv, m, 64);
-    if (lane == 0) { box[wave * 4] = dmi; box[wave * 4 + 1] = nv; }
-    __syncthreads();
-    if (total > list_cap(TH)) overflow = true;       // uniform
-    if (tid == 0) {
-        int dmax = 0, nvalid = 0;
-        for (int w = 0; w < NW; ++w) { dmax = max(dmax, box[w * 4]); nvalid += box[w * 4 + 1]; }
-        hdr[0] = kListMagic | TH; hdr[1] = bx; hdr[2] = by; hdr[3] = overflow ? 1 : 0;
-        hdr[4] = min(dmax, 0x3fffffff) + nvalid;     // (+ nvalid: rounding of the 16.16 weights)
-        hdr[5] = total;
-#pragma unroll
-        for (int k = 0; k < 9; ++k) hdr[6 + k] = counts[k];
-        hdr[15] = 0;
-    }
-    CERB_STAMP_AT(4);
-    if (overflow) return;
-    // ---- the records, ordered by (target tile, block row, lane) ----
-    int kbase = 0;
-#pragma unroll
-    for (int k = 0; k < 9; ++k) {
-        if (counts[k] != 0) {                        // uniform
-            const int kx = bx + k % 3, ky = by + k / 3;
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const int row = wave * R + r;
-                const bool has = (member[r] >> k) & 1u;
-                const unsigned long long m = __ballot(has);
-                const int before = tab[k * 16 + min(row, TH - 1)];   // records of this sub-list in lower block rows
-                if (has) {
-                    const int lx = u[r] - kx * TW, ly = v[r] - ky * TH;
-                    const int idx = kbase + before + __popcll(m & ((1ull << lane) - 1ull));
-                    rec[idx] = make_int4(pv[r], ly * PW + lx, __float_as_int(fx[r]), __float_as_int(fy[r]));
-                }
-            }
-        }
-        kbase += counts[k];
-    }
-    CERB_STAMP_AT(5);
-#endif
-}
-
 template <typename T, typename F>
 __global__ __launch_bounds__(256) void warp_fwd_staged_kernel(
     const T *__restrict__ image, const F *__restrict__ flow, T *__restrict__ out,
-    void *__restrict__ ctx, int B, int C, int H, int W, int pad_mode, int crange, int nrange, int nrole,
-    int list_th) {
+    void *__restrict__ ctx, int B, int C, int H, int W, int pad_mode, int crange, int nrange) {
 #if defined(__HIP_DEVICE_COMPILE__)
     __shared__ __attribute__((aligned(16))) float win[kStageCap];
     __shared__ int4 boxes[4];
-    if (static_cast<int>(blockIdx.x) < nrole) {      // the context's source lists (nrole = 0 without a context)
-        __shared__ int role_tab[kRoleTab];
-        if (list_th == 8) lists_role<F, 8, 4>(flow, ctx, reinterpret_cast<unsigned *>(win), kStageCap, role_tab, blockIdx.x, B, H, W, pad_mode);
-        else lists_role<F, 16, 4>(flow, ctx, reinterpret_cast<unsigned *>(win), kStageCap, role_tab, blockIdx.x, B, H, W, pad_mode);
-        return;
-    }
     constexpr int esz = sizeof(T);
     const int plane = H * W;   // the launcher guarantees C * plane * esz < 2^31
     const int tid = threadIdx.x;
     const int lane = tid & (kPix - 1), wave = __builtin_amdgcn_readfirstlane(tid / kPix);
     const Strips strips(H, W);
     const int tyn = (strips.ny + kStageRows - 1) / kStageRows;
-    int id = xcd_chunk(blockIdx.x - nrole, gridDim.x - nrole);
+    int id = xcd_chunk(blockIdx.x, gridDim.x);
     const int r = __builtin_amdgcn_readfirstlane(id % nrange); id /= nrange;
     const int tx = __builtin_amdgcn_readfirstlane(id % strips.nx); id /= strips.nx;
     const int ty = __builtin_amdgcn_readfirstlane(id % tyn);
@@ -806,27 +551,20 @@ __global__ __launch_bounds__(256) void warp_fwd_staged_kernel(
 // Context from the flow alone (backward called without a forward context): same strip ->
 // workgroup mapping as the forward, one wavefront per workgroup.
 template <typename F>
-__global__ __launch_bounds__(256) void warp_context_kernel(const F *__restrict__ flow,
-                                                            void *__restrict__ ctx, int B, int H,
-                                                            int W, int pad_mode, int nrole, int list_th) {
-    if (static_cast<int>(blockIdx.x) < nrole) {
-        __shared__ unsigned role_plane[kRolePlane];
-        __shared__ int role_tab[kRoleTab];
-        if (list_th == 8) lists_role<F, 8, 4>(flow, ctx, role_plane, kRolePlane, role_tab, blockIdx.x, B, H, W, pad_mode);
-        else lists_role<F, 16, 4>(flow, ctx, role_plane, kRolePlane, role_tab, blockIdx.x, B, H, W, pad_mode);
-        return;
-    }
+__global__ __launch_bounds__(kPix) void warp_context_kernel(const F *__restrict__ flow,
+                                                             void *__restrict__ ctx, int B, int H,
+                                                             int W, int pad_mode) {
     const int64_t plane = static_cast<int64_t>(H) * W;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x;
     const Strips strips(H, W);
     const int spp = strips.per_image();
     const int64_t nstrips = static_cast<int64_t>(B) * spp;
-    const int64_t strip = static_cast<int64_t>(blockIdx.x - nrole) * 4 + wave;   // one strip per wavefront
-    if (strip >= nstrips) return;
     TapRange range;
-    const int b = static_cast<int>(strip / spp);
-    int x, y;
-    if (strips.pixel(static_cast<int>(strip % spp), lane, H, W, x, y)) {
+    const int first = xcd_chunk(blockIdx.x, gridDim.x);
+    for (int64_t strip = first; strip < nstrips; strip += gridDim.x) {
+        const int b = static_cast<int>(strip / spp);
+        int x, y;
+        if (!strips.pixel(static_cast<int>(strip % spp), lane, H, W, x, y)) continue;
         const int64_t p = static_cast<int64_t>(y) * W + x;
         const F *fl = flow + static_cast<int64_t>(b) * 2 * plane + p;
         const Coord<float> cx = source_coord<float>(x, static_cast<float>(ld(fl)), W, pad_mode);
@@ -836,7 +574,7 @@ __global__ __launch_bounds__(256) void warp_context_kernel(const F *__restrict__
         pos[plane] = cy.pos;
         range.add(x, y, tap_index(floorf(cx.pos)), tap_index(floorf(cy.pos)), W, H);
     }
-    range.publish(ctx, static_cast<int>(strip), lane);
+    range.publish(ctx, first, lane);
 }
 
 // ---- atomics ----------------------------------------------------------------
@@ -1153,9 +891,19 @@ __device__ __forceinline__ void flow_role_tile_direct(
     st(gf + plane, my * sy / static_cast<float>(H - 1) * 2.0f);
 }
 
+#ifdef CERB_STAMP
+// diagnostic build only (-DCERB_STAMP): s_memtime at the phase boundaries of the first 64 tile
+// workgroups, fetched with cerberus_debug_stamps(); never compiled into the product
+__device__ unsigned long long g_stamps[64][16];
+#define CERB_STAMP_AT(k)                                                         \
+    do {                                                                         \
+        if (threadIdx.x == 0 && blockIdx.x < 64) g_stamps[blockIdx.x][k] = __builtin_readcyclecounter(); \
+    } while (0)
+#else
+#define CERB_STAMP_AT(k) do {} while (0)
+#endif
 
 constexpr int kTileW = 64;
-static_assert(kTileW == kListTileW, "the lists are built for the backward's tile width");
 template <int TH> struct TileGeom {
     static constexpr int PW = kTileW + 2;          // padded row, in accumulators
     static constexpr int PS = (TH + 2) * PW;       // accumulators per channel plane
@@ -1166,9 +914,7 @@ __global__ __launch_bounds__(256, 4) void warp_bwd_tile_kernel(
     const T *__restrict__ image, const T *__restrict__ gout, const void *__restrict__ ctx,
     T *__restrict__ gimage, F *__restrict__ gflow, int B, int C, int H, int W,
     int tiles_x, int tiles_y, int nrange, int crange, int ntile_blocks, int pad_mode,
-    int flow_staged, int flow_sub, int use_lists) {
-    const bool option_range_major = use_lists & 2;   // (experiments: the round-3 block order)
-    use_lists &= 1;
+    int flow_staged, int flow_sub) {
     constexpr int TW = kTileW, PW = TileGeom<TH>::PW, PS = TileGeom<TH>::PS;
     constexpr int NP = CW / 2;                       // channel pairs = planes of 64-bit slots
     static_assert(CW % 2 == 0, "channels are accumulated in pairs");
@@ -1268,10 +1014,9 @@ __global__ __launch_bounds__(256, 4) void warp_bwd_tile_kernel(
     // spatial region of one image with all its channel ranges -- the same region its share of the FLOW
     // workgroups covers (also image-major, row-major), so that gradOutput, which both roles read, goes over
     // the fabric once and is found in the XCD's L2 the second time (round 3: range-major tiles, the two
-    // roles of a region on different XCDs, gradOutput fetched twice: 1.41x the algorithmic bytes)
+    // roles of a region on different XCDs: 26.2 -> 24.0 us at level 3, profiles/r04_warp_lists_experiment.txt)
     int bid = xcd_chunk(blockIdx.x, ntile_blocks);
-    const int range = option_range_major ? bid / (ntile_blocks / nrange) : bid % nrange;
-    bid = option_range_major ? bid % (ntile_blocks / nrange) : bid / nrange;
+    const int range = bid % nrange; bid /= nrange;
     const int tx = bid % tiles_x; bid /= tiles_x;
     const int ty = bid % tiles_y; bid /= tiles_y;
     const int b = bid;
@@ -1281,7 +1026,70 @@ __global__ __launch_bounds__(256, 4) void warp_bwd_tile_kernel(
     const float *pos = ctx_pos(ctx, B, H, W) + static_cast<int64_t>(b) * 2 * plane;
 
     CERB_STAMP_AT(0);
+    // ---- scan region ----
+    // The context holds one signed tap-displacement range per 64-pixel strip.  A strip
+    // matters to this tile only if its pixels displaced by its OWN range can reach the tile;
+    // the region is the bounding box of those strips clipped to the tile displaced by the
+    // union of their ranges.  A fast object therefore widens only the tiles it feeds: there
+    // is no global limit and no fallback.
+    int rx0 = kExtEmptyLo, rx1 = kExtEmptyHi, ry0 = kExtEmptyLo, ry1 = kExtEmptyHi;
+    int dxl = kExtEmptyLo, dxh = kExtEmptyHi, dyl = kExtEmptyLo, dyh = kExtEmptyHi;
+    {
+        const int4 *ext = static_cast<const int4 *>(ctx);
+        const Strips strips(H, W);
+        const int spp = strips.per_image();
+        // strip j = tid + 256 k as (jy, jx), advanced without divisions in the loop
+        int jy = tid / strips.nx, jx = tid % strips.nx;
+        const int qy = 256 / strips.nx, qx = 256 % strips.nx;
+        for (int j = tid; j < spp; j += 256) {
+            const int slot = b * spp + j;
+            const int4 e = ext[slot];
+            const int sy0 = jy * kStripH, sy1 = min(sy0 + kStripH, H) - 1;
+            const int sx0 = jx * kStripW, sx1 = min(sx0 + kStripW, W) - 1;
+            const bool hit = e.x <= e.y && sx0 + e.x <= tx1 && sx1 + e.y >= tx0 &&
+                             sy0 + e.z <= ty1 && sy1 + e.w >= ty0;
+            if (hit) {
+                rx0 = min(rx0, sx0); rx1 = max(rx1, sx1);
+                ry0 = min(ry0, sy0); ry1 = max(ry1, sy1);
+                dxl = min(dxl, e.x); dxh = max(dxh, e.y);
+                dyl = min(dyl, e.z); dyh = max(dyh, e.w);
+            }
+            jx += qx; jy += qy;
+            if (jx >= strips.nx) { jx -= strips.nx; ++jy; }
+        }
+    }
+    // wave-wide folds on the DPP path (6 VALU each, result uniform); round 3 folded these eight values with
+    // 48 __shfl_xor = 48 ds_bpermute_b32 through the LDS crossbar the accumulators' atomics also use
+    rx0 = wave_minmax<false>(rx0); rx1 = wave_minmax<true>(rx1);
+    ry0 = wave_minmax<false>(ry0); ry1 = wave_minmax<true>(ry1);
+    dxl = wave_minmax<false>(dxl); dxh = wave_minmax<true>(dxh);
+    dyl = wave_minmax<false>(dyl); dyh = wave_minmax<true>(dyh);
+    // (folding the boxes with LDS min/max atomics instead of shuffles: 64 lanes on 8 addresses
+    // serialise -- 19k instead of 5k cycles for this phase, measured)
+    if (lane == 0) {
+        red[wave][0] = rx0; red[wave][1] = rx1; red[wave][2] = ry0; red[wave][3] = ry1;
+        red[wave][4] = dxl; red[wave][5] = dxh; red[wave][6] = dyl; red[wave][7] = dyh;
+    }
+    __syncthreads();
+    rx0 = min(min(red[0][0], red[1][0]), min(red[2][0], red[3][0]));
+    rx1 = max(max(red[0][1], red[1][1]), max(red[2][1], red[3][1]));
+    ry0 = min(min(red[0][2], red[1][2]), min(red[2][2], red[3][2]));
+    ry1 = max(max(red[0][3], red[1][3]), max(red[2][3], red[3][3]));
+    dxl = min(min(red[0][4], red[1][4]), min(red[2][4], red[3][4]));
+    dxh = max(max(red[0][5], red[1][5]), max(red[2][5], red[3][5]));
+    dyl = min(min(red[0][6], red[1][6]), min(red[2][6], red[3][6]));
+    dyh = max(max(red[0][7], red[1][7]), max(red[2][7], red[3][7]));
     int n = 0, xs = 0, ys = 0, rw = 1;
+    if (rx0 <= rx1) {   // at least one strip reaches the tile (ranges are small ints here)
+        xs = max(rx0, tx0 - dxh);
+        ys = max(ry0, ty0 - dyh);
+        rw = max(min(rx1, tx1 - dxl) + 1 - xs, 0);
+        n = rw * max(min(ry1, ty1 - dyl) + 1 - ys, 0);
+        rw = max(rw, 1);
+    }
+    __syncthreads();    // red[] is reused below
+    CERB_STAMP_AT(1);
+
     T *dst = gimage + static_cast<int64_t>(b) * C * plane;
     const T *go = gout + static_cast<int64_t>(b) * C * plane;
     unsigned long long *acc64 = reinterpret_cast<unsigned long long *>(acc);
@@ -1324,11 +1132,8 @@ __global__ __launch_bounds__(256, 4) void warp_bwd_tile_kernel(
     };
     // block maximum of two non-negative ints at once
     auto block_max2 = [&](int &u, int &v) {
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) {
-            u = max(u, __shfl_xor(u, m, 64));
-            v = max(v, __shfl_xor(v, m, 64));
-        }
+        u = wave_minmax<true>(u);
+        v = wave_minmax<true>(v);
         if (lane == 0) { red[wave][0] = u; red[wave][1] = v; }
         __syncthreads();
         u = max(max(red[0][0], red[1][0]), max(red[2][0], red[3][0]));
@@ -1471,171 +1276,6 @@ __global__ __launch_bounds__(256, 4) void warp_bwd_tile_kernel(
         }
     };
 
-    // ---- round 4: the forward's source lists (lists_role) -- no scan, no classification, no density pass ----
-    // Every block header of the image is read (one per thread on the benched maps); the blocks that
-    // listed sources for THIS tile give the segments of its list, the sum of their density bounds gives the
-    // headroom bits (an element's density is the sum of what each block piles onto it).  Any flagged block,
-    // a tiling mismatch or more sources than the registers hold -> the scan below, as before.
-    constexpr int kCap = (NP * PS * 8) / 16 < 256 * NS ? (NP * PS * 8) / 16 : 256 * NS;
-    // the tile's list = the contributing blocks' sub-lists, each padded to whole 16-entry chunks so that a thread
-    // finds its record with ONE table read (list position >> 4 -> {first record of the chunk, live entries})
-    constexpr int kMaxSeg = 32, kChunk = 16, kMaxChunks = kCap / kChunk;
-    __shared__ int2 chunks[kMaxChunks];
-    {
-        const int nblk = tiles_x * tiles_y;
-        const int *lh = ctx_list_hdr(ctx, B, H, W) + static_cast<int64_t>(b) * nblk * kListHdrInts;
-        const int4 *lr = ctx_list_rec(ctx, B, H, W) + static_cast<int64_t>(b) * nblk * list_cap(TH);
-        if (tid < 4) red[2][tid] = tid == 3 && !use_lists ? 1 : 0;
-        static_assert((NP * PS) % 2 == 0, "accumulators are zeroed 16 bytes at a time");
-        if (use_lists)   // (the scan path borrows this LDS for its list first and zeroes it later)
-            for (int i = tid; i < NP * PS / 2; i += 256) reinterpret_cast<int4 *>(acc)[i] = make_int4(0, 0, 0, 0);
-        __syncthreads();
-        for (int f = tid; f < (use_lists ? nblk : 0); f += 256) {
-            const int4 *hp = reinterpret_cast<const int4 *>(lh + f * kListHdrInts);
-            const int4 h0 = hp[0], h1 = hp[1], h2 = hp[2], h3 = hp[3];
-            const int kx = tx - h0.y, ky = ty - h0.z;
-            if (h0.x != (kListMagic | TH) || h0.w != 0) {
-                atomicOr(&red[2][3], 1);
-            } else if (kx >= 0 && kx <= 2 && ky >= 0 && ky <= 2) {
-                const int k = ky * 3 + kx;
-                const int c[9] = {h1.z, h1.w, h2.x, h2.y, h2.z, h2.w, h3.x, h3.y, h3.z};
-                int cnt = 0, before = 0;
-#pragma unroll
-                for (int q = 0; q < 9; ++q) {
-                    before += q < k ? c[q] : 0;
-                    cnt = q == k ? c[q] : cnt;
-                }
-                if (cnt > 0) {
-                    const int nch = (cnt + kChunk - 1) / kChunk;
-                    atomicAdd(&red[2][0], 1);
-                    const int start = atomicAdd(&red[2][1], nch);  // in chunks
-                    atomicAdd(&red[2][2], (h1.x >> 8) + 1);        // 24.8, rounded up: 32 blocks of 2048 sources fit
-                    for (int q = 0; q < nch && start + q < kMaxChunks; ++q)
-                        chunks[start + q] = make_int2(f * list_cap(TH) + before + q * kChunk, min(kChunk, cnt - q * kChunk));
-                }
-            }
-        }
-        __syncthreads();
-        const int nseg = red[2][0], nchunks = red[2][1], dsum = red[2][2], bad = red[2][3];
-        const int count = nchunks * kChunk;                        // list positions, padding included
-        if (!bad && nseg <= kMaxSeg && nchunks <= kMaxChunks) {
-            CERB_STAMP_AT(1);
-            Src src[NS];
-            float g[NS][CW];
-            const int ns = (count + 255) / 256;   // sources per thread actually present
-#pragma unroll
-            for (int j = 0; j < NS; ++j) {
-                const int e = j * 256 + tid;
-                const int2 ch = chunks[min(e / kChunk, kMaxChunks - 1)];
-                const bool have = e < count && (e % kChunk) < ch.y;
-                const int4 v = lr[have ? ch.x + e % kChunk : 0];
-                src[j].pv = have ? v.x : 0;
-                src[j].o = have ? v.y : -1;
-                src[j].fx = __int_as_float(v.z);
-                src[j].fy = __int_as_float(v.w);
-            }
-            CERB_STAMP_AT(2);
-#pragma unroll
-            for (int j = 0; j < NS; ++j)
-                if (j < ns) load_g(src[j], c_begin, g[j]);
-            CERB_STAMP_AT(3);
-            CERB_STAMP_AT(4);
-            // 2^S >= the tile's largest tap density (16.16 sums of the contributing blocks' bounds)
-            const int sbits = max(0, 32 - __clz(max(dsum, 1)) - 8);
-            for (int c0 = c_begin; c0 < c_end; c0 += CW) {
-                const int cw = min(CW, c_end - c0);
-                int gb = 0;
-#pragma unroll
-                for (int j = 0; j < NS; ++j)
-                    if (j < ns) gb = absmax_bits(src[j], g[j], gb);
-                float scale, unscale;
-                bool nonfinite;
-                block_scale(gb, false, sbits, scale, unscale, nonfinite);   // (its barriers: accumulators zeroed)
-                if (c0 == c_begin) CERB_STAMP_AT(5);
-#pragma unroll
-                for (int j = 0; j < NS; ++j)
-                    if (j < ns) add_taps(src[j], g[j], cw, scale, nonfinite);
-                if (c0 == c_begin) CERB_STAMP_AT(6);
-                if (c0 + CW < c_end) {   // the next group's gradOutput travels while this group's tile is written out
-#pragma unroll
-                    for (int j = 0; j < NS; ++j)
-                        if (j < ns) load_g(src[j], c0 + CW, g[j]);
-                }
-                __syncthreads();   // every tap of the group has been added
-                if (c0 == c_begin) CERB_STAMP_AT(7);
-                write_out(c0, cw, unscale, nonfinite);
-                if (c0 == c_begin) CERB_STAMP_AT(8);
-            }
-            CERB_STAMP_AT(9);
-            return;
-        }
-        __syncthreads();   // red[] is reused by the scan
-    }
-
-    // ---- scan region ----
-    // The context holds one signed tap-displacement range per 64-pixel strip.  A strip
-    // matters to this tile only if its pixels displaced by its OWN range can reach the tile;
-    // the region is the bounding box of those strips clipped to the tile displaced by the
-    // union of their ranges.  A fast object therefore widens only the tiles it feeds: there
-    // is no global limit and no fallback.
-    int rx0 = kExtEmptyLo, rx1 = kExtEmptyHi, ry0 = kExtEmptyLo, ry1 = kExtEmptyHi;
-    int dxl = kExtEmptyLo, dxh = kExtEmptyHi, dyl = kExtEmptyLo, dyh = kExtEmptyHi;
-    {
-        const int4 *ext = static_cast<const int4 *>(ctx);
-        const Strips strips(H, W);
-        const int spp = strips.per_image();
-        // strip j = tid + 256 k as (jy, jx), advanced without divisions in the loop
-        int jy = tid / strips.nx, jx = tid % strips.nx;
-        const int qy = 256 / strips.nx, qx = 256 % strips.nx;
-        for (int j = tid; j < spp; j += 256) {
-            const int slot = b * spp + j;
-            const int4 e = ext[slot];
-            const int sy0 = jy * kStripH, sy1 = min(sy0 + kStripH, H) - 1;
-            const int sx0 = jx * kStripW, sx1 = min(sx0 + kStripW, W) - 1;
-            const bool hit = e.x <= e.y && sx0 + e.x <= tx1 && sx1 + e.y >= tx0 &&
-                             sy0 + e.z <= ty1 && sy1 + e.w >= ty0;
-            if (hit) {
-                rx0 = min(rx0, sx0); rx1 = max(rx1, sx1);
-                ry0 = min(ry0, sy0); ry1 = max(ry1, sy1);
-                dxl = min(dxl, e.x); dxh = max(dxh, e.y);
-                dyl = min(dyl, e.z); dyh = max(dyh, e.w);
-            }
-            jx += qx; jy += qy;
-            if (jx >= strips.nx) { jx -= strips.nx; ++jy; }
-        }
-    }
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
-        rx0 = min(rx0, __shfl_xor(rx0, m, 64)); rx1 = max(rx1, __shfl_xor(rx1, m, 64));
-        ry0 = min(ry0, __shfl_xor(ry0, m, 64)); ry1 = max(ry1, __shfl_xor(ry1, m, 64));
-        dxl = min(dxl, __shfl_xor(dxl, m, 64)); dxh = max(dxh, __shfl_xor(dxh, m, 64));
-        dyl = min(dyl, __shfl_xor(dyl, m, 64)); dyh = max(dyh, __shfl_xor(dyh, m, 64));
-    }
-    // (folding the boxes with LDS min/max atomics instead of shuffles: 64 lanes on 8 addresses
-    // serialise -- 19k instead of 5k cycles for this phase, measured)
-    if (lane == 0) {
-        red[wave][0] = rx0; red[wave][1] = rx1; red[wave][2] = ry0; red[wave][3] = ry1;
-        red[wave][4] = dxl; red[wave][5] = dxh; red[wave][6] = dyl; red[wave][7] = dyh;
-    }
-    __syncthreads();
-    rx0 = min(min(red[0][0], red[1][0]), min(red[2][0], red[3][0]));
-    rx1 = max(max(red[0][1], red[1][1]), max(red[2][1], red[3][1]));
-    ry0 = min(min(red[0][2], red[1][2]), min(red[2][2], red[3][2]));
-    ry1 = max(max(red[0][3], red[1][3]), max(red[2][3], red[3][3]));
-    dxl = min(min(red[0][4], red[1][4]), min(red[2][4], red[3][4]));
-    dxh = max(max(red[0][5], red[1][5]), max(red[2][5], red[3][5]));
-    dyl = min(min(red[0][6], red[1][6]), min(red[2][6], red[3][6]));
-    dyh = max(max(red[0][7], red[1][7]), max(red[2][7], red[3][7]));
-    if (rx0 <= rx1) {   // at least one strip reaches the tile (ranges are small ints here)
-        xs = max(rx0, tx0 - dxh);
-        ys = max(ry0, ty0 - dyh);
-        rw = max(min(rx1, tx1 - dxl) + 1 - xs, 0);
-        n = rw * max(min(ry1, ty1 - dyl) + 1 - ys, 0);
-        rw = max(rw, 1);
-    }
-    __syncthreads();    // red[] is reused below
-    CERB_STAMP_AT(1);
-
     // ---- region scan: the sources that touch the tile, compacted ----
     // The region is walked ONCE per workgroup, in batches with all position loads in flight;
     // the sources whose taps touch the tile (under a rough flow half of the region misses it)
@@ -1643,6 +1283,7 @@ __global__ __launch_bounds__(256, 4) void warp_bwd_tile_kernel(
     // every thread keeps its NS sources in registers for all channel groups, so a group is
     // one set of gradOutput loads, one block reduction, the adds and the write-out.  The
     // list order depends on the waves' arrival order; the sums do not (integer adds commute).
+    constexpr int kCap = (NP * PS * 8) / 16 < 256 * NS ? (NP * PS * 8) / 16 : 256 * NS;
     int4 *list = reinterpret_cast<int4 *>(acc);
     if (tid == 0) red[1][1] = 0;
     __syncthreads();
@@ -1862,9 +1503,6 @@ int warp_forward(const void *image, const void *flow, void *out, void *ctx, int6
     const int64_t nstrips = static_cast<int64_t>(B) * Strips(H, W).per_image();
     if (nstrips > 0x7fffffff) return CERB_ETOOLARGE;
     const int staged_opt = option(OPT_WARP_STAGED);
-    // with a context: the leading workgroups of the launch build the backward's source lists
-    const int list_th = tile_rows(B, H, W);
-    const int nrole = ctx && interp == CERB_INTERP_BILINEAR ? list_role_blocks(B, H, W, list_th) : 0;
     // LDS-staged window: bilinear, 16-byte-aligned rows, 32-bit byte offsets.  Channels per
     // workgroup: as few as keep the launch at <= 1024 workgroups (the per-workgroup box
     // reduction and window set-up amortise over the channels), between 8 and 32.  Measured, 4
@@ -1883,27 +1521,26 @@ int warp_forward(const void *image, const void *flow, void *out, void *ctx, int6
         crange = std::max(1, std::min(C, crange));
         const int nrange = (C + crange - 1) / crange;
         const int64_t blocks = static_cast<int64_t>(B) * ((strips.ny + kStageRows - 1) / kStageRows) *
-                               strips.nx * nrange + nrole;
+                               strips.nx * nrange;
         if (blocks > 0x7fffffff) return CERB_ETOOLARGE;
         CERB_DISPATCH2(dtype, flow_dtype, if constexpr (!std::is_same<T, double>::value)
             hipLaunchKernelGGL((warp_fwd_staged_kernel<T, F>), dim3(static_cast<unsigned>(blocks)),
                                dim3(256), 0, s, static_cast<const T *>(image),
                                static_cast<const F *>(flow), static_cast<T *>(out), ctx, B, C, H, W,
-                               pad_mode, crange, nrange, nrole, list_th))
+                               pad_mode, crange, nrange))
         return launch_status();
     }
-    if (nstrips + nrole > 0x7fffffff) return CERB_ETOOLARGE;
-    const dim3 grid(static_cast<unsigned>(nstrips + nrole));
+    const dim3 grid(static_cast<unsigned>(nstrips));
     if (option(OPT_WARP_PAIR_TAPS) != 2) {  // default: paired taps in the forward gather
         CERB_PICK_CG(C, CERB_DISPATCH2(dtype, flow_dtype, hipLaunchKernelGGL(
             (warp_fwd_kernel<T, F, true, CG>), grid, dim3(kPix * CG), 0, s,
             static_cast<const T *>(image), static_cast<const F *>(flow), static_cast<T *>(out), ctx,
-            B, C, H, W, pad_mode, interp, nrole, list_th)))
+            B, C, H, W, pad_mode, interp)))
     } else {
         CERB_PICK_CG(C, CERB_DISPATCH2(dtype, flow_dtype, hipLaunchKernelGGL(
             (warp_fwd_kernel<T, F, false, CG>), grid, dim3(kPix * CG), 0, s,
             static_cast<const T *>(image), static_cast<const F *>(flow), static_cast<T *>(out), ctx,
-            B, C, H, W, pad_mode, interp, nrole, list_th)))
+            B, C, H, W, pad_mode, interp)))
     }
     return launch_status();
 }
@@ -1944,8 +1581,7 @@ static int launch_tiles(const void *image, const void *gout, const void *ctx, vo
                        static_cast<const T *>(image), static_cast<const T *>(gout), ctx,
                        static_cast<T *>(gimage), static_cast<F *>(gflow), B,
                        C, H, W, tiles_x, tiles_y, nrange, crange, static_cast<int>(tile_blocks),
-                       pad_mode, flow_staged ? 1 : 0, flow_sub,
-                       (option(OPT_WARP_NO_LISTS) & 1 ? 0 : 1) | (option(OPT_WARP_NO_LISTS) & 2));
+                       pad_mode, flow_staged ? 1 : 0, flow_sub);
     return launch_status();
 }
 
@@ -1978,24 +1614,23 @@ int warp_backward(const void *image, const void *flow, const void *gout, void *g
         if (!ctx) {
             // no forward context: positions + tap ranges from the flow (one extra launch)
             void *own = static_cast<char *>(workspace) + 16;
-            const int cth = tile_rows(B, H, W);
-            const int crole = list_role_blocks(B, H, W, cth);
-            const dim3 cgrid(static_cast<unsigned>(crole + (ctx_partials(B, H, W) + 3) / 4));
             if (flow_dtype == CERB_F32)
-                hipLaunchKernelGGL(warp_context_kernel<float>, cgrid, dim3(256), 0, s,
-                                   static_cast<const float *>(flow), own, B, H, W, pad_mode, crole, cth);
+                hipLaunchKernelGGL(warp_context_kernel<float>, dim3(ctx_partials(B, H, W)), dim3(kPix),
+                                   0, s, static_cast<const float *>(flow), own, B, H, W, pad_mode);
             else if (flow_dtype == CERB_F16)
-                hipLaunchKernelGGL(warp_context_kernel<__half>, cgrid, dim3(256), 0, s,
-                                   static_cast<const __half *>(flow), own, B, H, W, pad_mode, crole, cth);
+                hipLaunchKernelGGL(warp_context_kernel<__half>, dim3(ctx_partials(B, H, W)), dim3(kPix),
+                                   0, s, static_cast<const __half *>(flow), own, B, H, W, pad_mode);
             else
-                hipLaunchKernelGGL(warp_context_kernel<hip_bfloat16>, cgrid, dim3(256), 0, s,
-                                   static_cast<const hip_bfloat16 *>(flow), own, B, H, W, pad_mode, crole, cth);
+                hipLaunchKernelGGL(warp_context_kernel<hip_bfloat16>, dim3(ctx_partials(B, H, W)),
+                                   dim3(kPix), 0, s, static_cast<const hip_bfloat16 *>(flow), own, B,
+                                   H, W, pad_mode);
             if ((rc = launch_status())) return rc;
             ctx = own;
         }
         // ONE launch: grad_image tiles + grad_flow strips.  Tile height: 16 rows, 8 on small
         // maps (twice the workgroups, a smaller region per workgroup).
-        const bool th8 = tile_rows(B, H, W) == 8;
+        const int th_opt = option(OPT_WARP_TILE_H);
+        const bool th8 = th_opt ? th_opt == 8 : static_cast<int64_t>(B) * H * W <= 64 * 128 * 4;
         if (th8) {
             CERB_DISPATCH2(dtype, flow_dtype, if constexpr (!std::is_same<T, double>::value)
                 return (launch_tiles<T, F, 8, 5>(image, gout, ctx, gimage, gflow, B, C, H, W, pad_mode, s)))

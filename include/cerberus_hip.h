@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define CERBERUS_HIP_ABI_VERSION 5   /* 5: the warp context also holds the backward's per-tile source lists (larger: ask cerberus_flow_warp_context_bytes); cerberus_last_kernel is process-wide */
+#define CERBERUS_HIP_ABI_VERSION 5   /* 5: cerberus_last_kernel is process-wide (it was per thread) */
 
 /* element types (AT_DISPATCH_FLOATING_TYPES_AND_HALF in the reference,
  * correlation_cuda_kernel.cu:269,303; bf16 is an extension) */
@@ -119,18 +119,10 @@ int cerberus_flow_warp_forward(const void *image, const void *flow, void *out,
                                int interp_mode, int dtype, void *stream);
 
 /* The same forward, additionally saving what the backward needs again (what autograd's
- * save_for_backward is to the reference's grid_sample): every pixel's sample position, per
- * 64-pixel strip the signed range of tap displacements and -- ABI 5 -- the backward's SOURCE LISTS:
- * for every 16 x 64 (8 x 64 on small maps) block of pixels, the pixels sorted by the grad_image
- * tile their taps land in, with their offsets in the tile and tap fractions, plus a bound on the
- * tile's tap density (everything the tiled backward would otherwise re-derive from the positions
- * on every call and for every channel range; built by extra workgroups of the same launch).
+ * save_for_backward is to the reference's grid_sample): every pixel's sample position and,
+ * per 64-pixel strip, the signed range of tap displacements.
  *   context    : caller-owned device buffer of cerberus_flow_warp_context_bytes(B,H,W) bytes
- *                (16-byte aligned, contents irrelevant; the backward reads only what the forward
- *                wrote); NULL = plain forward.  Size: 16 bytes per 2 x 32 pixel strip + 8 bytes per
- *                pixel (positions) + 64 bytes per 8 x 64 block + 32 bytes per pixel of the image
- *                padded to whole blocks (lists) = about 41 bytes per pixel of ONE channel plane,
- *                i.e. 1.3 x the fp32 image at 32 channels.
+ *                (16-byte aligned, contents irrelevant, fully written); NULL = plain forward.
  *                The layout is private to the library (an opaque blob between the two calls).
  *   flow_dtype : element type of `flow`: equal to `dtype`, or CERB_F32 with a 16-bit image
  *                (under autocast the reference's grid_sample runs in fp32 on whatever
@@ -222,10 +214,6 @@ int cerberus_area_resize(const void *src, void *dst, int64_t planes, int H, int 
  *                          window on large maps with 16-byte aligned rows), 2 = always gather
  *                          from global memory, >= 4 = always staged where possible, with that
  *                          many channels per workgroup
- *   "warp_no_lists"      : 1 = the tiled warp backward ignores the source lists of the context and
- *                          derives each tile's sources from the positions (the pre-ABI-5 path; it is
- *                          also what runs when a block of the lists is flagged: taps of one 16 x 64
- *                          block spread over more than 3 x 3 tiles, i.e. a diverged flow)
  * Returns CERB_EINVAL for an unknown key. */
 int cerberus_set_option(const char *key, int value);
 int cerberus_get_option(const char *key, int *value);

@@ -26,19 +26,8 @@ lib = _lib.get()
 buf = np.zeros((64, 16), dtype=np.uint64)
 rc = lib.cerberus_debug_stamps(buf.ctypes.data_as(ctypes.c_void_p), buf.nbytes)
 assert rc == 0, rc
-for name in os.environ.get("CERB_OPT", "").split(","):
-    if name:
-        k_, _, v_ = name.partition("=")
-        _lib.set_option(k_, int(v_ or 1))
-        for _ in range(3):
-            ops.flow_warp_backward_ctx(img, fl, ctx, go, 1, 0, True, True)
-        torch.cuda.synchronize()
-        rc = lib.cerberus_debug_stamps(buf.ctypes.data_as(ctypes.c_void_p), buf.nbytes)
-lists = "warp_no_lists" not in os.environ.get("CERB_OPT", "")
-names = (["headers+segments", "records", "zero+issue g", "-", "wait g+max+scale", "adds", "barrier", "write-out",
-          "rest (other groups)"] if lists else
-         ["strip scan", "region scan+compact", "deal+zero+load g", "density", "max+scale", "adds",
-          "barrier", "write-out", "rest (other groups)"])
+names = ["strip scan", "region scan+compact", "deal+zero+load g", "density", "max+scale", "adds",
+         "barrier", "write-out", "rest (other groups)"]
 d = np.diff(buf[:, :10].astype(np.int64), axis=1)
 t0 = buf[:, 0].astype(np.int64)
 print("start skew of the 64 workgroups (cycles): min %d max %d" % (0, int(t0.max() - t0.min())))
