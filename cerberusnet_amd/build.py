@@ -63,7 +63,28 @@ def build(force: bool = False, verbose: bool = False, extra_flags=()):
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
+    build_runtime(force or any(changed for _, changed in results), verbose)
     return LIB
+
+
+RUNTIME_DIR = os.path.join(HERE, "runtime")
+RUNTIME_BIN = os.path.join(LIBDIR, "cerberus_run")
+
+
+def build_runtime(force: bool = False, verbose: bool = False):
+    """The torch-free C++ inference host (runtime/cerberus_run.cpp over runtime/cerberus_runtime.hpp): plain
+    host code against the HIP runtime and the C ABI of libcerberus_hip.so, found at run time through
+    $ORIGIN (the binary sits beside the library)."""
+    srcs = [os.path.join(RUNTIME_DIR, f) for f in ("cerberus_run.cpp", "cerberus_runtime.hpp")]
+    newest = max([os.path.getmtime(p) for p in srcs] + [_deps()])
+    if not force and os.path.exists(RUNTIME_BIN) and os.path.getmtime(RUNTIME_BIN) >= newest:
+        return RUNTIME_BIN
+    cmd = [_hipcc(), "-O2", "-std=c++17", "-Wall", srcs[0], "-o", RUNTIME_BIN, "-L", LIBDIR, "-lcerberus_hip",
+           "-Wl,-rpath,$ORIGIN"]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    return RUNTIME_BIN
 
 
 if __name__ == "__main__":
