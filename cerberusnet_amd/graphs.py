@@ -15,7 +15,26 @@ from typing import Callable, List, Optional, Sequence
 
 import torch
 
-__all__ = ["GraphedFlowStep", "GraphedFlowInference"]
+__all__ = ["GraphedFlowStep", "GraphedFlowInference", "graph_safe_mean", "graph_safe_sum"]
+
+
+def graph_safe_sum(t: torch.Tensor, block: int = 4096) -> torch.Tensor:
+    """``t.sum()`` as two block-level reductions (rows of ``block`` elements, then the row sums): no launch of
+    ATen's multi-block reduction, whose scratch buffer + semaphores are what goes wrong inside a replayed
+    hipGraph (see :class:`GraphedFlowStep`).  Differentiable; same value up to fp32 summation order."""
+    flat = t.reshape(-1)
+    n = flat.numel()
+    if n <= block:
+        return flat.sum()
+    pad = (-n) % block
+    if pad:
+        flat = torch.nn.functional.pad(flat, (0, pad))
+    return flat.reshape(-1, block).sum(1).sum()
+
+
+def graph_safe_mean(t: torch.Tensor, block: int = 4096) -> torch.Tensor:
+    """``t.mean()`` built on :func:`graph_safe_sum`."""
+    return graph_safe_sum(t, block) / t.numel()
 
 
 class GraphedFlowStep:
@@ -28,19 +47,25 @@ class GraphedFlowStep:
     graph is replayed, and the (static) loss tensor and flow lists are returned -- clone them
     if they must survive the next call.  Parameter ``.grad`` tensors are static too.
 
-    The returned loss is NOT the scalar the graph computed: with whole-tensor reductions inside
-    ``loss_fn`` -- e.g. ``f.abs().mean()`` over a full-resolution flow, which is what the UnFlow
-    terms are -- the captured scalar came back WRONG (10.48 expected; 8.06, 13.70, 5.64 ... seen)
-    once eager GPU work ran between replays, while every flow and every gradient of the same
-    replay stayed bit-exact (ROCm 7.2 / torch 2.10, ``tools/diag_graph_order.py``).  It is not
-    this package's kernels: the same happens with the head on STOCK PyTorch ops only
-    (``correlation_backend="torch"``: ``CorrelationTorch`` + ``F.grid_sample`` + MIOpen, run
-    ``tools/diag_graph_order.py torch``), with and without the fused concat / LeakyReLU /
-    upsample ops; a small stand-alone graph of reductions + a convolution + backward
-    (``tools/diag_graph_mean.py``) does NOT show it, so the trigger is somewhere in PyTorch's
-    handling of the larger captured step and is left there.  ``__call__`` evaluates ``loss_fn``
-    again, eagerly and without autograd, on the flows the replay wrote (exact: tests); the
-    captured scalar stays readable as ``captured_loss`` and an xfail test keeps it visible.
+    By default the returned loss is NOT the scalar the graph computed.  With whole-tensor reductions
+    inside ``loss_fn`` -- ``f.abs().mean()`` over a full-resolution flow, which is what the UnFlow terms
+    are -- the captured scalar comes back WRONG once an eager forward + backward of the head ran between
+    replays, while every flow and every gradient of the same replay stays bit-exact (ROCm 7.2 / torch
+    2.10).  Round 4 localised it (``tools/diag_graph_loss.py``, ``profiles/r04_graph_loss_defect.txt``):
+    with every term of the loss kept alive as a graph output, exactly ONE term is wrong -- the
+    ``.mean()`` of one 131 072-element flow, 26 344 instead of 1.3 -- the python ``sum`` and a
+    ``torch.stack(...).sum()`` of the captured terms are consistent with that wrong term, and the
+    row-wise means (``reshape(-1, 4096).mean(1)``) of the SAME tensor in the SAME replay are right: it is
+    ATen's multi-block reduction (``global_reduce``: per-launch scratch buffer + semaphores zeroed by a
+    captured memset) that returns garbage, not the whole-step capture, not the allocator's handling of
+    freed partial sums, and not this package's kernels (the head on stock PyTorch ops only shows the same
+    term going wrong; eager reductions or eager allocations alone between replays do not trigger it; the
+    graph-pool addresses of the scalars are disjoint).  A loss built from block-level reductions
+    (:func:`graph_safe_mean`) is exact in every replay, with the same interleaved eager steps.
+    So: ``__call__`` evaluates ``loss_fn`` again, eagerly and without autograd, on the flows the replay
+    wrote (exact: tests), unless ``trust_captured_loss=True`` says that ``loss_fn`` only uses block-level
+    reductions; the captured scalar stays readable as ``captured_loss`` either way, and an xfail test keeps
+    the plain-``mean`` defect visible.  ``loss_fn`` must be a pure function of the flows.
 
     The optimizer, if given, must be graph-capturable (e.g. ``torch.optim.Adam(...,
     capturable=True)``).  ``bidirectional=False`` captures the forward direction only.
@@ -49,12 +74,13 @@ class GraphedFlowStep:
     def __init__(self, head: torch.nn.Module, loss_fn: Callable[[List[torch.Tensor]], torch.Tensor],
                  pyr1: Sequence[torch.Tensor], pyr2: Sequence[torch.Tensor],
                  optimizer: Optional[torch.optim.Optimizer] = None, bidirectional: bool = True,
-                 input_grads: bool = False, warmup: int = 3):
+                 input_grads: bool = False, warmup: int = 3, trust_captured_loss: bool = False):
         if not pyr1[0].is_cuda:
             raise RuntimeError("GraphedFlowStep needs the pyramids on the GPU (there is no CPU "
                                "path for the HIP ops)")
         self.head, self.loss_fn, self.optimizer = head, loss_fn, optimizer
         self.bidirectional, self.input_grads = bidirectional, input_grads
+        self.trust_captured_loss = trust_captured_loss
         self.static1 = [t.detach().clone().requires_grad_(input_grads) for t in pyr1]
         self.static2 = [t.detach().clone().requires_grad_(input_grads) for t in pyr2]
         self.params = [p for p in head.parameters() if p.requires_grad]
@@ -119,8 +145,11 @@ class GraphedFlowStep:
         # The loss is re-evaluated EAGERLY on the flows the replay has just written (a few tiny
         # kernels) instead of trusting the captured scalar: see the class docstring.  The
         # captured one stays available as ``captured_loss``.
-        with torch.no_grad():
-            self.loss = self.loss_fn(list(self.flows_fw) + list(self.flows_bw))
+        if self.trust_captured_loss:
+            self.loss = self.captured_loss
+        else:
+            with torch.no_grad():
+                self.loss = self.loss_fn(list(self.flows_fw) + list(self.flows_bw))
         return self.loss, self.flows_fw, self.flows_bw
 
     def input_gradients(self):

@@ -79,3 +79,17 @@ def test_forward_both_equals_the_two_separate_calls_on_cpu(golden):
     for a, b in zip(fw + bw, list(fw2) + list(bw2)):
         assert a.shape == b.shape
         assert rel_err(a.numpy(), b.numpy()) < 1e-5
+
+
+def test_graph_safe_reductions_equal_the_plain_ones():
+    """graphs.graph_safe_sum / graph_safe_mean (block-level reductions for losses computed inside a replayed
+    hipGraph): values and gradients of sum / mean, ragged sizes included."""
+    from cerberusnet_amd.graphs import graph_safe_mean, graph_safe_sum
+    for n in (1, 17, 4096, 4097, 3 * 4096 + 5, 2 * 2 * 64 * 128):
+        x = torch.randn(n, dtype=torch.float64, requires_grad=True)
+        y = x.detach().clone().requires_grad_(True)
+        a, b = graph_safe_sum(x * x), (y * y).sum()
+        assert torch.allclose(a, b, rtol=1e-12)
+        a.backward(); b.backward()
+        assert torch.allclose(x.grad, y.grad, rtol=1e-12)
+        assert torch.allclose(graph_safe_mean(x.detach()), y.detach().mean(), rtol=1e-12)

@@ -202,6 +202,35 @@ def test_graphed_flow_step_returns_the_right_loss_for_a_plain_mean():
         torch.backends.cudnn.deterministic = det
 
 
+def test_graphed_flow_step_captured_loss_is_exact_with_block_level_reductions():
+    """Round 4: the defect is ATen's multi-block reduction inside the replayed graph, not the capture
+    (tools/diag_graph_loss.py).  With the loss built from block-level reductions (graph_safe_mean) the scalar
+    the GRAPH computed is the eager step's, bit for bit up to the summation order of the two forms, for new
+    inputs and with eager head passes interleaved -- and trust_captured_loss=True returns it without the
+    eager re-evaluation."""
+    from cerberusnet_amd.graphs import GraphedFlowStep, graph_safe_mean
+    det = torch.backends.cudnn.deterministic
+    torch.backends.cudnn.deterministic = True
+    try:
+        torch.manual_seed(5)
+        head = build("FlowEstimatorLite").to(DEV)
+        shapes = [(2, c, 8 * 2 ** l, 16 * 2 ** l) for l, c in enumerate(reversed(CHANS))]
+        mk = lambda: [torch.randn(s, device=DEV) for s in shapes]
+        loss_fn = lambda flows: sum(graph_safe_mean(f.abs()) for f in flows)
+        step = GraphedFlowStep(head, loss_fn, mk(), mk(), trust_captured_loss=True)
+        for _ in range(5):
+            p1, p2 = mk(), mk()
+            loss, _, _ = step(p1, p2)
+            assert loss is step.captured_loss
+            got = loss.detach().clone()
+            want = _eager_loss(head, loss_fn, p1, p2)     # also the interleaved eager work
+            assert torch.equal(got, want), (float(got), float(want))
+            plain = _eager_loss(head, lambda flows: sum(f.abs().mean() for f in flows), p1, p2)
+            assert abs(float(got) - float(plain)) <= 1e-5 * abs(float(plain))
+    finally:
+        torch.backends.cudnn.deterministic = det
+
+
 @pytest.mark.xfail(strict=False, reason="the loss scalar computed INSIDE the replayed graph comes back wrong "
                    "after interleaved eager work -- also with the head on stock PyTorch ops only "
                    "(tools/diag_graph_order.py torch), so not this package's kernels; GraphedFlowStep does not return it")
