@@ -631,7 +631,9 @@ def head_step_mode(args, device, rank, world, dist):
             gstep.graph.replay()
         torch.cuda.synchronize()
         g = (time.perf_counter() - t0) / args.steps
-        result["hipgraph_replay"] = {"ms_per_step": round(1e3 * g, 4), "pairs_per_s": round(B / g, 2)}
+        result["hipgraph_replay"] = {"ms_per_step": round(1e3 * g, 4), "pairs_per_s": round(B / g, 2),
+                                     "what": "graph replay only: GraphedFlowStep.__call__ adds the copy of the inputs and, unless "
+                                             "trust_captured_loss, the eager re-evaluation of the loss on the replayed flows"}
     print(json.dumps(result), flush=True)
 
 

@@ -2188,7 +2188,7 @@ int bwd_dispatch(const void *x1, const void *x2, const void *go, void *g1, void 
         // dispatch without it.
         const int v = option(OPT_CORR_BWD_VARIANT);
         const int64_t coarse_wgs = static_cast<int64_t>(g.B) * 2 * g.H * (g.C / (g.W == 64 ? 16 : 32));
-        if (vec && dma_ok(g) && (v == 14 || (v == 0 && g.W <= 64 && coarse_wgs <= 4096))) {
+        if (vec && dma_ok(g) && (v == 14 || ((v == 0 || v == 13) && g.W <= 64 && coarse_wgs <= 4096))) {   // 13 = auto, minus the strip kernel on 64-wide maps
             const int rc = corr_coarse_backward(x1, x2, go, g1, g2, g, s);
             if (rc != CERB_EUNSUPPORTED) return rc;
         }

@@ -186,10 +186,10 @@ int cerberus_area_resize(const void *src, void *dst, int64_t planes, int H, int 
  *   "corr_fwd_variant"   : 0 = auto, 1..8 = force one register-staged forward variant,
  *                          9..13 = the LDS-DMA variants (fp32, W % 4 == 0) with 1, 2, 4, 8,
  *                          16 channel groups, 14 = the matrix-core kernel (fp16 / bf16 storage,
- *                          C <= 64; auto uses it for 16 < C <= 64), 15 = the coarse-level kernel (fp32,
- *                          W = 16 / 32 / 64 and a channel count its lane layout divides: corr_coarse.hip;
- *                          auto uses it there up to 2560 (row, displacement row) workgroups), 16 = auto
- *                          without it
+ *                          C <= 64; auto uses it for 16 < C <= 64), 15 = the coarse-level kernel (fp32, and
+ *                          fp16 / bf16 storage with C > 64; W = 16 / 32 / 64 and a channel count its lane
+ *                          layout divides: corr_coarse.hip; auto uses it there up to 2560 (row, displacement
+ *                          row) workgroups), 16 = auto without it
  *   "corr_bwd_variant"   : 0 = auto, 1 = all 81 displacements per lane (register-staged),
  *                          3 = three displacement groups, 4 / 5 = LDS-DMA with the 8x64 /
  *                          16x32 tile (fp32, W % 4 == 0), 8 = displacement-row streaming,
@@ -201,6 +201,14 @@ int cerberus_area_resize(const void *src, void *dst, int64_t planes, int H, int 
  *                          it; 2, 6, 7, 9, 10 (and forward
  *                          1, 2, 8) are measured-and-rejected variants that exist only in
  *                          -DCERB_EXPERIMENTS test builds (otherwise: auto)
+ *                          NOTE on batch invariance: auto picks kernels from WORKGROUP COUNTS (the 2560 /
+ *                          4096 / 192-workgroup thresholds above), which include the batch size, and the
+ *                          kernels differ in summation order: a batch item's correlation values (and
+ *                          forward of a stacked batch vs two separate calls) agree to fp32 rounding
+ *                          (<= 1e-6 relative), not bit for bit, across batch sizes that change the kernel.
+ *                          The warp ops choose from one image's shape only, except the grad_image tile
+ *                          height (8 rows up to 32768 pixels per call, else 16), which moves the
+ *                          fixed-point scale by <= 2^-29 of a tile's largest gradient.
  *   "experiments_build"  : read-only (cerberus_get_option): 1 in a -DCERB_EXPERIMENTS build
  *   "corr_bwd_cslice"    : 0 = auto, else channels per backward workgroup (the matrix-core
  *                          backward reads it as the number of tiles a workgroup walks down)
