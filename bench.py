@@ -1033,8 +1033,9 @@ def main():
         # a constant read from a file, labelled as such -- it is not measured by this run
         traffic, traffic_src = None, None
         cfg_key = (args.width, args.height, args.dtype)
-        tnames = {(1024, 512, "f32"): ("r03_pmc_traffic.json", "r02_pmc_traffic.json"),
-                  (2048, 1024, "f16"): ("r03_config5_f16_pmc_traffic.json", "r02_config5_f16_pmc_traffic.json")}.get(cfg_key, ())
+        tnames = {(1024, 512, "f32"): ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"),
+                  (2048, 1024, "f16"): ("r04_config5_f16_pmc_traffic.json", "r03_config5_f16_pmc_traffic.json",
+                                        "r02_config5_f16_pmc_traffic.json")}.get(cfg_key, ())
         for tname in tnames:
             tpath = os.path.join(REPO, "profiles", tname)
             if os.path.exists(tpath) and args.pairs == 4 and not args.fuse_directions:

@@ -503,7 +503,14 @@ __global__ __launch_bounds__(K::THREADS, 4) void corr_bwd_d4_coarse_kernel(
                     for (int p = 0; p < 4; ++p) acc[i][p] += z[p];
             }
         };
+        // the counted waits below are only right while ONE stage() is exactly NDMA LDS-DMA requests + CPL
+        // 16-byte x loads per wave, all unconditional, and compute() issues no vector-memory operation at all (its
+        // ds_write / ds_read count in lgkmcnt).  Anyone adding a load to stage() or compute(), or a compiler splitting a
+        // b128 load, breaks "vmcnt(PER) = the previous stage has landed": keep PER tied to stage() here, and keep the
+        // non-finite-locality and random-shape sweep tests of tests/test_corr_gpu.py in the default GPU run -- they are the
+        // guard (a wrong count reads rows that have not landed: data-dependent garbage, never a crash).
         constexpr int PER = K::NDMA + CPL;
+        static_assert(PER == K::NDMA + CPL && PER <= 15, "vmcnt immediates of compute(): one stage = NDMA DMAs + CPL loads, < 16 in flight");
         stage(0, 0);
         __builtin_amdgcn_sched_barrier(0);
         stage(1, 1);
