@@ -7,14 +7,15 @@ forward + backward, on the HRNetV2-W32 feature pyramid of a 1024x512 frame pair.
 N > 1: one process per GPU over RCCL.  Under torchrun (RANK / WORLD_SIZE set) the process is
 one rank; launched plainly, the parent starts `python -m torch.distributed.run` with N
 children BEFORE it touches the GPU, relays rank 0's JSON line and exits with their code.
-Every rank owns `--pairs` image pairs (weak scaling); there is no data-path collective in
-the ops: `value` is the op-only rate of the N ranks.  The one exchange of data-parallel training
--- the gradient all-reduce of the MODEL's parameters (137.1 MB fp32 for HRNetV2-W32 + flow head,
-BASELINE.md section 3; the ops themselves have no parameters) -- is a side report
-(`gradient_exchange`): the same loop timed again with a bucketed RCCL all-reduce on a side stream
-beside every step, and the all-reduce alone (bus bandwidth).  A 137 MB all-reduce cannot hide
-behind a 0.35 ms step; `--with-exchange` makes it part of `value` anyway, and `--step head` is the
-mode where the gradients belong to the step that is timed (the flow head under DDP).
+Every rank owns `--pairs` image pairs (weak scaling).  Default step by N:
+  N = 1  --step ops   : the hot-path ops alone (below): the headline, with roofline and cpu_baseline
+  N > 1  --step model : one TRAINING step of the host model (HRNetV2-W32 backbone + PWC flow head, unFlowLoss,
+                        backward, Adam) under DistributedDataParallel over RCCL: 122 MB of gradients all-reduced
+                        inside every step -- the step data-parallel scaling is judged on; read it against
+                        `extra.model_step` of the N = 1 line (the same step on one GPU)
+`--step ops` at N > 1 reports the op-only rate of the N ranks (the ops have no parameters: no collective
+belongs to them) with the model-sized exchange timed beside it as `gradient_exchange`; `--step head` is the
+flow head alone under DDP.
 
 One "step" = the hot path of one training iteration over a batch of `--pairs`
 image pairs (default 4 per GPU, BASELINE config 4's per-GPU batch; the tensors
