@@ -305,6 +305,11 @@ def trace_child(args, device):
     for _ in range(3):
         wl.serial_step()
     torch.cuda.synchronize()
+    if args.no_graph:        # the counter passes: plain launches (counters are collected per dispatch, serialised)
+        for _ in range(args.steps):
+            wl.serial_step()
+        torch.cuda.synchronize()
+        return
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
@@ -397,6 +402,77 @@ def in_step_times(args, nlevels, replays=60):
         return None, repr(exc)[:200]
     finally:
         shutil.rmtree(out, ignore_errors=True)
+
+
+def live_traffic(args, nlevels, steps=4):
+    """HBM-side bytes per launch of every kernel of the step, measured by THIS run: two children replay the
+    step eagerly on one stream under `rocprofv3 --kernel-trace --pmc FETCH_SIZE` and `--pmc WRITE_SIZE`
+    (separate passes: the two do not fit one on gfx950; MI355X_MICROARCH.md, HBM / rocprofv3 PMC slots) and
+    the dispatches are matched to the step's launch order as in in_step_times().  Corrections as that
+    guide prescribes: read bytes = 2 x FETCH_SIZE KiB (gfx950 tallies the 128-byte requests of a wide
+    coalesced stream at 64 bytes; factor 2.000 re-measured for 16- and 4-byte-per-lane streams,
+    profiles/r04_fetch_size_calibration.json), write bytes = WRITE_SIZE KiB.  FETCH_SIZE counts Infinity-Cache
+    hits as traffic.  Returns ({label: {"read_bytes", "write_bytes", "traffic_bytes"}}, info) or (None, reason)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(prof):
+        return None, "rocprofv3 not found"
+    if profiler_in_environment():
+        return None, "already under a profiler"
+    order = step_order(nlevels)
+    per_step = 2 * len(order)
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK",
+                        "LOCAL_WORLD_SIZE", "ROLE_RANK", "ROLE_WORLD_SIZE", "TORCHELASTIC_RUN_ID")
+           and not _is_profiler_variable(k)}
+    env["TMPDIR"] = "/tmp"
+    got = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = tempfile.mkdtemp(prefix="cerb_pmc_", dir="/tmp")
+            try:
+                cmd = [prof, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "--", sys.executable,
+                       os.path.abspath(__file__), "--trace-child", "--no-graph", "--steps", str(steps), "--pairs", str(args.pairs),
+                       "--width", str(args.width), "--height", str(args.height), "--dtype", args.dtype, "--flow", args.flow]
+                if args.no_mfma:
+                    cmd.append("--no-mfma")
+                subprocess.run(cmd, cwd="/tmp", env=env, timeout=300, check=True, stdout=subprocess.DEVNULL,
+                               stderr=subprocess.DEVNULL)
+                paths = glob.glob(out + "/**/*counter_collection.csv", recursive=True)
+                if not paths:
+                    return None, "no counter file written (%s)" % counter
+                rows = []
+                for r in csv.DictReader(open(paths[0])):
+                    n = r["Kernel_Name"]
+                    if r["Counter_Name"] == counter and any(k in n for k in ("corr_fwd", "corr_bwd", "warp_fwd", "warp_bwd")):
+                        rows.append((int(r["Dispatch_Id"]), float(r["Counter_Value"]), n))
+                rows.sort()
+                if len(rows) < steps * per_step or len(rows) % per_step:
+                    return None, "unexpected dispatch count %d in the %s pass" % (len(rows), counter)
+                rows = rows[-steps * per_step:]
+                acc = {k: [] for k in order}
+                for i, (_, val, name) in enumerate(rows):
+                    label = order[(i % per_step) % len(order)]
+                    if label.split("_L")[0] not in name.replace("corr_bwd_d4", "corr_bwd").replace("corr_fwd_d4", "corr_fwd"):
+                        return None, "dispatch order mismatch at %d: %s vs %s" % (i, label, name[:60])
+                    acc[label].append(val)
+                got[counter] = {k: float(np.mean(v)) for k, v in acc.items()}
+            finally:
+                shutil.rmtree(out, ignore_errors=True)
+        res = {}
+        for k in order:
+            rd, wr = 2.0 * got["FETCH_SIZE"][k] * 1024.0, got["WRITE_SIZE"][k] * 1024.0
+            res[k] = {"read_bytes": int(round(rd)), "write_bytes": int(round(wr)), "traffic_bytes": int(round(rd + wr))}
+        return res, {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (two passes) of children of this run replaying "
+                               "the step eagerly on one stream; read = 2 x FETCH_SIZE KiB, write = WRITE_SIZE KiB; "
+                               "Infinity-Cache hits count as traffic",
+                     "launches_per_label": 2 * steps}
+    except Exception as exc:  # the headline must not depend on the profiler
+        return None, repr(exc)[:200]
 
 
 def torch_gpu_reference(wl, budget_s=4.0):
@@ -818,6 +894,9 @@ def main():
                     help="--step head: run both flow directions as one stacked pass (PWCNetHead.forward_both)")
     ap.add_argument("--trace-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-cold", action="store_true", help="skip the cold (HBM-resident inputs) per-kernel pass")
+    ap.add_argument("--no-traffic", action="store_true",
+                    help="skip the two counter passes (FETCH_SIZE / WRITE_SIZE children) behind roofline.traffic; the committed "
+                         "figure of profiles/ is reported instead, labelled as such")
     ap.add_argument("--probe-after", action="store_true",
                     help="run the per-kernel passes after the timed region (the order of rounds 1-3) instead of before it")
     ap.add_argument("--bwd-variant", type=int, default=0, help="experiments: option corr_bwd_variant")
@@ -916,8 +995,9 @@ def main():
     if rank == 0 and not args.probe_after:
         instep, instep_info = ((None, "skipped") if (args.no_cold or args.fuse_directions or args.chains > 1 or world > 1)
                                else in_step_times(args, len(wl.levels)))
+        live, live_info = ((None, "skipped") if instep is None or args.no_traffic else live_traffic(args, len(wl.levels)))
         hot, cold = per_kernel_times(wl, max(2, args.probe_steps), cold=not args.no_cold)
-        probe = (hot, cold, instep, instep_info)
+        probe = (hot, cold, instep, instep_info, live, live_info)
     if graph is not None:
         for _ in range(args.warmup):
             graph.replay()
@@ -1031,8 +1111,9 @@ def main():
             hot, cold = per_kernel_times(wl, max(2, args.probe_steps), cold=not args.no_cold)
             instep, instep_info = ((None, "skipped") if (args.no_cold or args.fuse_directions or args.chains > 1 or world > 1)
                                    else in_step_times(args, len(wl.levels)))
+            live, live_info = ((None, "skipped") if instep is None or args.no_traffic else live_traffic(args, len(wl.levels)))
         else:
-            hot, cold, instep, instep_info = probe
+            hot, cold, instep, instep_info, live, live_info = probe
         # The roofline figures use the IN-STEP launch time (the profiler's kernel durations while the whole
         # step replays on one stream: caches in the state the step leaves them in); "us_hot" (one launch
         # replayed on the same tensors, HIP events: Infinity-Cache resident) and "us_cold" (inputs from
@@ -1051,17 +1132,20 @@ def main():
         top = len(wl.levels) - 1
         fb_t = per["corr_fwd_L%d" % top] + per["corr_bwd_L%d" % top]
         fb_b = kern["corr_fwd_L%d" % top] + kern["corr_bwd_L%d" % top]
-        # HBM-side bytes per launch: from the committed rocprofv3 PMC passes of THIS round's
-        # kernels (tools/collect_profiles.sh: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE);
-        # a constant read from a file, labelled as such -- it is not measured by this run
+        # HBM-side bytes per launch: measured by this run (live_traffic: two counter passes of children); without
+        # a profiler, the committed figure of profiles/ (tools/collect_profiles.sh), labelled as a constant
         traffic, traffic_src = None, None
+        if live is not None:
+            traffic = live[dominant]["traffic_bytes"]
+            traffic_src = dict(live_info, measured_by_this_run=True,
+                               ratio_to_algorithmic=round(traffic / kern[dominant], 3))
         cfg_key = (args.width, args.height, args.dtype)
         tnames = {(1024, 512, "f32"): ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"),
                   (2048, 1024, "f16"): ("r04_config5_f16_pmc_traffic.json", "r03_config5_f16_pmc_traffic.json",
                                         "r02_config5_f16_pmc_traffic.json")}.get(cfg_key, ())
         for tname in tnames:
             tpath = os.path.join(REPO, "profiles", tname)
-            if os.path.exists(tpath) and args.pairs == 4 and not args.fuse_directions:
+            if traffic is None and os.path.exists(tpath) and args.pairs == 4 and not args.fuse_directions:
                 blob = json.load(open(tpath))
                 traffic = blob.get(dominant, {}).get("traffic_bytes")
                 traffic_src = {"file": "profiles/" + tname,
@@ -1094,7 +1178,9 @@ def main():
             "per_kernel": {k: {"us": round(per[k] * 1e6, 2), "us_hot": round(hot[k] * 1e6, 2),
                                "us_cold": round(cold[k] * 1e6, 2) if cold else None,
                                "us_in_step": round(instep[k] * 1e6, 2) if instep else None,
-                               "GBps": round(gbps(k), 1), "frac": round(gbps(k) / HBM_PEAK_GBPS, 4)}
+                               "GBps": round(gbps(k), 1), "frac": round(gbps(k) / HBM_PEAK_GBPS, 4),
+                               "traffic": live[k]["traffic_bytes"] if live else None,
+                               "traffic_over_algorithmic": round(live[k]["traffic_bytes"] / kern[k], 3) if live else None}
                            for k in sorted(per)},
         }
         try:

@@ -58,3 +58,14 @@ def test_in_step_pass_refuses_to_nest_profilers():
         assert times is None and "profiler" in why
     finally:
         del os.environ["ROCP_TOOL_LIBRARIES"]
+
+
+def test_live_traffic_refuses_to_nest_profilers_too():
+    os.environ["ROCP_TOOL_LIBRARIES"] = "x.so"
+    try:
+        class A:
+            pairs, width, height, dtype, flow, no_mfma = 4, 1024, 512, "f32", "smooth", False
+        res, why = bench.live_traffic(A(), 4)
+        assert res is None and "profiler" in why
+    finally:
+        del os.environ["ROCP_TOOL_LIBRARIES"]

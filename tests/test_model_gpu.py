@@ -55,3 +55,21 @@ def test_hip_and_torch_backends_of_the_model_agree_on_the_gpu():
         fb = b(l_img=l_img, l_seq=l_seq)["flow"]
     for x, y in zip(fa, fb):
         assert rel_err(x.cpu().numpy(), y.cpu().numpy()) < 1e-4
+
+
+def test_config2_w18_backbone_bf16_plumbing():
+    """BASELINE config 2 (HRNetV2-W18 + segmentation head, 512x256, bf16): it contains no hot-path op and its
+    OCR head is outside this package's scope -- what IS here, the W18 backbone, runs forward + backward under bf16
+    autocast at the config's frame size and returns the four scales the heads consume, finite."""
+    from cerberusnet_amd.nnet_models import HighResolutionNet, hrnet_config
+    from cerberusnet_amd.nnet_models.hrnetv2 import W18
+    net = HighResolutionNet(**hrnet_config(W18)).to(DEV).train()
+    fill_parameters(net, 300)
+    x = torch.from_numpy(hash_uniform((2, 3, 256, 512), 421, -2.0, 2.0)).to(DEV)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        feats, pyr = net(x)
+    assert feats.shape == (2, sum(W18), 64, 128) and feats.dtype in (torch.bfloat16, torch.float32)   # (autocast: the residual sums promote)
+    assert [tuple(p.shape[1:]) for p in pyr] == [(144, 8, 16), (72, 16, 32), (36, 32, 64), (18, 64, 128)]
+    feats.float().square().mean().backward()
+    assert all(torch.isfinite(p.grad).all() for p in net.parameters() if p.grad is not None)
+    assert sum(p.grad is not None for p in net.parameters()) > 300
