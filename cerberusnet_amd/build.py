@@ -32,7 +32,7 @@ def _hipcc():
 
 
 def _deps():
-    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".inc"))]
     hdrs.append(os.path.join(os.path.dirname(HERE), "include", "cerberus_hip.h"))
     return max(os.path.getmtime(h) for h in hdrs)
 

@@ -1642,177 +1642,6 @@ __global__ __launch_bounds__(K::THREADS, K::WPS) void corr_bwd_d4_rows_kernel(
 #endif
 }
 
-#ifdef CERB_EXPERIMENTS
-// ============================================================================
-// backward, column-walking variant of the displacement-row streaming kernel
-// ============================================================================
-// Every kernel of this file ends up at (bytes moved between L2 and the CUs) / ~5-6 TB/s, halo
-// re-reads included: what is left to gain is traffic.  corr_bwd_d4_rows_kernel
-// re-loads the TH+8 window rows of every 4-row tile (3x the rows) and refills its ring in a
-// lock-step prologue per tile.  Here a workgroup walks DOWN a 64-pixel column of tiles with
-// the WHOLE window (TH+8 rows x 32 channels) resident in a 12-row ring: moving to the next tile
-// costs TH new rows (requested one per step while the current tile computes, into the slot of
-// the row that just retired), gradOutput streams through a ring of 4 buffers three steps
-// ahead of its use (one step ahead exposed the ~2 us DMA latency in every step of the first
-// rows kernel), and there is one prologue per workgroup instead of one per tile.
-// L2<->CU bytes per 4x64 tile and side: 4*9.2 + 9*10.4 = 130 KB (+ the prologue's 110 KB over NT
-// tiles) against 203 KB.  One workgroup (8 waves) per CU: 152 KB of LDS.
-template <int CB_, int NG_>
-struct BwdColCfg : BwdRowsCfg<CB_, NG_> {
-    using Base = BwdRowsCfg<CB_, NG_>;
-    static constexpr int NRING = Base::TH + 2 * kD;       // the whole window of a tile
-    static constexpr int NGB = 4;                         // gradOutput buffers: 3 steps in flight
-    static constexpr int AHEAD = NGB - 1;
-    static constexpr size_t LDS_BYTES = sizeof(float) * (NRING * Base::ROWF + NGB * Base::GBUF);
-    static_assert(LDS_BYTES <= 160 * 1024, "one workgroup per CU");
-};
-
-template <int N> __device__ __forceinline__ void wait_vmcnt_upto(int n) {
-    // s_waitcnt takes an immediate: dispatch a (wave-uniform) runtime count to it
-    if constexpr (N >= 0) {
-        if (n >= N) wait_vmcnt<N>();
-        else wait_vmcnt_upto<N - 1>(n);
-    }
-}
-
-template <typename K>
-__global__ __launch_bounds__(K::THREADS, 2) void corr_bwd_d4_col_kernel(
-    const float *__restrict__ x1, const float *__restrict__ x2, const float *__restrict__ gout,
-    float *__restrict__ gin1, float *__restrict__ gin2, int C, int H, int W, int tiles_x,
-    int tiles_y, int nrange, int ntile, int ngroup) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int kDead = static_cast<int>(0x80000000u);
-    const int tid = threadIdx.x;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    const int r = lane / K::TSX, sx = lane % K::TSX;
-
-    // (column of tiles, group of ntile tiles, channel range, side), side fastest
-    int bid = xcd_chunk(blockIdx.x, gridDim.x);
-    const int side = __builtin_amdgcn_readfirstlane(bid & 1); bid >>= 1;
-    const int range = __builtin_amdgcn_readfirstlane(bid % nrange); bid /= nrange;
-    const int tx = __builtin_amdgcn_readfirstlane(bid % tiles_x); bid /= tiles_x;
-    const int tg = __builtin_amdgcn_readfirstlane(bid % ngroup);
-    const int b = __builtin_amdgcn_readfirstlane(bid / ngroup);
-    const int x0 = tx * K::TW;
-    const int ty0 = tg * ntile;
-    const int nt = min(ntile, tiles_y - ty0);              // tiles this workgroup walks
-    const int ybase = ty0 * K::TH;                         // first row of the first tile
-    const int c_begin = range * K::CR, c_end = min(C, c_begin + K::CR);
-    const int plane = H * W;
-
-    const float *src = (side == 0 ? x2 : x1) + static_cast<int64_t>(b) * C * plane;
-    float *dstb = (side == 0 ? gin1 : gin2) + static_cast<int64_t>(b) * C * plane;
-    const __amdgpu_buffer_rsrc_t rsrc_src = uniform_rsrc(src, C * plane * 4);
-    const __amdgpu_buffer_rsrc_t rsrc_go =
-        uniform_rsrc(gout + static_cast<int64_t>(b) * (kND * kND) * plane, kND * kND * plane * 4);
-
-    float *ring = smem;
-    float *gbufs = smem + K::NRING * K::ROWF;
-
-    int voff[K::ROW_PW];
-#pragma unroll
-    for (int q = 0; q < K::ROW_PW; ++q) {
-        constexpr int kNoSlot = static_cast<int>(0x80000001u);
-        const int i = (wave + K::NG * q) * 64 + lane;
-        const int ch = i / 18, sl = i % 18;
-        const int gx = x0 - kD + 4 * sl;
-        voff[q] = i >= K::ROW_SLOTS ? kNoSlot
-                  : (c_begin + ch < c_end && gx >= 0 && gx < W) ? (ch * plane + gx) * 4 : kDead;
-    }
-    // DMA instructions this wave issues per gradOutput step / per window row (wave-uniform)
-    int gpw = 0, rpw = 0;
-#pragma unroll
-    for (int q = 0; q < K::G_PW; ++q) gpw += (wave + K::NG * q < K::G_INSTR) ? 1 : 0;
-#pragma unroll
-    for (int q = 0; q < K::ROW_PW; ++q) rpw += (wave + K::NG * q < K::ROW_INSTR) ? 1 : 0;
-
-    // gradOutput of global step k (tile k / 9, displacement row k % 9) into buffer k % NGB
-    auto issue_g = [&](int k) {
-        const int t = k / kND, s = k - t * kND;
-        float *wr = gbufs + (k % K::NGB) * K::GBUF;
-        if (side == 0) rows_issue_g<K, 0>(wr, rsrc_go, wave, lane, s, x0, ybase + t * K::TH, H, W, plane, t < nt);
-        else rows_issue_g<K, 1>(wr, rsrc_go, wave, lane, s, x0, ybase + t * K::TH, H, W, plane, t < nt);
-    };
-    // window row `row` (counted from ybase - 4) into its ring slot
-    auto issue_row = [&](int row, bool alive) {
-        rows_issue_row<K>(ring + (row % K::NRING) * K::ROWF, rsrc_src, voff, wave, ybase - kD + row, H, W,
-                          c_begin, plane, alive);
-    };
-
-    // ---- prologue: the whole window of the first tile, gradOutput of the first AHEAD steps ----
-#pragma unroll
-    for (int row = 0; row < K::NRING; ++row) issue_row(row, true);
-#pragma unroll
-    for (int k = 0; k < K::AHEAD; ++k) issue_g(k);
-
-    float acc[K::CB][kP];
-#pragma unroll
-    for (int i = 0; i < K::CB; ++i)
-#pragma unroll
-        for (int p = 0; p < kP; ++p) acc[i][p] = 0.f;
-    const float inv_nelems = 1.0f / static_cast<float>(C);
-    const int goff = r * K::RSF + 4 * sx;
-    const int choff = wave * K::CB * K::RSF + 4 * sx;
-    wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();
-
-    for (int t = 0; t < nt; ++t) {
-#pragma unroll
-        for (int s = 0; s < kND; ++s) {
-            const int k = t * kND + s;
-            // requests of this step: gradOutput AHEAD steps on; during steps 1..TH the next
-            // tile's rows, each into the slot of the row that retired with the previous step
-            issue_g(k + K::AHEAD);
-            asm volatile("" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            constexpr bool kRowStep = true;
-            const bool row_step = s >= 1 && s <= K::TH;
-            if (row_step) issue_row(t * K::TH + K::NRING + s - 1, t + 1 < nt);
-            asm volatile("" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            (void)kRowStep;
-            // ---- consume step (t, s) ----
-            const int slot = (t * K::TH + s + r) % K::NRING;
-            const float *g_rd = gbufs + (k % K::NGB) * K::GBUF;
-            if (side == 0) rows_compute<K, 0>(ring, g_rd, slot * K::ROWF + choff, goff, acc, 0);
-            else rows_compute<K, 1>(ring, g_rd, slot * K::ROWF + choff, goff, acc, 0);
-            int stores = 0;
-            if (s == kND - 1) {
-                // ---- the tile is complete: 1/C, coalesced 16-byte stores, fresh accumulators ----
-                const int y = ybase + t * K::TH + r, x = x0 + 4 * sx;
-#pragma unroll
-                for (int i = 0; i < K::CB; ++i) {
-                    const int c = c_begin + wave * K::CB + i;
-                    typedef unsigned uint4v __attribute__((ext_vector_type(4)));
-                    typedef float f4v __attribute__((ext_vector_type(4)));
-                    // buffer store: lanes outside the image / channels past the range are dropped
-                    // by an out-of-range offset, so every wave issues the same CB stores
-                    const int off = (y < H && x < W && c < c_end) ? (y * W + x) * 4 : kDead;
-                    __builtin_amdgcn_raw_buffer_store_b128(
-                        __builtin_bit_cast(uint4v, f4v{acc[i][0] * inv_nelems, acc[i][1] * inv_nelems,
-                                                       acc[i][2] * inv_nelems, acc[i][3] * inv_nelems}),
-                        uniform_rsrc(dstb, C * plane * 4), off,
-                        __builtin_amdgcn_readfirstlane(min(c, C - 1) * plane * 4), 2 /* nt */);
-#pragma unroll
-                    for (int p = 0; p < kP; ++p) acc[i][p] = 0.f;
-                }
-                stores = K::CB;
-            }
-            // gradOutput of the NEXT step was requested two steps ago: everything this wave has
-            // issued since (two steps of requests, the stores of a tile end) may stay in flight
-            const int prev_rows = (s - 1 >= 1 && s - 1 <= K::TH) || false ? rpw : 0;
-            const int prev_stores = (s == 0 && t > 0) ? K::CB : 0;
-            wait_vmcnt_upto<24>(2 * gpw + (row_step ? rpw : 0) + prev_rows + stores + prev_stores);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-        }
-    }
-#endif
-}
-
-#endif  // CERB_EXPERIMENTS
-
 // ---- host side -------------------------------------------------------------
 // 16-bit storage is only instantiated for the vector (aligned, W % 4 == 0) path; other
 // shapes of those dtypes take the generic kernels.
@@ -2022,37 +1851,8 @@ int launch_bwd_rows(const char *name, const void *in1, const void *in2, const vo
 }
 
 #ifdef CERB_EXPERIMENTS
-using BwdCol = BwdColCfg<4, 8>;     // 4x64 tiles walked down a column, 8 waves x 4 channels
-#endif
-
-#ifdef CERB_EXPERIMENTS
-template <typename K>
-int launch_bwd_col(const char *name, const void *in1, const void *in2, const void *goutp, void *g1p,
-                   void *g2p, const CorrGeom &g, hipStream_t s) {
-    const int tiles_x = (g.W + K::TW - 1) / K::TW, tiles_y = (g.H + K::TH - 1) / K::TH;
-    const int nrange = (g.C + K::CR - 1) / K::CR;
-    // tiles per workgroup: as many as still leave one workgroup per CU (one prologue per walk)
-    int ntile = tiles_y;
-    if (const int forced = option(OPT_CORR_BWD_CSLICE)) ntile = forced;   // tuning hook: tiles per walk
-    else
-        while (ntile > 1 && static_cast<int64_t>(g.B) * tiles_x * ((tiles_y + ntile - 1) / ntile) * nrange * 2 < 256)
-            ntile = (ntile + 1) / 2;
-    ntile = std::max(1, std::min(ntile, tiles_y));
-    const int ngroup = (tiles_y + ntile - 1) / ntile;
-    const int64_t blocks = static_cast<int64_t>(g.B) * tiles_x * ngroup * nrange * 2;
-    if (blocks > 0x7fffffff) return CERB_ETOOLARGE;
-    static std::atomic<uint64_t> lds_done{0};
-    int rc;
-    if ((rc = ensure_lds(corr_bwd_d4_col_kernel<K>, K::LDS_BYTES, &lds_done))) return rc;
-    note_kernel(1, name);
-    hipLaunchKernelGGL((corr_bwd_d4_col_kernel<K>), dim3(static_cast<unsigned>(blocks)),
-                       dim3(K::THREADS), K::LDS_BYTES, s, static_cast<const float *>(in1),
-                       static_cast<const float *>(in2), static_cast<const float *>(goutp),
-                       static_cast<float *>(g1p), static_cast<float *>(g2p), g.C, g.H, g.W, tiles_x,
-                       tiles_y, nrange, ntile, ngroup);
-    return launch_status();
-}
-
+// the column-walking backward (measured and rejected): compiled into -DCERB_EXPERIMENTS test builds only
+#include "corr_d4_experiments.inc"
 #endif
 
 bool fast_config(const CorrGeom &g, int dtype) {
