@@ -776,7 +776,9 @@ def model_step_mode(args, device, rank, world, dist, quiet=False):
     fill_parameters(model.flow, 500)
     l_img = torch.from_numpy(hash_uniform((B, 3, H, W), 11 + 1000 * rank, -2.0, 2.0)).to(device)
     l_seq = torch.from_numpy(hash_uniform((B, 3, H, W), 12 + 1000 * rank, -2.0, 2.0)).to(device)
-    net = wrap_ddp(model, device) if world > 1 else model
+    # (CERB_FORCE_DIST=1 on one GPU: a one-rank RCCL group, the model really under DDP -- the self-test of this path)
+    net = wrap_ddp(model, device, force=dist is not None) if dist is not None else model
+    ddp = net is not model
     loss_fn = unFlowLoss(weights={"l1": 0.15, "ssim": 0.85}, consistency=True)
     params = [p for p in model.parameters() if p.requires_grad]
     opt = torch.optim.Adam(params, lr=1e-4, betas=(0.9, 0.99), weight_decay=1e-6)
@@ -831,7 +833,7 @@ def model_step_mode(args, device, rank, world, dist, quiet=False):
             "launch": "eager",
             "sharding": ("image pairs sharded over ranks; DistributedDataParallel over RCCL (64 MB buckets, static graph): "
                          "%.1f MB of gradients all-reduced inside every step, overlapped with backward" % (4e-6 * nparam)
-                         if world > 1 else "one rank"),
+                         if ddp else "one rank"),
             "hot_path_ops": "cerberus:: HIP kernels (correlation_leaky_into, flow_warp, flow_upsample, area_resize)",
             "loss_last_step": float(loss.item()),
         },

@@ -76,3 +76,60 @@ def test_rccl_world2_exchange_and_ddp_gradients(tmp_path):
     for g, p in zip(got["grads"], head.parameters()):
         den = float(p.grad.norm()) or 1.0
         assert float((g - p.grad).norm()) / den < 2e-3
+
+
+def _one_rank_worker(rank, port, out):
+    os.environ.update(RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LOCAL_RANK="0",
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)      # RCCL, one rank
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from cerberusnet_amd.loss_functions import unFlowLoss
+    from cerberusnet_amd.nnet_models import CerberusBase, cerberus_flow_config
+    from cerberusnet_amd.synth import fill_parameters
+    torch.backends.cudnn.deterministic = True
+
+    def build():
+        m = CerberusBase(**cerberus_flow_config()).to(dev).train()
+        fill_parameters(m.backbone, 400)
+        fill_parameters(m.flow, 500)
+        return m
+    l_img = torch.from_numpy(hash_uniform((2, 3, 128, 256), 431, -2.0, 2.0)).to(dev)
+    l_seq = torch.from_numpy(hash_uniform((2, 3, 128, 256), 432, -2.0, 2.0)).to(dev)
+    loss_fn = unFlowLoss()
+    res = {}
+    for tag, wrap in (("plain", False), ("ddp", True)):
+        model = build()
+        net = cdist.wrap_ddp(model, dev, force=True) if wrap else model
+        if wrap:
+            assert isinstance(net, torch.nn.parallel.DistributedDataParallel)
+        for _ in range(2):                                   # two steps: static_graph settles in the first
+            for p in model.parameters():
+                p.grad = None
+            out_ = net(l_img=l_img, l_seq=l_seq, consistency=True)
+            loss_fn(out_, {"l_img": l_img, "l_seq": l_seq}).backward()
+        res[tag] = [p.grad.detach().cpu() for p in model.parameters()]
+        res[tag + "_keys"] = list(cdist.rank0_state_dict(net).keys())
+    # the stand-alone exchange on the same communicator
+    ex = cdist.GradientExchange(300_000, dev, bucket_mb=0.5)
+    ex.flat.copy_(torch.from_numpy(hash_uniform((300_000,), 433)))
+    ex.start(); ex.finish(); torch.cuda.synchronize()
+    res["flat"] = ex.flat.cpu()
+    torch.save(res, out)
+    dist.destroy_process_group()
+
+
+def test_rccl_one_rank_group_runs_the_model_under_ddp(tmp_path):
+    """What a 1-GPU box CAN verify of the N > 1 path: a real RCCL communicator (one rank), the host model under
+    DistributedDataParallel (bucket hooks, gradient_as_bucket_view, static_graph with the head called twice) on the
+    HIP ops, gradients equal to the unwrapped model's, checkpoints without the `module.` prefix, and the bucketed
+    exchange (an average over one rank = identity)."""
+    out = str(tmp_path / "one.pt")
+    mp.spawn(_one_rank_worker, args=(_free_port(), out), nprocs=1, join=True)
+    got = torch.load(out)
+    assert got["plain_keys"] == got["ddp_keys"] and not any(k.startswith("module.") for k in got["ddp_keys"])
+    worst = max(float((a - b).norm() / (b.norm() + 1e-12)) for a, b in zip(got["ddp"], got["plain"]))
+    assert worst < 1e-4, worst
+    assert torch.allclose(got["flat"], torch.from_numpy(hash_uniform((300_000,), 433)), rtol=0, atol=1e-7)
