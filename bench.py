@@ -243,8 +243,10 @@ def per_kernel_times(wl, reps, cold=True):
              its inputs from HBM, as it does inside the step.  The roofline fractions use this one."""
     ops = torch.ops.cerberus
     lv = wl.dirs[0]
-    if any("warped" not in t for t in lv):
-        wl._direction(lv, [])
+    # an eager pass first: the tensors a capture assigned (warped, ctx) belong to the graph's pool and hold nothing until
+    # the graph has been replayed; the launches timed here must see a real context
+    wl._direction(lv, [])
+    torch.cuda.synchronize()
     kern = dict(wl.kernels())
 
     def calls_for(t, l):

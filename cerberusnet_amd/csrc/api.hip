@@ -20,6 +20,7 @@ const char *const g_option_names[OPT_COUNT] = {
     "warp_tile_h",          // 0: auto, 8 / 16: rows per warp-backward tile
     "warp_force_scatter",   // 1: warp backward by global atomics (ATen's method) even with a context
     "warp_staged",          // 0: auto (warp gathers through an LDS window), 2: never, >= 4: that many channels per forward workgroup
+    "warp_stagger",         // warp backward phase shift: 0 auto, -1 off, else delays (x 1024 cycles) of the 2nd / 3rd / 4th 256 workgroups, a byte each
 #ifdef CERB_ABLATE
     "corr_debug_ablate",    // timing ablation mask (WRONG results when != 0); ablation builds only
 #endif

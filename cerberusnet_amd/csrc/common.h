@@ -76,6 +76,7 @@ enum OptId {
     OPT_WARP_TILE_H,
     OPT_WARP_FORCE_SCATTER,
     OPT_WARP_STAGED,
+    OPT_WARP_STAGGER,
 #ifdef CERB_ABLATE
     OPT_DEBUG_ABLATE,   // timing-ablation mask: exists in -DCERB_ABLATE builds only
 #endif

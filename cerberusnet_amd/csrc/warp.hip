@@ -189,6 +189,17 @@ __device__ __forceinline__ int tap_index(float f) {
     return min(max(static_cast<int>(f), -(1 << 24)), 1 << 24);
 }
 
+// One channel's contribution to grad_flow (the derivative of the bilinear sample by its position, times
+// gradOutput): d out / d x = (vne - vnw) * (y1 - iy) + (vse - vsw) * (iy - y0), d out / d y likewise.  Round 4: as
+// differences and explicit fused multiply-adds -- 5 VALU per component instead of the 9 of the term-by-term form
+// (the warp backward executes ~100 VALU instructions per pixel-channel: profiles/r04_pmc_counters.csv) -- and ONE
+// definition for every grad_flow role, so that the roles keep producing identical bits.
+template <typename A>
+__device__ __forceinline__ void flow_grad_terms(A vnw, A vne, A vsw, A vse, A ax, A fx, A ay, A fy, A g, A &gix, A &giy) {
+    gix = fma(fma(vne - vnw, ay, (vse - vsw) * fy), g, gix);
+    giy = fma(fma(vsw - vnw, ax, (vse - vne) * fx), g, giy);
+}
+
 // Grid: 1-D over the B * strips-per-image pixel strips, one per workgroup.  T: image / output
 // storage type, F: flow type
 // (F = float with a 16-bit image keeps full flow precision: the reference's grid_sample runs
@@ -441,6 +452,7 @@ __global__ __launch_bounds__(256) void warp_fwd_staged_kernel(
 #if defined(__HIP_DEVICE_COMPILE__)
     __shared__ __attribute__((aligned(16))) float win[kStageCap];
     __shared__ int4 boxes[4];
+
     constexpr int esz = sizeof(T);
     const int plane = H * W;   // the launcher guarantees C * plane * esz < 2^31
     const int tid = threadIdx.x;
@@ -666,10 +678,8 @@ __global__ __launch_bounds__(kPix * kCg) void warp_bwd_kernel(
                     if (oky1 && okx1) atomic_accumulate(gimage + q + W + 1, wse * g[u]);
                 }
                 if (gflow) {
-                    gix += (-vnw[u] * (y1f - cy.pos) + vne[u] * (y1f - cy.pos) -
-                            vsw[u] * (cy.pos - y0f) + vse[u] * (cy.pos - y0f)) * g[u];
-                    giy += (-vnw[u] * (x1f - cx.pos) - vne[u] * (cx.pos - x0f) +
-                            vsw[u] * (x1f - cx.pos) + vse[u] * (cx.pos - x0f)) * g[u];
+                    flow_grad_terms<A>(vnw[u], vne[u], vsw[u], vse[u], x1f - cx.pos, cx.pos - x0f, y1f - cy.pos,
+                                       cy.pos - y0f, g[u], gix, giy);
                 }
             }
         }
@@ -804,10 +814,8 @@ __device__ __forceinline__ bool flow_role_staged(
                 const float *wc = tap + h * w.area;
                 const float vnw = dead ? 0.f : wc[0], vne = dead ? 0.f : wc[1];
                 const float vsw = dead ? 0.f : wc[w.pitch], vse = dead ? 0.f : wc[w.pitch + 1];
-                gix[u % NPL] += (-vnw * (y1f - iyp) + vne * (y1f - iyp) - vsw * (iyp - y0f) +
-                                 vse * (iyp - y0f)) * g[u];
-                giy[u % NPL] += (-vnw * (x1f - ixp) - vne * (ixp - x0f) + vsw * (x1f - ixp) +
-                                 vse * (ixp - x0f)) * g[u];
+                flow_grad_terms<float>(vnw, vne, vsw, vse, x1f - ixp, ixp - x0f, y1f - iyp, iyp - y0f, g[u],
+                                       gix[u % NPL], giy[u % NPL]);
             }
         }
     }
@@ -872,10 +880,8 @@ __device__ __forceinline__ void flow_role_tile_direct(
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             if (c + u >= C) break;
-            gix[u & 3] += (-vnw[u] * (y1f - iyp) + vne[u] * (y1f - iyp) - vsw[u] * (iyp - y0f) +
-                           vse[u] * (iyp - y0f)) * g[u];
-            giy[u & 3] += (-vnw[u] * (x1f - ixp) - vne[u] * (ixp - x0f) + vsw[u] * (x1f - ixp) +
-                           vse[u] * (ixp - x0f)) * g[u];
+            flow_grad_terms<float>(vnw[u], vne[u], vsw[u], vse[u], x1f - ixp, ixp - x0f, y1f - iyp, iyp - y0f, g[u],
+                                   gix[u & 3], giy[u & 3]);
         }
     }
     float sx = 0.f, sy = 0.f;
@@ -909,12 +915,15 @@ template <int TH> struct TileGeom {
     static constexpr int PS = (TH + 2) * PW;       // accumulators per channel plane
 };
 
+#ifndef CERB_TILE16_WPS
+#define CERB_TILE16_WPS 4
+#endif
 template <typename T, typename F, int TH, int CW, int NS>
-__global__ __launch_bounds__(256, 4) void warp_bwd_tile_kernel(
+__global__ __launch_bounds__(256, TH == 16 ? CERB_TILE16_WPS : 4) void warp_bwd_tile_kernel(
     const T *__restrict__ image, const T *__restrict__ gout, const void *__restrict__ ctx,
     T *__restrict__ gimage, F *__restrict__ gflow, int B, int C, int H, int W,
     int tiles_x, int tiles_y, int nrange, int crange, int ntile_blocks, int pad_mode,
-    int flow_staged, int flow_sub) {
+    int flow_staged, int flow_sub, int stagger) {
     constexpr int TW = kTileW, PW = TileGeom<TH>::PW, PS = TileGeom<TH>::PS;
     constexpr int NP = CW / 2;                       // channel pairs = planes of 64-bit slots
     static_assert(CW % 2 == 0, "channels are accumulated in pairs");
@@ -923,6 +932,12 @@ __global__ __launch_bounds__(256, 4) void warp_bwd_tile_kernel(
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int plane = H * W;
 
+    if (stagger > 0) {   // phase shift of the co-resident workgroups of a CU (blocks i, i + 256, i + 512, i + 768): launch_tiles
+        const int q = (blockIdx.x >> 8) & 3;
+        const unsigned long long wait = q == 0 ? 0ull : static_cast<unsigned long long>((stagger >> (8 * (q - 1))) & 255) * 1024ull;
+        const unsigned long long t0 = __builtin_readcyclecounter();
+        while (__builtin_readcyclecounter() - t0 < wait) __builtin_amdgcn_s_sleep(16);
+    }
     if (static_cast<int>(blockIdx.x) >= ntile_blocks) {
         // ------------------------------ FLOW workgroup ------------------------------
         if (flow_staged) {
@@ -981,10 +996,8 @@ __global__ __launch_bounds__(256, 4) void warp_bwd_tile_kernel(
 #pragma unroll
             for (int u = 0; u < kU; ++u) {
                 if (c + u * ncg >= C) continue;   // no 0 * Inf from a repeated channel
-                gix += (-vnw[u] * (y1f - iyp) + vne[u] * (y1f - iyp) - vsw[u] * (iyp - y0f) +
-                        vse[u] * (iyp - y0f)) * g[u];
-                giy += (-vnw[u] * (x1f - ixp) - vne[u] * (ixp - x0f) + vsw[u] * (x1f - ixp) +
-                        vse[u] * (ixp - x0f)) * g[u];
+                flow_grad_terms<float>(vnw[u], vne[u], vsw[u], vse[u], x1f - ixp, ixp - x0f, y1f - iyp, iyp - y0f, g[u],
+                                       gix, giy);
             }
         }
         part[wave][0][lane] = gix;
@@ -1010,6 +1023,7 @@ __global__ __launch_bounds__(256, 4) void warp_bwd_tile_kernel(
     }
 
     // -------------------------------- TILE workgroup --------------------------------
+
     // (image, tile row, tile column, channel range) with the RANGE fastest: an XCD's contiguous share is then a
     // spatial region of one image with all its channel ranges -- the same region its share of the FLOW
     // workgroups covers (also image-major, row-major), so that gradOutput, which both roles read, goes over
@@ -1118,13 +1132,30 @@ __global__ __launch_bounds__(256, 4) void warp_bwd_tile_kernel(
         __device__ __forceinline__ void next() { rx += qx; ry += qy; if (rx >= rw) { rx -= rw; ++ry; } }
     };
     // gradOutput of CW channels at one source (channels past the range re-read the last one)
+    // Through a buffer resource: the channel is a SCALAR offset and the source pixel one 32-bit VGPR offset (round 3: a
+    // 64-bit address per load -- v_lshl_add_u64 on a VGPR pair each, 48 of them in flight per thread; the last two loaded
+    // values were spilled behind an s_waitcnt vmcnt(0), which serialised the batch).  The launcher guarantees
+    // C * plane * sizeof(T) < 2^31.
+#if defined(__HIP_DEVICE_COMPILE__)
+    const __amdgpu_buffer_rsrc_t rsrc_go = uniform_rsrc(go, C * plane * static_cast<int>(sizeof(T)));
+#endif
     auto load_g = [&](const Src &s, int c0, float (&g)[CW]) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        const int voff = s.pv * static_cast<int>(sizeof(T));
 #pragma unroll
         for (int c = 0; c < CW; ++c)
-            g[c] = ld(go + static_cast<int64_t>(min(c0 + c, c_end - 1)) * plane + s.pv);
+            g[c] = buffer_load_px1<T>(rsrc_go, voff, __builtin_amdgcn_readfirstlane(min(c0 + c, c_end - 1) * plane * static_cast<int>(sizeof(T))));
+#endif
     };
-    auto absmax_bits = [&](const Src &s, const float (&g)[CW], int gb) {
-        // integer order of |g| bit patterns: NaN > Inf > every finite value
+    auto absmax_bits = [&](const Src &, const float (&g)[CW], int gb) {
+        // integer order of |g| bit patterns: NaN > Inf > every finite value.  Unmasked: every slot of the register
+        // path holds a live source or a repeat of one (see the deal); round 3 masked per value (3 VALU instead of 2)
+#pragma unroll
+        for (int c = 0; c < CW; ++c)
+            gb = max(gb, __float_as_int(g[c]) & 0x7fffffff);
+        return gb;
+    };
+    auto absmax_bits_masked = [&](const Src &s, const float (&g)[CW], int gb) {   // the region-walking path: non-members masked
 #pragma unroll
         for (int c = 0; c < CW; ++c)
             gb = max(gb, s.o >= 0 ? (__float_as_int(g[c]) & 0x7fffffff) : 0);
@@ -1183,9 +1214,15 @@ __global__ __launch_bounds__(256, 4) void warp_bwd_tile_kernel(
         const float w00 = ax * ay, w01 = s.fx * ay, w10 = ax * s.fy, w11 = s.fx * s.fy;
         unsigned long long *a = acc64 + s.o;
         if (!nonfinite) {
-            // (a, b) -> a + (b << 32) as two's complement: low word a, high word b + (a >> 31)
+            // (a, b) -> a + (b << 32) as two's complement: low word a, high word b + (a >> 31).  Round 4: rounded by ONE
+            // instruction each (v_cvt_rpi_i32_f32 = floor(x + 0.5); __float2int_rn is v_rndne_f32 + v_cvt_i32_f32): 26 instead
+            // of 34 VALU per source and channel pair (multiplying the two channels as a v_pk_mul_f32 pair saves four more but
+            // the aligned register pairs it needs spill 48 VGPRs of this kernel's 128).  Ties round up instead of to even: a fixed rule, so the integer sums stay
+            // order-independent, and half a unit of 2^-29 of the group's maximum either way.
             auto pack = [](float va, float vb) {
-                const int ia = __float2int_rn(va), ib = __float2int_rn(vb);
+                int ia, ib;
+                asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(ia) : "v"(va));
+                asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(ib) : "v"(vb));
                 return (static_cast<unsigned long long>(static_cast<unsigned>(ib + (ia >> 31))) << 32) |
                        static_cast<unsigned>(ia);
             };
@@ -1231,27 +1268,30 @@ __global__ __launch_bounds__(256, 4) void warp_bwd_tile_kernel(
                     for (int k = 0; k < 4; ++k) acc[slot + k] = 0;
                 }
                 if (ty0 + yy < H && tx0 + xx < W) {      // (W % 4 == 0: the four columns are in or out together)
-                    float ra[4], rb[4];
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const int lo = static_cast<int>(v[k]);
-                        const int hi = static_cast<int>((v[k] - lo) >> 32);
-                        ra[k] = nonfinite ? __int_as_float(lo) : static_cast<float>(lo) * unscale;
-                        rb[k] = nonfinite ? __int_as_float(static_cast<int>(v[k] >> 32)) : static_cast<float>(hi) * unscale;
-                    }
                     T *d = dst + static_cast<int64_t>(c0 + 2 * q) * plane + (ty0 + yy) * W + tx0 + xx;
-                    if constexpr (sizeof(T) == 4) {
-                        *reinterpret_cast<float4 *>(d) = make_float4(ra[0], ra[1], ra[2], ra[3]);
-                        if (2 * q + 1 < cw) *reinterpret_cast<float4 *>(d + plane) = make_float4(rb[0], rb[1], rb[2], rb[3]);
-                    } else {
-                        T ta[4], tb[4];
+                    // one channel at a time (four results live, not eight: the kernel sits at its 128 VGPRs)
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) { st(&ta[k], ra[k]); st(&tb[k], rb[k]); }
-                        uint2 pa, pb;
-                        __builtin_memcpy(&pa, ta, 8);
-                        __builtin_memcpy(&pb, tb, 8);
-                        *reinterpret_cast<uint2 *>(d) = pa;
-                        if (2 * q + 1 < cw) *reinterpret_cast<uint2 *>(d + plane) = pb;
+                    for (int half = 0; half < 2; ++half) {
+                        if (half == 1 && 2 * q + 1 >= cw) break;
+                        float r[4];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const int lo = static_cast<int>(v[k]);
+                            const int word = half == 0 ? lo : (nonfinite ? static_cast<int>(v[k] >> 32)
+                                                                         : static_cast<int>((v[k] - lo) >> 32));
+                            r[k] = nonfinite ? __int_as_float(word) : static_cast<float>(word) * unscale;
+                        }
+                        T *dh = d + half * plane;
+                        if constexpr (sizeof(T) == 4) {
+                            *reinterpret_cast<float4 *>(dh) = make_float4(r[0], r[1], r[2], r[3]);
+                        } else {
+                            T t4[4];
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) st(&t4[k], r[k]);
+                            uint2 pk;
+                            __builtin_memcpy(&pk, t4, 8);
+                            *reinterpret_cast<uint2 *>(dh) = pk;
+                        }
                     }
                 }
             }
@@ -1328,12 +1368,15 @@ __global__ __launch_bounds__(256, 4) void warp_bwd_tile_kernel(
         Src src[NS];
         float g[NS][CW];
         const int ns = (count + 255) / 256;   // sources per thread actually present
+        const int first_pv = count > 0 ? list[0].x : 0;
 #pragma unroll
         for (int j = 0; j < NS; ++j) {
             const int e = j * 256 + tid;
             const int4 v = list[min(e, kCap - 1)];
             const bool have = e < count;
-            src[j].pv = have ? v.x : 0;
+            // an idle slot (past the end of the list) points at the list's FIRST source: its gradOutput values then take
+            // part in the block maximum unmasked (a repeated value cannot change a maximum or add a non-finite one)
+            src[j].pv = have ? v.x : first_pv;
             src[j].o = have ? v.y : -1;
             src[j].fx = __int_as_float(v.z);
             src[j].fy = __int_as_float(v.w);
@@ -1425,7 +1468,7 @@ __global__ __launch_bounds__(256, 4) void warp_bwd_tile_kernel(
                     for (int j = 0; j < NB; ++j) load_g(src[j], c0, g[j]);
                     if (pass == 0) {
 #pragma unroll
-                        for (int j = 0; j < NB; ++j) gb = absmax_bits(src[j], g[j], gb);
+                        for (int j = 0; j < NB; ++j) gb = absmax_bits_masked(src[j], g[j], gb);
                     } else {
 #pragma unroll
                         for (int j = 0; j < NB; ++j) add_taps(src[j], g[j], cw, scale, nonfinite);
@@ -1576,12 +1619,28 @@ static int launch_tiles(const void *image, const void *gout, const void *ctx, vo
     const int64_t nstrips = static_cast<int64_t>(B) * strips.per_image();
     const int64_t flow_blocks = !gflow ? 0 : flow_staged ? flow_tiles : nstrips * flow_sub;
     if (tile_blocks + flow_blocks > 0x7fffffff) return CERB_ETOOLARGE;
+    // PHASE SHIFT (round 4).  When the whole launch is resident at once (<= 4 workgroups per CU) every workgroup runs the
+    // same phase at the same time and each phase is bound by a throughput the chip shares -- the gradOutput gather by the
+    // memory system, the adds by the LDS-atomic pipe and the VALU, the write-out by store issue -- so the launch takes the
+    // SUM of its phases (section 3.4 of DESIGN.md).  Workgroups i, i + 256, i + 512, i + 768 share a CU: starting some of
+    // them a few thousand cycles late lets one's gather run under another's adds.  Measured (4 pairs, us, off -> on):
+    // 32 x 128 x 256 (two 16-row tile workgroups per CU: the second starts 6 k cycles late) 24.7 -> 22.8; 128 x 32 x 64 (one
+    // tile workgroup per CU: the first half of the flow workgroups 8 k cycles late) 10.9 -> 10.4; 64 x 64 x 128 loses with
+    // every pattern tried (15.0 -> 15.3 .. 17.3) and keeps none.  "warp_stagger": 0 = this rule, -1 = off, else delays of the
+    // second / third / fourth 256 workgroups in units of 1024 cycles, one byte each.
+    int stagger = option(OPT_WARP_STAGGER);
+    if (stagger == 0) {
+        const int64_t total = tile_blocks + flow_blocks;
+        if (TH == 16 && tile_blocks == 512 && total <= 1024) stagger = 6;
+        else if (tile_blocks == 256 && total > 512 && total <= 1024) stagger = 8;
+    }
+    if (stagger < 0) stagger = 0;
     hipLaunchKernelGGL((warp_bwd_tile_kernel<T, F, TH, CW, NS>),
                        dim3(static_cast<unsigned>(tile_blocks + flow_blocks)), dim3(256), 0, s,
                        static_cast<const T *>(image), static_cast<const T *>(gout), ctx,
                        static_cast<T *>(gimage), static_cast<F *>(gflow), B,
                        C, H, W, tiles_x, tiles_y, nrange, crange, static_cast<int>(tile_blocks),
-                       pad_mode, flow_staged ? 1 : 0, flow_sub);
+                       pad_mode, flow_staged ? 1 : 0, flow_sub, stagger);
     return launch_status();
 }
 
@@ -1607,7 +1666,7 @@ int warp_backward(const void *image, const void *flow, const void *gout, void *g
     const bool ws_ok = workspace && workspace_bytes >= warp_backward_workspace_bytes(B, C, H, W) &&
                        (reinterpret_cast<uintptr_t>(workspace) & 15) == 0;
     const bool tiled = gimage && dtype != CERB_F64 && (ctx || ws_ok) &&
-                       static_cast<int64_t>(C) * plane < 0x7fffffff &&
+                       static_cast<int64_t>(C) * plane * static_cast<int64_t>(esz) < 0x7fffffff &&
                        option(OPT_WARP_FORCE_SCATTER) == 0;
     if (tiled) {
         int rc;
