@@ -1625,14 +1625,14 @@ static int launch_tiles(const void *image, const void *gout, const void *ctx, vo
     // SUM of its phases (section 3.4 of DESIGN.md).  Workgroups i, i + 256, i + 512, i + 768 share a CU: starting some of
     // them a few thousand cycles late lets one's gather run under another's adds.  Measured (4 pairs, us, off -> on):
     // 32 x 128 x 256 (two 16-row tile workgroups per CU: the second starts 6 k cycles late) 24.7 -> 22.8; 128 x 32 x 64 (one
-    // tile workgroup per CU: the first half of the flow workgroups 8 k cycles late) 10.9 -> 10.4; 64 x 64 x 128 loses with
+    // tile workgroup per CU: the two halves of the flow workgroups 6 k and 2 k cycles late) 11.1 -> 10.1; 64 x 64 x 128 loses with
     // every pattern tried (15.0 -> 15.3 .. 17.3) and keeps none.  "warp_stagger": 0 = this rule, -1 = off, else delays of the
     // second / third / fourth 256 workgroups in units of 1024 cycles, one byte each.
     int stagger = option(OPT_WARP_STAGGER);
     if (stagger == 0) {
         const int64_t total = tile_blocks + flow_blocks;
         if (TH == 16 && tile_blocks == 512 && total <= 1024) stagger = 6;
-        else if (tile_blocks == 256 && total > 512 && total <= 1024) stagger = 8;
+        else if (tile_blocks == 256 && total > 512 && total <= 1024) stagger = 6 | (2 << 8);
     }
     if (stagger < 0) stagger = 0;
     hipLaunchKernelGGL((warp_bwd_tile_kernel<T, F, TH, CW, NS>),

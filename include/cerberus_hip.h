@@ -224,8 +224,8 @@ int cerberus_area_resize(const void *src, void *dst, int64_t planes, int H, int 
  *                          many channels per workgroup
  *   "warp_stagger"       : phase shift of the warp backward's co-resident workgroups (round 4): 0 = auto (when
  *                          the whole launch is resident at once: the second 16-row tile workgroup of every CU
- *                          starts 6 k cycles late, or, with one tile workgroup per CU, the first half of the
- *                          grad_flow workgroups 8 k cycles late), -1 = off, else the delays of the 2nd / 3rd / 4th
+ *                          starts 6 k cycles late, or, with one tile workgroup per CU, the two halves of the
+ *                          grad_flow workgroups 6 k and 2 k cycles late), -1 = off, else the delays of the 2nd / 3rd / 4th
  *                          256 workgroups in units of 1024 cycles, one byte each.  Speed only: same results.
  * Returns CERB_EINVAL for an unknown key. */
 int cerberus_set_option(const char *key, int value);
