@@ -39,3 +39,44 @@ for trial in range(3):
     print("trial %d: wall %.3f ms for %d replays (%.4f ms each), host issue of all %.3f ms (per replay call: first %.0f us, median %.0f us)"
           % (trial, wall * 1e3, N, wall * 1e3 / N, t_issue * 1e3, host[0] * 1e6, sorted(host)[N // 2] * 1e6))
     print("   event-to-event ms:", " ".join("%.3f" % x for x in d))
+
+# ---- is the ramp a property of the GRAPH EXEC (its first ~25 launches) or of the chip's state? ----
+# the chip has just run ~80 replays of graph `g`; capture a SECOND graph of the same step now and time its first replays
+def capture():
+    c = torch.cuda.Stream(); c.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(c):
+        wl.step(streams)
+    torch.cuda.current_stream().wait_stream(c)
+    gg = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gg):
+        h = wl.step(streams)
+    return gg, h
+for _ in range(30):
+    g.replay()
+torch.cuda.synchronize()
+g2, held2 = capture()
+for _ in range(30):          # the chip busy with the OLD graph right up to the new graph's first replay
+    g.replay()
+N = 24
+ev = [torch.cuda.Event(enable_timing=True) for _ in range(N + 1)]
+ev[0].record()
+for i in range(N):
+    g2.replay(); ev[i + 1].record()
+torch.cuda.synchronize()
+print("a FRESH graph exec right after 30 replays of the old one (no idle gap): event-to-event ms:",
+      " ".join("%.3f" % ev[i].elapsed_time(ev[i + 1]) for i in range(N)))
+# and the old graph after an idle gap of 20 ms
+time.sleep(0.02)
+ev = [torch.cuda.Event(enable_timing=True) for _ in range(N + 1)]
+ev[0].record()
+for i in range(N):
+    g.replay(); ev[i + 1].record()
+torch.cuda.synchronize()
+print("the OLD graph after 20 ms of idle: event-to-event ms:", " ".join("%.3f" % ev[i].elapsed_time(ev[i + 1]) for i in range(N)))
+time.sleep(1.0)
+ev = [torch.cuda.Event(enable_timing=True) for _ in range(N + 1)]
+ev[0].record()
+for i in range(N):
+    g.replay(); ev[i + 1].record()
+torch.cuda.synchronize()
+print("the OLD graph after 1 s of idle: event-to-event ms:", " ".join("%.3f" % ev[i].elapsed_time(ev[i + 1]) for i in range(N)))
