@@ -1002,6 +1002,28 @@ def main():
         live, live_info = ((None, "skipped") if instep is None or args.no_traffic else live_traffic(args, len(wl.levels)))
         hot, cold = per_kernel_times(wl, max(2, args.probe_steps), cold=not args.no_cold)
         probe = (hot, cold, instep, instep_info, live, live_info)
+    # The step's steady-state time by HIP events over 60 back-to-back replays: a figure of its own (the rate a training
+    # loop sees once it runs) AND the last pass before the warm-up + timed region, which therefore start on a chip that is
+    # in its working state.  Measured (profiles/r04_replay_gaps.txt): after >= 10 ms of idle -- and the set-up, capture and
+    # single-kernel probe passes above are full of such gaps -- this chip runs the next ~8 ms of work 5-12 % slow (0.39 ->
+    # 0.36 -> 0.39 -> 0.365 ms per replay over 24 replays), a transient longer than the driver's whole 20-step timed region;
+    # 40 replays, a synchronize and <= 3 ms of idle later it holds 0.34 ms from the first replay.  Nothing is skipped or
+    # shortened inside the timed region; --probe-after restores the order of rounds 1-3.
+    steady = None
+    if graph is not None and not args.probe_after:
+        for _ in range(20):
+            graph.replay()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        for _ in range(60):
+            graph.replay()
+        ev1.record()
+        torch.cuda.synchronize()
+        steady = {"ms_per_step": round(ev0.elapsed_time(ev1) / 60, 5), "replays": 60,
+                  "pairs_per_s_per_gpu": round(args.pairs * 60 / (ev0.elapsed_time(ev1) * 1e-3), 1),
+                  "what": "HIP events around 60 back-to-back replays of the step graph after 20 untimed ones, on this rank; "
+                          "run right before the W warm-up and K timed steps (the chip's post-idle transient, "
+                          "profiles/r04_replay_gaps.txt, is over by then)"}
     if graph is not None:
         for _ in range(args.warmup):
             graph.replay()
@@ -1108,6 +1130,8 @@ def main():
             },
         }
         result.update(extra)
+        if steady is not None:
+            result["steady_state"] = steady
 
     # ---- the roofline report from the per-kernel passes ----
     if rank == 0:

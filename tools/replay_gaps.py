@@ -80,3 +80,41 @@ for i in range(N):
     g.replay(); ev[i + 1].record()
 torch.cuda.synchronize()
 print("the OLD graph after 1 s of idle: event-to-event ms:", " ".join("%.3f" % ev[i].elapsed_time(ev[i + 1]) for i in range(N)))
+
+# ---- how long an idle gap does it take to trigger the transient? ----
+for gap_ms in (0.0, 0.2, 1.0, 3.0, 10.0):
+    for _ in range(40):
+        g.replay()
+    torch.cuda.synchronize()
+    if gap_ms:
+        t_end = time.perf_counter() + gap_ms * 1e-3
+        while time.perf_counter() < t_end:
+            pass
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(20):
+        g.replay()
+    b.record(); torch.cuda.synchronize()
+    print("40 replays, synchronize, %.1f ms of idle, then 20 replays: %.4f ms per replay" % (gap_ms, a.elapsed_time(b) / 20))
+# ---- and what kind of load keeps the chip in its working state: single-kernel graphs with a synchronize after each (the probe passes) ----
+ops = torch.ops.cerberus
+t3 = wl.dirs[0][3]
+def one():
+    return ops.correlation_backward(t3["f1"], t3["warped"], t3["gout"], 4, 1, 4, 1, 1, 1)
+one(); torch.cuda.synchronize()
+sg = torch.cuda.CUDAGraph()
+cs = torch.cuda.Stream(); cs.wait_stream(torch.cuda.current_stream())
+with torch.cuda.stream(cs):
+    one()
+torch.cuda.current_stream().wait_stream(cs)
+with torch.cuda.graph(sg):
+    keep = [one() for _ in range(20)]
+time.sleep(0.5)
+for _ in range(18):
+    sg.replay(); torch.cuda.synchronize()
+a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+a.record()
+for _ in range(20):
+    g.replay()
+b.record(); torch.cuda.synchronize()
+print("0.5 s idle, 18 x (replay of a 20-launch single-kernel graph + synchronize) = ~12 ms of bursty load, then 20 step replays: %.4f ms per replay" % (a.elapsed_time(b) / 20))
