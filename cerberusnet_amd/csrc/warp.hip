@@ -1105,7 +1105,7 @@ __global__ __launch_bounds__(256, TH == 16 ? CERB_TILE16_WPS : 4) void warp_bwd_
     CERB_STAMP_AT(1);
 
     T *dst = gimage + static_cast<int64_t>(b) * C * plane;
-    const T *go = gout + static_cast<int64_t>(b) * C * plane;
+    [[maybe_unused]] const T *go = gout + static_cast<int64_t>(b) * C * plane;   // (host pass: only the device code reads it)
     unsigned long long *acc64 = reinterpret_cast<unsigned long long *>(acc);
 
     // One source = one pixel whose taps touch the tile: its pixel index, its offset in the
