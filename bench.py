@@ -817,6 +817,29 @@ def model_step_mode(args, device, rank, world, dist, quiet=False):
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    # N > 1: the same step on every rank's own GPU WITHOUT the gradient exchange (DDP's no_sync), timed after the DDP
+    # region: the per-GPU rate the scaling of `value` is to be read against, measured on this node in this run
+    single = None
+    if ddp:
+        try:
+            with net.no_sync():
+                for _ in range(2):
+                    step()
+                fence()
+                t0 = time.perf_counter()
+                for _ in range(args.steps):
+                    step()
+                fence()
+                ds = time.perf_counter() - t0
+            t = torch.tensor([ds], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            ds = float(t.item())
+            single = {"pairs_per_s_per_gpu": round(B * args.steps / ds, 2), "ms_per_step": round(1e3 * ds / args.steps, 4),
+                      "what": "the same training step on every rank's GPU with the gradient all-reduce switched off "
+                              "(DistributedDataParallel.no_sync), slowest rank, timed after the DDP region: "
+                              "value / (n_gpus x this) is the scaling of the DDP step on this node"}
+        except Exception as exc:  # a side report: never fail the line on it
+            single = {"error": repr(exc)[:200]}
     if rank != 0:
         return None
     nparam = sum(p.numel() for p in params)
@@ -841,8 +864,11 @@ def model_step_mode(args, device, rank, world, dist, quiet=False):
         },
         "roofline": None, "cpu_baseline": None,
         "note": "the op-only headline (python bench.py --gpus 1, or --step ops at any N) carries roofline and cpu_baseline; "
-                "to judge scaling compare this line with `model_step` of the N = 1 line (the same step on one GPU)",
+                "to judge scaling compare `value` with n_gpus x `single_gpu_step` of this line (or with `extra.model_step` of "
+                "the N = 1 line): the N = 1 default line times a different step (the ops alone)",
     }
+    if single is not None:
+        result["single_gpu_step"] = single
     if not quiet:
         print(json.dumps(result), flush=True)
     return result
