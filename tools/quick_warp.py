@@ -15,7 +15,7 @@ if len(sys.argv) > 2:
     _lib.set_option("warp_tile_h", int(sys.argv[2]))
 if len(sys.argv) > 3:
     _lib.set_option("warp_tile_ranges", int(sys.argv[3]))
-for name in os.environ.get("CERB_OPT", "").split(","):      # e.g. CERB_OPT=warp_no_lists
+for name in os.environ.get("CERB_OPT", "").split(","):      # e.g. CERB_OPT=warp_stagger=-1
     if name:
         k, _, v = name.partition("=")
         _lib.set_option(k, int(v or 1))
