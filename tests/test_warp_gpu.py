@@ -578,3 +578,24 @@ def test_a_misaligned_context_is_rejected_with_a_clear_message():
     assert shifted.data_ptr() % 16 == 8
     with pytest.raises(RuntimeError, match="16-byte aligned"):
         torch.ops.cerberus.flow_warp_backward_ctx(img, flo, shifted, go, 1, 0, True, True)
+
+
+@pytest.mark.parametrize("lvl", [1, 3])
+def test_phase_shift_of_coresident_workgroups_changes_nothing_but_time(lvl):
+    """Round 4: when the whole warp-backward launch is resident at once some of its workgroups start a few thousand
+    cycles late (option warp_stagger, auto rule in launch_tiles).  Speed only: grad_image and grad_flow must be bit-identical
+    with the shift off, on (auto) and with an arbitrary explicit pattern, at the two benched shapes the rule fires on."""
+    from cerberusnet_amd import _lib
+    C, H, W = W32_PYRAMID_1024x512[lvl]
+    img, go = dev(hash_uniform((4, C, H, W), 301)), dev(hash_uniform((4, C, H, W), 303))
+    flo = dev(hash_uniform((4, 2, H, W), 302, -6.0, 6.0))
+    _, ctx = torch.ops.cerberus.flow_warp_ctx(img, flo, 1, 0)
+    res = {}
+    for tag, val in (("off", -1), ("auto", 0), ("explicit", 3 | (5 << 8) | (9 << 16))):
+        _lib.set_option("warp_stagger", val)
+        try:
+            res[tag] = torch.ops.cerberus.flow_warp_backward_ctx(img, flo, ctx, go, 1, 0, True, True)
+        finally:
+            _lib.set_option("warp_stagger", 0)
+    for tag in ("auto", "explicit"):
+        assert torch.equal(res[tag][0], res["off"][0]) and torch.equal(res[tag][1], res["off"][1]), tag
