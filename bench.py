@@ -898,7 +898,7 @@ def main():
                          "one HIP stream each")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true",
-                    help="skip the two short side passes of the default line (extra.config5_f16, extra.model_step)")
+                    help="skip the short side passes of the default line (extra.config5_f16, extra.bf16_1024x512, extra.model_step)")
     ap.add_argument("--probe-steps", type=int, default=20)
     ap.add_argument("--flow", choices=["smooth", "noise"], default="smooth",
                     help="synthetic flow fields fed to the warp (see Workload._flow)")
@@ -1260,6 +1260,13 @@ def main():
                              "accumulation), 4 image pairs, both directions, fwd+bwd; same launch as the headline")
             except Exception as exc:  # never fail the headline on a side report
                 extra_lines["config5_f16"] = {"error": repr(exc)[:200]}
+            try:    # bf16 storage at the headline's own pyramid (AMP with bf16), value only
+                extra_lines["bf16_1024x512"] = dict(
+                    short_ops_rate(4, 1024, 512, torch.bfloat16, device),
+                    workload="the headline's tensors in bf16 storage (fp32 accumulation), 4 image pairs, both directions, "
+                             "fwd+bwd; same launch as the headline")
+            except Exception as exc:
+                extra_lines["bf16_1024x512"] = {"error": repr(exc)[:200]}
             try:    # the host model's training step on this GPU: the N = 1 point of the DDP scaling curve
                 margs = argparse.Namespace(**vars(args))
                 margs.steps, margs.warmup = 10, 3
