@@ -779,7 +779,7 @@ def model_step_mode(args, device, rank, world, dist, quiet=False):
     l_img = torch.from_numpy(hash_uniform((B, 3, H, W), 11 + 1000 * rank, -2.0, 2.0)).to(device)
     l_seq = torch.from_numpy(hash_uniform((B, 3, H, W), 12 + 1000 * rank, -2.0, 2.0)).to(device)
     # (CERB_FORCE_DIST=1 on one GPU: a one-rank RCCL group, the model really under DDP -- the self-test of this path)
-    net = wrap_ddp(model, device, force=dist is not None) if dist is not None else model
+    net = wrap_ddp(model, device, force=dist is not None, sync_bn=args.sync_bn) if dist is not None else model
     ddp = net is not model
     loss_fn = unFlowLoss(weights={"l1": 0.15, "ssim": 0.85}, consistency=True)
     params = [p for p in model.parameters() if p.requires_grad]
@@ -924,6 +924,8 @@ def main():
                     help="--step head: run both flow directions as one stacked pass (PWCNetHead.forward_both)")
     ap.add_argument("--trace-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-cold", action="store_true", help="skip the cold (HBM-resident inputs) per-kernel pass")
+    ap.add_argument("--sync-bn", action="store_true",
+                    help="--step model, N > 1: SyncBatchNorm instead of per-replica BatchNorm statistics")
     ap.add_argument("--no-traffic", action="store_true",
                     help="skip the two counter passes (FETCH_SIZE / WRITE_SIZE children) behind roofline.traffic; the committed "
                          "figure of profiles/ is reported instead, labelled as such")

@@ -42,15 +42,21 @@ def shard_pairs(n_pairs: int, rank: int, world: int):
 
 
 def wrap_ddp(module: torch.nn.Module, device: Optional[torch.device] = None,
-             bucket_cap_mb: int = 64, force: bool = False) -> torch.nn.Module:
+             bucket_cap_mb: int = 64, force: bool = False, sync_bn: bool = False) -> torch.nn.Module:
     """DDP around a flow head.  The head is called twice per step (1->2 and 2->1,
     cerberus.py:131,135): its parameters are used twice in one autograd graph, every
     parameter always receives a gradient, and the graph is the same every step ->
     ``static_graph=True``, ``find_unused_parameters=False``.
     ``force=True`` wraps even in a one-rank group: the RCCL communicator, DDP's bucket hooks and the
-    static-graph bookkeeping then run for real on a single GPU (the self-test a 1-GPU box can do)."""
+    static-graph bookkeeping then run for real on a single GPU (the self-test a 1-GPU box can do).
+    ``sync_bn=True`` converts the module's BatchNorm layers to ``SyncBatchNorm`` first (the reference's own note,
+    ``ocr_utils.py:13-17``: "if you want to do multi-gpu training, this needs a synchronised version"); off by default:
+    at 4 pairs per GPU per-replica statistics are the cheaper choice (305 more latency-bound collectives per pass
+    otherwise)."""
     if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not force):
         return module
+    if sync_bn:
+        module = torch.nn.SyncBatchNorm.convert_sync_batchnorm(module)
     ids = [device.index] if device is not None and device.type == "cuda" else None
     return DistributedDataParallel(module, device_ids=ids, bucket_cap_mb=bucket_cap_mb,
                                    gradient_as_bucket_view=True, static_graph=True,
