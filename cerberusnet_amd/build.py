@@ -63,7 +63,10 @@ def build(force: bool = False, verbose: bool = False, extra_flags=()):
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
-    build_runtime(force or any(changed for _, changed in results), verbose)
+    try:    # the inference host is an optional extra: its failure must not fail the build of the product library
+        build_runtime(force or any(changed for _, changed in results), verbose)
+    except (subprocess.CalledProcessError, OSError) as exc:
+        print("warning: cerberus_run (runtime/) was not built: %s" % exc, file=sys.stderr)
     return LIB
 
 

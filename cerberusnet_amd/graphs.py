@@ -19,17 +19,19 @@ __all__ = ["GraphedFlowStep", "GraphedFlowInference", "graph_safe_mean", "graph_
 
 
 def graph_safe_sum(t: torch.Tensor, block: int = 4096) -> torch.Tensor:
-    """``t.sum()`` as two block-level reductions (rows of ``block`` elements, then the row sums): no launch of
-    ATen's multi-block reduction, whose scratch buffer + semaphores are what goes wrong inside a replayed
-    hipGraph (see :class:`GraphedFlowStep`).  Differentiable; same value up to fp32 summation order."""
+    """``t.sum()`` as a cascade of block-level reductions (rows of ``block`` elements, then rows of the row sums,
+    ... until one row is left): no launch of ATen's multi-block reduction, whose scratch buffer + semaphores are
+    what goes wrong inside a replayed hipGraph (see :class:`GraphedFlowStep`).  Every stage reduces along the
+    last dimension of a (rows, <= block) matrix, also for inputs of more than ``block ** 2`` elements (a second
+    stage over > ``block`` row sums would itself be a whole-tensor reduction).  Differentiable; same value up
+    to fp32 summation order."""
     flat = t.reshape(-1)
-    n = flat.numel()
-    if n <= block:
-        return flat.sum()
-    pad = (-n) % block
-    if pad:
-        flat = torch.nn.functional.pad(flat, (0, pad))
-    return flat.reshape(-1, block).sum(1).sum()
+    while flat.numel() > block:
+        pad = (-flat.numel()) % block
+        if pad:
+            flat = torch.nn.functional.pad(flat, (0, pad))
+        flat = flat.reshape(-1, block).sum(1)
+    return flat.sum()
 
 
 def graph_safe_mean(t: torch.Tensor, block: int = 4096) -> torch.Tensor:

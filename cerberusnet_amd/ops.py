@@ -279,10 +279,19 @@ def _flow_warp_ctx_cuda(image, flow, pad_mode, interp_mode):
     return _flow_warp_run(image, flow, pad_mode, interp_mode, True, "cerberus::flow_warp_ctx")
 
 
+def _warp_context_bytes(B, H, W):
+    """Size of the warp backward's context in pure Python (what cerberus_flow_warp_context_bytes returns; a test holds
+    the two equal): one int4 tap range per 2 x 32 pixel strip + two fp32 sample-position planes per image.  Meta /
+    fake-tensor tracing must not need the shared library."""
+    if B <= 0 or H <= 0 or W <= 0:
+        return 0
+    strips = ((W + 31) // 32) * ((H + 1) // 2)
+    return B * strips * 16 + B * 2 * H * W * 4
+
+
 def _flow_warp_ctx_meta(image, flow, pad_mode, interp_mode):
     B, _, H, W = image.shape
-    # the size function is host arithmetic of the library itself (no device involved): one definition
-    n = (_lib.get().cerberus_flow_warp_context_bytes(B, H, W) + 7) // 8
+    n = (_warp_context_bytes(B, H, W) + 7) // 8
     return torch.empty_like(image), image.new_empty((n,), dtype=torch.int64)
 
 

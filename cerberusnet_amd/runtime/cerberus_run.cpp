@@ -69,6 +69,7 @@ int main(int argc, char **argv) {
         if (dtype < 0) throw std::invalid_argument("--dtype must be f32, f16 or bf16");
         const int pad = pad_s == "border" ? CERB_PAD_BORDER : pad_s == "zeros" ? CERB_PAD_ZEROS : -1;
         if (pad < 0) throw std::invalid_argument("--pad must be border or zeros");
+        if (reps < 1 || batch < 1) { std::fprintf(stderr, "cerberus_run: --reps and --batch must be >= 1\n"); return 2; }
         std::vector<Dims4> levels;
         std::stringstream ss(levels_s);
         for (std::string item; std::getline(ss, item, ';');) {

@@ -117,34 +117,36 @@ class FlowPyramidGraph {
     FlowPyramidGraph(const std::vector<Dims4> &levels, int dtype, const CorrelationLayer &corr,
                      const FlowWarpLayer &warp)
         : dtype_(dtype), corr_(corr), warp_(warp) {
-        const size_t e = dtype_bytes(dtype);
-        check_hip(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking), "hipStreamCreate");
-        for (size_t l = 0; l < levels.size(); ++l) {
-            PyramidLevel lv;
-            lv.feat = levels[l];
-            lv.has_flow = l > 0;
-            lv.cost_dims = corr_.getOutputDimensions(lv.feat);
-            const size_t fbytes = size_t(lv.feat.count()) * e;
-            check_hip(hipMalloc(&lv.f1, fbytes), "hipMalloc");
-            check_hip(hipMalloc(&lv.f2, fbytes), "hipMalloc");
-            check_hip(hipMalloc(&lv.cost, size_t(lv.cost_dims.count()) * e), "hipMalloc");
-            if (lv.has_flow) {
-                check_hip(hipMalloc(&lv.flow, size_t(lv.feat.n) * 2 * lv.feat.h * lv.feat.w * e), "hipMalloc");
-                check_hip(hipMalloc(&lv.warped, fbytes), "hipMalloc");
+        // a throw from a constructor skips the destructor: release what was acquired so far ourselves
+        try {
+            const size_t e = dtype_bytes(dtype);
+            for (const Dims4 &d : levels)
+                if (d.n <= 0 || d.c <= 0 || d.h <= 0 || d.w <= 0) throw std::runtime_error("FlowPyramidGraph: level dimensions must be positive");
+            check_hip(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking), "hipStreamCreate");
+            levels_.reserve(levels.size());
+            for (size_t l = 0; l < levels.size(); ++l) {
+                levels_.emplace_back();          // registered first: a failing hipMalloc below leaves its siblings to release()
+                PyramidLevel &lv = levels_.back();
+                lv.feat = levels[l];
+                lv.has_flow = l > 0;
+                lv.cost_dims = corr_.getOutputDimensions(lv.feat);
+                const size_t fbytes = size_t(lv.feat.count()) * e;
+                check_hip(hipMalloc(&lv.f1, fbytes), "hipMalloc");
+                check_hip(hipMalloc(&lv.f2, fbytes), "hipMalloc");
+                check_hip(hipMalloc(&lv.cost, size_t(lv.cost_dims.count()) * e), "hipMalloc");
+                if (lv.has_flow) {
+                    check_hip(hipMalloc(&lv.flow, size_t(lv.feat.n) * 2 * lv.feat.h * lv.feat.w * e), "hipMalloc");
+                    check_hip(hipMalloc(&lv.warped, fbytes), "hipMalloc");
+                }
             }
-            levels_.push_back(lv);
+        } catch (...) {
+            release();
+            throw;
         }
     }
     FlowPyramidGraph(const FlowPyramidGraph &) = delete;
     FlowPyramidGraph &operator=(const FlowPyramidGraph &) = delete;
-    ~FlowPyramidGraph() {
-        if (exec_) (void)hipGraphExecDestroy(exec_);
-        if (graph_) (void)hipGraphDestroy(graph_);
-        for (auto &lv : levels_)
-            for (void *p : {lv.f1, lv.f2, lv.flow, lv.warped, lv.cost})
-                if (p) (void)hipFree(p);
-        if (stream_) (void)hipStreamDestroy(stream_);
-    }
+    ~FlowPyramidGraph() { release(); }
     std::vector<PyramidLevel> &levels() { return levels_; }
     hipStream_t stream() const { return stream_; }
     int dtype() const { return dtype_; }
@@ -164,12 +166,20 @@ class FlowPyramidGraph {
             check(corr_.enqueue(lv.feat, dtype_, cin, cout_, nullptr, s), "correlation enqueue");
         }
     }
-    // record once ...
+    // record once ... (a second call re-records: the old graph and its executable are destroyed first)
     void capture() {
+        drop_graph();
         enqueue(stream_);                                   // warm-up (lazy module load is not capturable)
         check_hip(hipStreamSynchronize(stream_), "warm-up");
         check_hip(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal), "begin capture");
-        enqueue(stream_);
+        try {
+            enqueue(stream_);
+        } catch (...) {                                     // never leave the stream in capture mode
+            hipGraph_t partial = nullptr;
+            (void)hipStreamEndCapture(stream_, &partial);
+            if (partial) (void)hipGraphDestroy(partial);
+            throw;
+        }
         check_hip(hipStreamEndCapture(stream_, &graph_), "end capture");
         check_hip(hipGraphInstantiate(&exec_, graph_, nullptr, nullptr, 0), "graph instantiate");
     }
@@ -181,6 +191,17 @@ class FlowPyramidGraph {
     void synchronize() const { check_hip(hipStreamSynchronize(stream_), "synchronize"); }
 
   private:
+    void drop_graph() {
+        if (exec_) { (void)hipGraphExecDestroy(exec_); exec_ = nullptr; }
+        if (graph_) { (void)hipGraphDestroy(graph_); graph_ = nullptr; }
+    }
+    void release() {
+        drop_graph();
+        for (auto &lv : levels_)
+            for (void **p : {&lv.f1, &lv.f2, &lv.flow, &lv.warped, &lv.cost})
+                if (*p) { (void)hipFree(*p); *p = nullptr; }
+        if (stream_) { (void)hipStreamDestroy(stream_); stream_ = nullptr; }
+    }
     int dtype_;
     CorrelationLayer corr_;
     FlowWarpLayer warp_;

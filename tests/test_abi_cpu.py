@@ -135,6 +135,10 @@ def test_warp_context_ops_are_registered_and_fail_loudly_on_cpu():
     # context / workspace sizes grow with the shape and never go negative
     assert lib.cerberus_flow_warp_context_bytes(0, 8, 8) == 0
     assert lib.cerberus_flow_warp_context_bytes(-1, 8, 8) == 0
+    # the meta function's pure-Python size (fake-tensor tracing must not need the .so) equals the library's
+    from cerberusnet_amd.ops import _warp_context_bytes
+    for shape in ((1, 1, 1), (2, 8, 16), (3, 7, 33), (4, 128, 256), (4, 512, 1024), (1, 1025, 31), (0, 8, 8), (-1, 8, 8)):
+        assert _warp_context_bytes(*shape) == lib.cerberus_flow_warp_context_bytes(*shape), shape
     assert (lib.cerberus_flow_warp_backward_workspace_bytes(4, 32, 128, 256)
             == 16 + lib.cerberus_flow_warp_context_bytes(4, 128, 256))
 

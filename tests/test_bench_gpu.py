@@ -40,6 +40,11 @@ def test_bench_line_keeps_the_driver_contract():
     assert d["steady_state"]["ms_per_step"] > 0
     # the timed K steps and the steady-state pass measure the same step: within 15 % of each other
     assert abs(d["ms_per_step"] - d["steady_state"]["ms_per_step"]) <= 0.15 * d["ms_per_step"]
+    # what ran before the timed region is in the line, and the old-order figure of rounds 1-3 beside the headline
+    assert d["pre_timed"]["probe_order"] == "before" and d["pre_timed"]["graph_replays_before_warmup"] == 80
+    f = d["first_steps_after_idle"]
+    assert f["steps"] == 8 and f["warmup"] == 2 and f["value"] > 0
+    assert abs(f["value"] - 4 * 1e3 / f["ms_per_step"]) <= 0.01 * f["value"]
 
 
 def test_bench_prints_a_skipped_record_when_the_box_has_fewer_gpus():

@@ -93,3 +93,17 @@ def test_graph_safe_reductions_equal_the_plain_ones():
         a.backward(); b.backward()
         assert torch.allclose(x.grad, y.grad, rtol=1e-12)
         assert torch.allclose(graph_safe_mean(x.detach()), y.detach().mean(), rtol=1e-12)
+    # more than block ** 2 elements: every stage must still be a row-wise reduction of <= block columns
+    x = torch.randn(16 * 16 * 16 + 3, dtype=torch.float64)
+    assert torch.allclose(graph_safe_sum(x, block=16), x.sum(), rtol=1e-12)
+    seen = []
+    real = torch.Tensor.sum
+    def spy(self, *a, **k):
+        seen.append((tuple(self.shape), a))
+        return real(self, *a, **k)
+    torch.Tensor.sum = spy
+    try:
+        graph_safe_sum(x, block=16)
+    finally:
+        torch.Tensor.sum = real
+    assert all(shape[-1] <= 16 for shape, _ in seen), seen
