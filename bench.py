@@ -618,6 +618,141 @@ def spawn_ranks(n):
     return subprocess.run(cmd, env=env).returncode
 
 
+def loss_side_times(pairs, width, height, device, reps=12):
+    """The hot path's SECOND workload inside a training step: what unFlowLoss launches around the
+    head -- the two target images resized to every flow scale (UnFlowLoss.py:279-280), the RGB warps of those images by
+    every predicted flow, forward and grad_flow (UnFlowLoss.py:282-283: 8 + 8 launches per step) -- and the pass that
+    turns the concatenation buffer's gradient into the correlation backward's gradOutput (pwcnet_sfd.py:181-187 seen
+    from autograd).  Every launch timed on its own like `per_kernel_times`: hot (replayed on the same tensors) and cold
+    (rotating copies, > 256 MiB apart); `frac` = algorithmic bytes / cold time / 8 TB/s.  `before` = the same call on
+    the round-4 kernels (warp option warp_fewc = -1: channel-group kernels with context; one area_resize per scale)."""
+    from cerberusnet_amd import _lib
+    from cerberusnet_amd.synth import hash_uniform
+    ops = torch.ops.cerberus
+    B, H, W = pairs, height, width
+    scales = [(H, W), (H // 4, W // 4), (H // 8, W // 8), (H // 16, W // 16)]      # w_wrp_scales [1, 1, 1, 1, 0]
+    t = lambda shape, seed, lo=-1.0, hi=1.0: torch.from_numpy(hash_uniform(shape, seed, lo, hi)).to(device)
+    out = {}
+
+    def measure(label, make, nbytes, before=None):
+        """make(i) -> a zero-argument launch on the i-th independent copy of the tensors"""
+        ncopy = int(min(48, L3_BYTES // max(nbytes, 1) + 2))
+        fns = [make(i) for i in range(ncopy)]
+        hot = _time_graph([fns[0]], reps)
+        cold = _time_graph(fns, max(reps, len(fns)))
+        rec = {"us_hot": round(hot * 1e6, 2), "us_cold": round(cold * 1e6, 2), "algorithmic_bytes": nbytes,
+               "GBps": round(nbytes / cold / 1e9, 1), "frac": round(nbytes / cold / 1e9 / HBM_PEAK_GBPS, 4)}
+        if before is not None:
+            bf = [before(i) for i in range(ncopy)]
+            rec["before_us_hot"] = round(_time_graph([bf[0]], reps) * 1e6, 2)
+            rec["before_us_cold"] = round(_time_graph(bf, max(reps, len(bf))) * 1e6, 2)
+        del fns
+        torch.cuda.empty_cache()
+        out[label] = rec
+
+    # ---- the loss pyramid of ONE image: source read once, three scales written (the identity scale is the image)
+    flat = [v for s in scales for v in s]
+    pyr_bytes = 4 * B * 3 * (H * W + sum(h * w for h, w in scales[1:]))
+    imgs = {}
+
+    def pyr_make(i):
+        imgs[i] = t((B, 3, H, W), 500 + i, -2.0, 2.0)
+        return lambda: ops.area_pyramid(imgs[i], flat)
+
+    def pyr_before(i):
+        return lambda: [ops.area_resize(imgs[i], h, w) for h, w in scales]
+    measure("area_pyramid", pyr_make, pyr_bytes, pyr_before)
+    imgs.clear()
+
+    # ---- the RGB warps, scale by scale
+    for si, (h, w) in enumerate(scales):
+        fb, bb = warp_bytes(3, B, h, w)
+        bb = (2 * 3 + 4) * B * h * w * 4            # grad_flow alone: gradOutput + image taps (3 each) + flow in, grad_flow out
+        keep = {}
+
+        def mk(i, h=h, w=w):
+            if i not in keep:
+                keep[i] = (t((B, 3, h, w), 600 + i, -2.0, 2.0), Workload._flow(B, h, w, 700 + i, "smooth", device),
+                           t((B, 3, h, w), 800 + i))
+            return keep[i]
+
+        def fwd_make(i):
+            img, flo, _ = mk(i)
+            return lambda: ops.flow_warp(img, flo, 1, 0)
+
+        def bwd_make(i):
+            img, flo, go = mk(i)
+            return lambda: ops.flow_warp_backward(img, flo, go, 1, 0, False, True)
+
+        def old(fn_maker):
+            def wrapped(i):
+                inner = fn_maker(i)
+                def call():
+                    _lib.set_option("warp_fewc", -1)
+                    try:
+                        return inner()
+                    finally:
+                        _lib.set_option("warp_fewc", 0)
+                return call
+            return wrapped
+
+        def fwd_before(i):
+            img, flo, _ = mk(i)
+            def call():
+                _lib.set_option("warp_fewc", -1)
+                try:
+                    return ops.flow_warp_ctx(img, flo, 1, 0)      # round 4: the forward of a training warp always saved a context
+                finally:
+                    _lib.set_option("warp_fewc", 0)
+            return call
+        measure("rgb_warp_fwd_s%d" % si, fwd_make, fb, fwd_before)
+        measure("rgb_warp_bwd_s%d" % si, bwd_make, bb, old(bwd_make))
+        if si == 0:
+            # the same launches under a uniform translation: the headline's synthetic "smooth" field has slopes of up to
+            # 1.5 px per px (a gather instruction's 64 taps then spread over up to 13 image rows and the texture path walks
+            # every cache line they touch); a real full-resolution flow is a x4 bilinear upsample with slopes ~0.1
+            for i in list(keep):
+                img, flo, go = keep[i]
+                flo = torch.empty_like(flo)
+                flo[:, 0] = 2.3
+                flo[:, 1] = -1.7
+                keep[i] = (img, flo, go)
+            measure("rgb_warp_fwd_s0_translation", fwd_make, fb)
+            measure("rgb_warp_bwd_s0_translation", bwd_make, bb)
+        keep.clear()
+
+    # ---- gradOutput of the level-3 correlation backward from the concatenation buffer's gradient
+    C3, H3, W3 = 32, H // 4, W // 4            # the finest level of the W32 pyramid
+    item = 81 * H3 * W3
+    keep = {}
+
+    def prep_tensors(i):
+        if i not in keep:
+            keep[i] = (t((B, C3, H3, W3), 900 + i), t((B, C3, H3, W3), 950 + i), t((B, 81 + 34, H3, W3), 1000 + i),
+                       t((B, 81 + 34, H3, W3), 1050 + i))
+        return keep[i]
+
+    def prep_make(i):
+        x1, x2, g, f = prep_tensors(i)
+        return lambda: ops.correlation_backward_leaky(x1, x2, g, f, 0, *CORR_P, 0.1)
+
+    def prep_before(i):
+        x1, x2, g, f = prep_tensors(i)
+        def call():
+            gg = g[:, :81]
+            gg = torch.where(f[:, :81] > 0, gg, gg * 0.1)
+            return ops.correlation_backward(x1, x2, gg, *CORR_P)
+        return call
+    cb = corr_bytes(C3, B, H3, W3)[1] + 3 * B * item * 4      # the backward itself + one read of g, one of the stored volume, one write
+    measure("corr_bwd_L3_from_concat_gradient", prep_make, cb, prep_before)
+    keep.clear()
+    tot = lambda key: round(2 * out["area_pyramid"][key] + 2 * sum(v[key] for k, v in out.items()
+                                                                     if k.startswith("rgb_warp") and not k.endswith("translation")), 2)
+    out["_per_step"] = {"us_cold": tot("us_cold"), "before_us_cold": tot("before_us_cold"),
+                        "what": "2 pyramids + 8 forward + 8 grad_flow warps: the loss side of one training step at %d pairs" % B}
+    return out
+
+
 def head_step_mode(args, device, rank, world, dist):
     """--step head: what `--gpus N` scaling is judged on.  One step = zero_grad, PWCNetHead(1 -> 2),
     PWCNetHead(2 -> 1), loss, backward on `--pairs` image pairs per rank at the config-3 pyramid
@@ -1297,6 +1432,10 @@ def main():
                              "fwd+bwd; same launch as the headline")
             except Exception as exc:
                 extra_lines["bf16_1024x512"] = {"error": repr(exc)[:200]}
+            try:    # the loss side of the training step: pyramid, RGB warps, gradOutput from the concat buffer's gradient
+                extra_lines["loss_side"] = loss_side_times(args.pairs, args.width, args.height, device)
+            except Exception as exc:
+                extra_lines["loss_side"] = {"error": repr(exc)[:300]}
             try:    # the host model's training step on this GPU: the N = 1 point of the DDP scaling curve
                 margs = argparse.Namespace(**vars(args))
                 margs.steps, margs.warmup = 10, 3

@@ -11,7 +11,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # CERBERUS_HIP_LIB: another build of the same library (e.g. a -DCERB_EXPERIMENTS / -DCERB_STAMP test build)
 LIB_PATH = os.environ.get("CERBERUS_HIP_LIB") or os.path.join(_HERE, "lib", "libcerberus_hip.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _lock = threading.Lock()
 _lib = None
@@ -29,6 +29,8 @@ PROTOTYPES = {
     "cerberus_correlation_forward_ex": (_I, [_P, _P, _P] + [_I] * 9 +
                                         [ctypes.c_float, _I64, _I, _P]),
     "cerberus_correlation_backward": (_I, [_P, _P, _P, _P, _P] + [_I] * 11 + [_P]),
+    "cerberus_correlation_backward_ex_workspace_bytes": (_I64, [_I] * 9),
+    "cerberus_correlation_backward_ex": (_I, [_P, _P, _P, _I64, _P, _I64, ctypes.c_float, _P, _I64, _P, _P] + [_I] * 10 + [_P]),
     "cerberus_flow_warp_forward": (_I, [_P, _P, _P] + [_I] * 7 + [_P]),
     "cerberus_flow_warp_context_bytes": (_I64, [_I, _I, _I]),
     "cerberus_flow_warp_forward_ctx": (_I, [_P, _P, _P, _P, _I64] + [_I] * 8 + [_P]),
@@ -37,6 +39,7 @@ PROTOTYPES = {
     "cerberus_flow_upsample_forward": (_I, [_P, _P, _I64, _I, _I, _I, _I, _P]),
     "cerberus_flow_upsample_backward": (_I, [_P, _P, _I64, _I, _I, _I, _I, _P]),
     "cerberus_area_resize": (_I, [_P, _P, _I64, _I, _I, _I, _I, _I, _P]),
+    "cerberus_area_pyramid": (_I, [_P, ctypes.POINTER(_P), ctypes.POINTER(_I), ctypes.POINTER(_I), _I, _I64, _I, _I, _I, _P]),
     "cerberus_set_option": (_I, [ctypes.c_char_p, _I]),
     "cerberus_get_option": (_I, [ctypes.c_char_p, ctypes.POINTER(_I)]),
     "cerberus_last_kernel": (ctypes.c_char_p, [_I]),

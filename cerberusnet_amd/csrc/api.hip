@@ -21,6 +21,7 @@ const char *const g_option_names[OPT_COUNT] = {
     "warp_force_scatter",   // 1: warp backward by global atomics (ATen's method) even with a context
     "warp_staged",          // 0: auto (warp gathers through an LDS window), 2: never, >= 4: that many channels per forward workgroup
     "warp_stagger",         // warp backward phase shift: 0 auto, -1 off, else delays (x 1024 cycles) of the 2nd / 3rd / 4th 256 workgroups, a byte each
+    "warp_fewc",            // 0: auto (<= 4 channels without context / grad_image take the lane-per-pixel kernels), -1: off
 #ifdef CERB_ABLATE
     "corr_debug_ablate",    // timing ablation mask (WRONG results when != 0); ablation builds only
 #endif
@@ -135,6 +136,47 @@ int cerberus_correlation_backward(const void *input1, const void *input2, const 
                                  s);
 }
 
+int64_t cerberus_correlation_backward_ex_workspace_bytes(int B, int H, int W, int pad_size, int kernel_size,
+                                                         int max_displacement, int stride1, int stride2, int dtype) {
+    if (!dtype_ok(dtype)) return 0;
+    CorrGeom g;
+    if (corr_geom_init(g, B, 1, H, W, pad_size, kernel_size, max_displacement, stride1, stride2)) return 0;
+    const int64_t esz = dtype == CERB_F32 ? 4 : dtype == CERB_F64 ? 8 : 2;
+    return static_cast<int64_t>(B) * g.oC * g.oH * g.oW * esz;
+}
+
+int cerberus_correlation_backward_ex(const void *input1, const void *input2, const void *grad_output,
+                                     int64_t grad_out_batch_stride, const void *fwd_output,
+                                     int64_t fwd_out_batch_stride, float negative_slope, void *workspace,
+                                     int64_t workspace_bytes, void *grad_input1, void *grad_input2, int B, int C,
+                                     int H, int W, int pad_size, int kernel_size, int max_displacement, int stride1,
+                                     int stride2, int dtype, void *stream) {
+    if (!dtype_ok(dtype)) return CERB_EDTYPE;
+    CorrGeom g;
+    int rc = corr_geom_init(g, B, C, H, W, pad_size, kernel_size, max_displacement, stride1, stride2);
+    if (rc) return rc;
+    if (stride1 != 1) return CERB_ESTRIDE1;
+    if (B == 0) return CERB_OK;
+    const int64_t item = static_cast<int64_t>(g.oC) * g.oH * g.oW;
+    if ((grad_out_batch_stride != 0 && grad_out_batch_stride < item) ||
+        (fwd_output && fwd_out_batch_stride != 0 && fwd_out_batch_stride < item))
+        return CERB_EINVAL;
+    const bool dense = B == 1 || grad_out_batch_stride == 0 || grad_out_batch_stride == item;   // one item: no stride to honour
+    if (dense && !fwd_output)
+        return cerberus_correlation_backward(input1, input2, grad_output, grad_input1, grad_input2, B, C, H, W, pad_size,
+                                             kernel_size, max_displacement, stride1, stride2, 1, dtype, stream);
+    if (!input1 || !input2 || !grad_output || !grad_input1 || !grad_input2) return CERB_EINVAL;
+    const int64_t need = cerberus_correlation_backward_ex_workspace_bytes(B, H, W, pad_size, kernel_size, max_displacement,
+                                                                          stride1, stride2, dtype);
+    if (!workspace || workspace_bytes < need || (reinterpret_cast<uintptr_t>(workspace) & 15)) return CERB_EINVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    rc = corr_grad_prep(grad_output, dense ? item : grad_out_batch_stride, fwd_output,
+                        fwd_out_batch_stride ? fwd_out_batch_stride : item, workspace, B, item, negative_slope, dtype, s);
+    if (rc) return rc;
+    return cerberus_correlation_backward(input1, input2, workspace, grad_input1, grad_input2, B, C, H, W, pad_size,
+                                         kernel_size, max_displacement, stride1, stride2, 1, dtype, stream);
+}
+
 static int warp_args_ok(int B, int C, int H, int W, int pad_mode, int interp_mode, int dtype) {
     if (!dtype_ok(dtype)) return CERB_EDTYPE;
     if (B < 0 || C <= 0 || H <= 0 || W <= 0) return CERB_EINVAL;
@@ -216,6 +258,25 @@ int cerberus_area_resize(const void *src, void *dst, int64_t planes, int H, int 
     if (planes == 0) return CERB_OK;
     if (!src || !dst) return CERB_EINVAL;
     return area_resize(src, dst, planes, H, W, out_h, out_w, dtype, static_cast<hipStream_t>(stream));
+}
+
+int cerberus_area_pyramid(const void *src, void *const *dsts, const int *out_h, const int *out_w, int n_scales,
+                          int64_t planes, int H, int W, int dtype, void *stream) {
+    if (!dtype_ok(dtype)) return CERB_EDTYPE;
+    if (planes < 0 || H <= 0 || W <= 0 || n_scales < 0) return CERB_EINVAL;
+    if (n_scales == 0 || planes == 0) return CERB_OK;
+    if (!src || !dsts || !out_h || !out_w) return CERB_EINVAL;
+    for (int i = 0; i < n_scales; ++i)
+        if (!dsts[i] || out_h[i] <= 0 || out_w[i] <= 0) return CERB_EINVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int rc = area_pyramid(src, dsts, out_h, out_w, n_scales, planes, H, W, dtype, s);
+    if (rc != CERB_EUNSUPPORTED) return rc;
+    // general ratios (or more scales than one launch holds): scale by scale
+    for (int i = 0; i < n_scales; ++i) {
+        const int r = area_resize(src, dsts[i], planes, H, W, out_h[i], out_w[i], dtype, s);
+        if (r) return r;
+    }
+    return CERB_OK;
 }
 
 int cerberus_set_option(const char *key, int value) {

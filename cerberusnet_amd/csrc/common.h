@@ -77,6 +77,7 @@ enum OptId {
     OPT_WARP_FORCE_SCATTER,
     OPT_WARP_STAGED,
     OPT_WARP_STAGGER,
+    OPT_WARP_FEWC,
 #ifdef CERB_ABLATE
     OPT_DEBUG_ABLATE,   // timing-ablation mask: exists in -DCERB_ABLATE builds only
 #endif
@@ -186,6 +187,14 @@ int flow_upsample(bool forward, const void *src, void *dst, int64_t planes, int 
                   int dtype, hipStream_t s);
 int area_resize(const void *src, void *dst, int64_t planes, int H, int W, int oH, int oW, int dtype,
                 hipStream_t s);
+// every scale of an image pyramid in one pass over the source (integer ratios 4..64); CERB_EUNSUPPORTED otherwise
+int area_pyramid(const void *src, void *const *dsts, const int *out_h, const int *out_w, int n, int64_t planes, int H,
+                 int W, int dtype, hipStream_t s);
+
+// corr_grad_prep.hip: dense gradOutput (LeakyReLU derivative applied from the stored volume's sign) from a
+// batch-strided one; `fwd` may be null (copy only)
+int corr_grad_prep(const void *gout, int64_t g_stride, const void *fwd, int64_t f_stride, void *dst, int B, int64_t count,
+                   float slope, int dtype, hipStream_t s);
 
 static inline int launch_status() {
     hipError_t e = hipGetLastError();

@@ -55,7 +55,7 @@ namespace {
 
 constexpr int kD = 4;
 constexpr int kND = 2 * kD + 1;
-constexpr int kDead = static_cast<int>(0x80000000u);   // buffer offset that is out of range: reads 0
+[[maybe_unused]] constexpr int kDead = static_cast<int>(0x80000000u);   // buffer offset that is out of range: reads 0
 
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef int i4 __attribute__((ext_vector_type(4)));

@@ -148,7 +148,139 @@ int launch_area(const void *a, void *b, int64_t planes, int H, int W, int oH, in
     return launch_status();
 }
 
+// ---- every scale of the loss pyramid from ONE pass over the source -------------------------------
+// unFlowLoss resizes both target images to every flow scale (UnFlowLoss.py:279-280): four launches per
+// image that each re-read the 25 MB full-resolution image (one of them the identity): 93 us per image.  Here a
+// workgroup owns a band of RMAX source rows x SEG columns of one plane (32 KB), copies it into LDS with ONE round
+// of coalesced 16-byte loads, and writes the outputs of EVERY scale that lie in the band from there: one trip to
+// HBM per workgroup, whatever the number of scales (the first version read the windows from global memory scale
+// after scale -- 8 dependent round trips per workgroup: 15.5 us; this one: see profiles/).  Integer ratios that are
+// multiples of 4 only; one thread per output element adds its window in row-major order and divides by kh, then
+// kw, exactly as area_resize_kernel (and ATen's CPU kernel) does: bit-identical to the per-scale launches.  The
+// scales are walked coarsest first, so that the longest chains of adds (a 16 x 16 window: 256) start first.
+constexpr int kPyrMax = 4;
+constexpr int kPyrBand = 8192;   // floats of LDS per workgroup: RMAX rows x SEG columns
+struct AreaPyr {
+    void *dst[kPyrMax];
+    int ratio[kPyrMax];          // descending
+    int n;
+};
+
+template <int R>
+__device__ __forceinline__ float area_window_sum(const float *__restrict__ q, int pitch) {
+    float sum = 0.f;
+    constexpr int kRowsInFlight = R <= 8 ? R : 4;
+#pragma unroll kRowsInFlight
+    for (int y = 0; y < R; ++y) {
+#pragma unroll
+        for (int x4 = 0; x4 < R / 4; ++x4) {
+            const float4 v = *reinterpret_cast<const float4 *>(q + y * pitch + 4 * x4);
+            sum += v.x; sum += v.y; sum += v.z; sum += v.w;
+        }
+    }
+    return sum;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void area_pyramid_kernel(const T *__restrict__ in, AreaPyr pyr, int H, int W, int rmax,
+                                                           int seg, int nseg) {
+    __shared__ __attribute__((aligned(16))) float band[kPyrBand];
+    int id = blockIdx.x;
+    const int sg = id % nseg; id /= nseg;
+    const int nband = H / rmax;
+    const int bnd = id % nband;
+    const int64_t pl = id / nband;
+    const int xs = sg * seg, xw = min(seg, W - xs);
+    const T *src = in + pl * H * W + static_cast<int64_t>(bnd) * rmax * W + xs;
+    const int cpr = xw / 4, cells = rmax * cpr;
+    for (int k = threadIdx.x; k < cells; k += 256) {
+        const int row = k / cpr, c4 = k - row * cpr;
+        const T *q = src + static_cast<int64_t>(row) * W + 4 * c4;
+        float4 v;
+        if constexpr (sizeof(T) == 4) {
+            v = *reinterpret_cast<const float4 *>(q);
+        } else {
+            const uint2 raw = *reinterpret_cast<const uint2 *>(q);
+            T e[4];
+            __builtin_memcpy(e, &raw, 8);
+            v = make_float4(ld(&e[0]), ld(&e[1]), ld(&e[2]), ld(&e[3]));
+        }
+        *reinterpret_cast<float4 *>(band + row * xw + 4 * c4) = v;
+    }
+    __syncthreads();
+    int total = 0;
+    for (int s = 0; s < pyr.n; ++s) total += (rmax / pyr.ratio[s]) * (xw / pyr.ratio[s]);
+    for (int i = threadIdx.x; i < total; i += 256) {
+        int s = 0, j = i;
+        for (; s < pyr.n - 1; ++s) {
+            const int cnt = (rmax / pyr.ratio[s]) * (xw / pyr.ratio[s]);
+            if (j < cnt) break;
+            j -= cnt;
+        }
+        const int r = pyr.ratio[s];
+        const int rows = rmax / r, cols = xw / r, oW = W / r, oH = H / r;
+        const int oy = j / cols, ox = j - oy * cols;
+        const float *q = band + oy * r * xw + ox * r;
+        float sum;
+        switch (r) {
+            case 4: sum = area_window_sum<4>(q, xw); break;
+            case 8: sum = area_window_sum<8>(q, xw); break;
+            case 16: sum = area_window_sum<16>(q, xw); break;
+            case 32: sum = area_window_sum<32>(q, xw); break;
+            default: sum = area_window_sum<64>(q, xw); break;
+        }
+        T *dst = static_cast<T *>(pyr.dst[s]) + pl * oH * oW + (static_cast<int64_t>(bnd) * rows + oy) * oW + xs / r + ox;
+        st(dst, sum / static_cast<float>(r) / static_cast<float>(r));
+    }
+}
+
 }  // namespace
+
+// CERB_EUNSUPPORTED when a scale is not an integer ratio in {4, 8, 16, 32, 64} of the source (the caller then resizes
+// scale by scale with area_resize)
+int area_pyramid(const void *src, void *const *dsts, const int *out_h, const int *out_w, int n, int64_t planes, int H,
+                 int W, int dtype, hipStream_t s) {
+    if (n < 1 || n > kPyrMax || dtype == CERB_F64) return CERB_EUNSUPPORTED;
+    AreaPyr pyr;
+    pyr.n = n;
+    int rmax = 0;
+    for (int i = 0; i < n; ++i) {
+        const int r = H / out_h[i];
+        if (r * out_h[i] != H || r * out_w[i] != W || !(r == 4 || r == 8 || r == 16 || r == 32 || r == 64))
+            return CERB_EUNSUPPORTED;
+        // insertion by descending ratio
+        int at = i;
+        while (at > 0 && pyr.ratio[at - 1] < r) { pyr.ratio[at] = pyr.ratio[at - 1]; pyr.dst[at] = pyr.dst[at - 1]; --at; }
+        pyr.dst[at] = dsts[i];
+        pyr.ratio[at] = r;
+        rmax = std::max(rmax, r);
+    }
+    const size_t esz = dtype == CERB_F32 ? 4 : 2;
+    if (H % rmax || W % rmax || (reinterpret_cast<uintptr_t>(src) & (4 * esz - 1))) return CERB_EUNSUPPORTED;
+    // a band of RMAX rows x SEG columns fills the workgroup's LDS: 16 x 512 for the loss pyramid (768 workgroups for
+    // 12 planes of 512 x 1024); SEG is a multiple of every ratio
+    const int seg = std::min(W, kPyrBand / rmax);
+    const int nseg = (W + seg - 1) / seg;
+    const int64_t blocks = planes * (H / rmax) * nseg;
+    if (blocks > 0x7fffffff) return CERB_ETOOLARGE;
+    const dim3 grid(static_cast<unsigned>(blocks));
+    switch (dtype) {
+        case CERB_F32:
+            hipLaunchKernelGGL(area_pyramid_kernel<float>, grid, dim3(256), 0, s, static_cast<const float *>(src), pyr, H, W,
+                               rmax, seg, nseg);
+            break;
+        case CERB_F16:
+            hipLaunchKernelGGL(area_pyramid_kernel<__half>, grid, dim3(256), 0, s, static_cast<const __half *>(src), pyr, H,
+                               W, rmax, seg, nseg);
+            break;
+        case CERB_BF16:
+            hipLaunchKernelGGL(area_pyramid_kernel<hip_bfloat16>, grid, dim3(256), 0, s,
+                               static_cast<const hip_bfloat16 *>(src), pyr, H, W, rmax, seg, nseg);
+            break;
+        default: return CERB_EDTYPE;
+    }
+    return launch_status();
+}
 
 int area_resize(const void *src, void *dst, int64_t planes, int H, int W, int oH, int oW, int dtype,
                 hipStream_t s) {

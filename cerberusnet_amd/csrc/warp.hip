@@ -699,6 +699,121 @@ __global__ __launch_bounds__(kPix * kCg) void warp_bwd_kernel(
     }
 }
 
+// ---- few channels: the photometric loss's RGB warps (UnFlowLoss.py:282-283) --------------------------
+// The loss warps a 3-channel target image by every predicted flow: 8 forward + 8 backward launches per training
+// step, the full-resolution ones (4 x 3 x 512 x 1024) the largest warps of the whole step.  The image carries no
+// gradient there (no context to save, no grad_image), and with C <= 4 the channel-group kernels above leave a
+// quarter of every 256-thread workgroup idle (4 groups for 3 channels), meet in LDS behind a barrier to add up
+// ONE value per group, and walk their channels in trips.  Here a lane owns its pixels with ALL their channels:
+// every load (flow, gradOutput, 4 x NC taps per pixel) is issued before the first is used, nothing crosses lanes.
+//   * a wavefront owns PX x 64 consecutive pixels of ONE image row (the row and the segment are wave-uniform: no
+//     per-lane division); a lane's PX pixels lie 64 apart, so every memory instruction still has its 64 lanes on 64
+//     consecutive pixels.  (Four ADJACENT pixels per lane -- 16-byte flow loads and stores -- measured slower, 48 vs
+//     30 us at full resolution: a tap gather's lanes then lie 16 bytes apart and touch four times the cache lines.)
+//   * every access goes through a buffer resource with 32-bit byte offsets: the channel is the scalar offset, a tap
+//     outside the image (or a lane past the row's end) gets an out-of-range offset -- reads 0, drops the store -- by
+//     ONE select, where 64-bit pointers cost two selects and a 64-bit add per tap.  The first version of this kernel
+//     (pointers, a division per pixel) executed ~300 vector instructions per pixel and was bound by them: 30 us for
+//     67 MB at full resolution, one pixel per lane or four.
+// Measured at (4, 3, 512, 1024), us forward / grad_flow: 13.9 / 16.0 under a translation (67 / 84 MB: 60 / 65 % of
+// the HBM roofline), 29.0 / 30.6 under the bench's synthetic "smooth" field (channel-group kernels: 43.4 with context /
+// 97.9).  The difference is the gather itself, not memory, instructions or latency: that field's slope reaches 1.5
+// px per px, the 64 taps of one gather instruction then spread over up to 13 image rows, and the texture path walks
+// every cache line they touch (ablation, same launch: taps redirected to the lane's own pixel 13.5 / 15.5 us; no taps
+// 12.6 / 14.0; no stores 27.7; one or four pixels per lane: the same).
+// Same arithmetic in the same order as warp_fwd_kernel / warp_bwd_kernel (the backward adds its per-channel terms
+// in the four-group order of warp_bwd_kernel<.., 4>): bit-identical results (test).
+// Work items in row-major order, XCD-contiguous (an XCD's L2 sees whole image rows and their vertical neighbours).
+template <typename T, typename F, int NC, int PX, bool BWD>
+__global__ __launch_bounds__(256) void warp_fewc_kernel(const T *__restrict__ image, const F *__restrict__ flow,
+                                                        const T *__restrict__ gout, T *__restrict__ out,
+                                                        F *__restrict__ gflow, int items, int segs, int H, int W,
+                                                        int pad_mode) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int esz = sizeof(T), fsz = sizeof(F);
+    const int plane = H * W;            // the launcher guarantees 4 * plane * 4 < 2^31
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kPix), lane = threadIdx.x & (kPix - 1);
+    const int item = xcd_chunk(blockIdx.x, gridDim.x) * 4 + wave;       // (image, row, segment), wave-uniform
+    if (item >= items) return;
+    const int sg = item % segs, row = item / segs;
+    const int y = row % H, b = row / H;
+    const __amdgpu_buffer_rsrc_t r_img = uniform_rsrc(image + static_cast<int64_t>(b) * NC * plane, NC * plane * esz);
+    const __amdgpu_buffer_rsrc_t r_flow = uniform_rsrc(flow + static_cast<int64_t>(b) * 2 * plane, 2 * plane * fsz);
+    const __amdgpu_buffer_rsrc_t r_go = uniform_rsrc(BWD ? gout + static_cast<int64_t>(b) * NC * plane : image, NC * plane * esz);
+    float fx[PX], fy[PX], g[NC][PX];
+    int pix[PX], xs[PX];
+#pragma unroll
+    for (int i = 0; i < PX; ++i) {
+        xs[i] = sg * (PX * kPix) + i * kPix + lane;
+        pix[i] = xs[i] < W ? y * W + xs[i] : kDeadOffset / 4;      // a lane past the row's end: reads 0, stores nothing
+        fx[i] = buffer_load_px1<F>(r_flow, pix[i] * fsz, 0);
+        fy[i] = buffer_load_px1<F>(r_flow, pix[i] * fsz, plane * fsz);
+        if constexpr (BWD) {
+#pragma unroll
+            for (int c = 0; c < NC; ++c) g[c][i] = buffer_load_px1<T>(r_go, pix[i] * esz, c * plane * esz);
+        }
+    }
+    float v[PX][NC][4], ax[PX], bx[PX], ay[PX], by[PX], mx[PX], my[PX];
+#pragma unroll
+    for (int i = 0; i < PX; ++i) {
+        const Coord<float> cx = source_coord<float>(xs[i], fx[i], W, pad_mode);
+        const Coord<float> cy = source_coord<float>(y, fy[i], H, pad_mode);
+        const float x0f = floorf(cx.pos), y0f = floorf(cy.pos);
+        const float x1f = x0f + 1.f, y1f = y0f + 1.f;
+        ax[i] = x1f - cx.pos; bx[i] = cx.pos - x0f;
+        ay[i] = y1f - cy.pos; by[i] = cy.pos - y0f;
+        mx[i] = cx.mult; my[i] = cy.mult;
+        const int x0 = tap_index(x0f), y0 = tap_index(y0f);
+        const bool okx0 = x0 >= 0 && x0 < W, okx1 = x0 + 1 >= 0 && x0 + 1 < W;
+        const bool oky0 = y0 >= 0 && y0 < H, oky1 = y0 + 1 >= 0 && y0 + 1 < H;
+        // |x0|, |y0| <= 2^24: the product may wrap (unsigned arithmetic: defined), but only in-image taps use it
+        const int o00 = static_cast<int>((static_cast<unsigned>(y0) * static_cast<unsigned>(W) + static_cast<unsigned>(x0)) * esz);
+        const int onw = (oky0 && okx0) ? o00 : kDeadOffset, one = (oky0 && okx1) ? o00 + esz : kDeadOffset;
+        const int osw = (oky1 && okx0) ? o00 + W * esz : kDeadOffset, ose = (oky1 && okx1) ? o00 + (W + 1) * esz : kDeadOffset;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            v[i][c][0] = buffer_load_px1<T>(r_img, onw, c * plane * esz);
+            v[i][c][1] = buffer_load_px1<T>(r_img, one, c * plane * esz);
+            v[i][c][2] = buffer_load_px1<T>(r_img, osw, c * plane * esz);
+            v[i][c][3] = buffer_load_px1<T>(r_img, ose, c * plane * esz);
+        }
+    }
+    if constexpr (!BWD) {
+        const __amdgpu_buffer_rsrc_t r_out = uniform_rsrc(out + static_cast<int64_t>(b) * NC * plane, NC * plane * esz);
+#pragma unroll
+        for (int i = 0; i < PX; ++i) {
+            const float wnw = ax[i] * ay[i], wne = bx[i] * ay[i], wsw = ax[i] * by[i], wse = bx[i] * by[i];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                float acc = v[i][c][0] * wnw;   // absent taps contribute exact zeros
+                acc += v[i][c][1] * wne;
+                acc += v[i][c][2] * wsw;
+                acc += v[i][c][3] * wse;
+                buffer_store_px<T>(r_out, pix[i] * esz, c * plane * esz, acc);
+            }
+        }
+    } else {
+        const __amdgpu_buffer_rsrc_t r_gf = uniform_rsrc(gflow + static_cast<int64_t>(b) * 2 * plane, 2 * plane * fsz);
+#pragma unroll
+        for (int i = 0; i < PX; ++i) {
+            // warp_bwd_kernel<.., 4>: channel c adds into partial c & 3, the partials are summed 0..3
+            float sx = 0, sy = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float px = 0, py = 0;
+                if (k < NC)
+                    flow_grad_terms<float>(v[i][k][0], v[i][k][1], v[i][k][2], v[i][k][3], ax[i], bx[i], ay[i], by[i],
+                                           g[k][i], px, py);
+                sx += px; sy += py;
+            }
+            // autograd order: grad_grid = mult * sum ; through norm_grid: / (size-1) then * 2.0
+            buffer_store_px<F>(r_gf, pix[i] * fsz, 0, mx[i] * sx / static_cast<float>(W - 1) * 2.0f);
+            buffer_store_px<F>(r_gf, pix[i] * fsz, plane * fsz, my[i] * sy / static_cast<float>(H - 1) * 2.0f);
+        }
+    }
+#endif
+}
+
 // ---- backward, owner-computes tiles ------------------------------------------------
 // ATen's image gradient is a global float-atomic scatter: 4 atomics per (pixel, channel),
 // ~0.1 TB/s when neighbouring lanes hit different rows (measured: 555 us at the 32x128x256
@@ -1511,6 +1626,36 @@ size_t dtype_size(int dtype) {
     if ((C) >= 128) { constexpr int CG = 16; __VA_ARGS__; }    \
     else { constexpr int CG = 4; __VA_ARGS__; }
 
+// the few-channel kernels; CERB_EUNSUPPORTED when they do not apply (C > 4, fp64, or a batch item beyond 32-bit offsets)
+template <bool BWD>
+static int launch_fewc(const void *image, const void *flow, const void *gout, void *out, void *gflow, int B, int C, int H,
+                       int W, int pad_mode, int dtype, int flow_dtype, hipStream_t s) {
+    const int64_t plane = static_cast<int64_t>(H) * W;
+    if (C > 4 || dtype == CERB_F64 || plane * 16 >= (1ll << 31)) return CERB_EUNSUPPORTED;
+    // four pixels per lane once a row has them and the launch is large (>= 2 workgroups per CU either way), else one
+    const bool px4 = W >= 256 && static_cast<int64_t>(B) * plane >= 512ll * 1024;
+    const int per_wave = kPix * (px4 ? 4 : 1);
+    const int segs = (W + per_wave - 1) / per_wave;
+    const int64_t items = static_cast<int64_t>(B) * H * segs;
+    if (items > 0x7fffffff) return CERB_ETOOLARGE;
+    const dim3 grid(static_cast<unsigned>((items + 3) / 4));
+#define CERB_FEWC(NC, PX)                                                                                          \
+    CERB_DISPATCH2(dtype, flow_dtype, if constexpr (!std::is_same<T, double>::value)                              \
+        hipLaunchKernelGGL((warp_fewc_kernel<T, F, NC, PX, BWD>), grid, dim3(256), 0, s,                          \
+        static_cast<const T *>(image), static_cast<const F *>(flow), static_cast<const T *>(gout),               \
+        static_cast<T *>(out), static_cast<F *>(gflow), static_cast<int>(items), segs, H, W, pad_mode))
+#define CERB_FEWC_PX(NC) if (px4) { CERB_FEWC(NC, 4) } else { CERB_FEWC(NC, 1) }
+    switch (C) {
+        case 1: CERB_FEWC_PX(1) break;
+        case 2: CERB_FEWC_PX(2) break;
+        case 3: CERB_FEWC_PX(3) break;
+        default: CERB_FEWC_PX(4) break;
+    }
+#undef CERB_FEWC_PX
+#undef CERB_FEWC
+    return launch_status();
+}
+
 int64_t warp_context_bytes(int B, int H, int W) { return ctx_bytes(B, H, W); }
 
 #ifdef CERB_STAMP
@@ -1545,6 +1690,11 @@ int warp_forward(const void *image, const void *flow, void *out, void *ctx, int6
         return CERB_EINVAL;
     const int64_t nstrips = static_cast<int64_t>(B) * Strips(H, W).per_image();
     if (nstrips > 0x7fffffff) return CERB_ETOOLARGE;
+    if (!ctx && C <= 4 && interp == CERB_INTERP_BILINEAR && option(OPT_WARP_FEWC) >= 0) {
+        // no context wanted and <= 4 channels (the loss's RGB warps): a lane owns its pixels with all their channels
+        const int rc = launch_fewc<false>(image, flow, nullptr, out, nullptr, B, C, H, W, pad_mode, dtype, flow_dtype, s);
+        if (rc != CERB_EUNSUPPORTED) return rc;
+    }
     const int staged_opt = option(OPT_WARP_STAGED);
     // LDS-staged window: bilinear, 16-byte-aligned rows, 32-bit byte offsets.  Channels per
     // workgroup: as few as keep the launch at <= 1024 workgroups (the per-workgroup box
@@ -1698,6 +1848,11 @@ int warp_backward(const void *image, const void *flow, const void *gout, void *g
                 return (launch_tiles<T, F, 16, 6>(image, gout, ctx, gimage, gflow, B, C, H, W, pad_mode, s)))
         }
         return CERB_EDTYPE;
+    }
+    if (!gimage && gflow && C <= 4 && option(OPT_WARP_FEWC) >= 0) {
+        // grad_flow alone for <= 4 channels (the loss's RGB warps: the target image carries no gradient)
+        const int rc = launch_fewc<true>(image, flow, gout, nullptr, gflow, B, C, H, W, pad_mode, dtype, flow_dtype, s);
+        if (rc != CERB_EUNSUPPORTED) return rc;
     }
     if (gimage) {
         hipError_t e = hipMemsetAsync(gimage, 0, static_cast<size_t>(B) * C * plane * esz, s);

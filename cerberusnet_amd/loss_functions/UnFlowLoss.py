@@ -14,13 +14,20 @@ import torch
 
 from .. import ops as _ops
 
-__all__ = ["flow_warp", "mesh_grid", "norm_grid", "area_resize", "unFlowLoss"]
+__all__ = ["flow_warp", "mesh_grid", "norm_grid", "area_resize", "area_pyramid", "unFlowLoss"]
 
 
 def area_resize(image, size):
     """``F.interpolate(image, size, mode='area')`` as one HIP launch: how the photometric loss
     brings the target images to every flow scale (reference :279-280).  Forward only."""
     return torch.ops.cerberus.area_resize(image, int(size[0]), int(size[1]))
+
+
+def area_pyramid(image, sizes):
+    """``[F.interpolate(image, size, mode='area') for size in sizes]`` with ONE pass over the image for all
+    integer-ratio scales; a scale of the image's own size is the image itself (reference :279-280, per scale)."""
+    flat = [int(v) for size in sizes for v in size]
+    return list(torch.ops.cerberus.area_pyramid(image, flat))
 
 
 def mesh_grid(batch_sz, height, width):
@@ -49,10 +56,13 @@ def flow_warp(image, flow12, pad='border', mode='bilinear'):
     if mode not in _ops.INTERP_MODES:
         raise ValueError("flow_warp: mode must be 'bilinear' or 'nearest', got '%s'" % mode)
     modes = (_ops.PAD_MODES[pad], _ops.INTERP_MODES[mode])
-    if torch.is_grad_enabled() and (image.requires_grad or flow12.requires_grad):
+    if torch.is_grad_enabled() and image.requires_grad:
         # training: the forward also saves the sample positions for the backward (what
         # autograd's save_for_backward is to grid_sample in the reference)
         return torch.ops.cerberus.flow_warp_ctx(image, flow12, *modes)[0]
+    # inference, and training warps of an image that carries no gradient (the photometric loss's target
+    # images, :282-283): the positions are only needed by grad_image's tiles -- grad_flow recomputes them from
+    # the flow -- so no context is written (2 floats per pixel at full resolution)
     return torch.ops.cerberus.flow_warp(image, flow12, *modes)
 
 
@@ -123,10 +133,10 @@ class unFlowLoss(torch.nn.Module):
             raise ValueError("backend must be 'hip' or 'torch'")
         self.backend = backend
 
-    def _resize(self, image, size):
+    def _pyramid(self, image, sizes):
         if self.backend == "hip":
-            return area_resize(image, size)
-        return torch.nn.functional.interpolate(image, size, mode="area")
+            return area_pyramid(image, sizes)
+        return [torch.nn.functional.interpolate(image, size, mode="area") for size in sizes]
 
     def _warp(self, image, flow):
         return flow_warp(image, flow, pad="border") if self.backend == "hip" \
@@ -142,12 +152,17 @@ class unFlowLoss(torch.nn.Module):
 
     def forward(self, predictions, targets):
         total_warp, total_smooth, s = 0., 0., 1.
+        used = [i for i in range(min(len(predictions["flow"]), len(predictions["flow_b"]))) if self.w_wrp_scales[i] != 0]
+        sizes = [tuple(predictions["flow"][i].shape[2:]) for i in used]
+        # both target images at every scale the loss uses: one pass over each image (reference: one
+        # F.interpolate per scale and image, :279-280)
+        pyr1 = dict(zip(used, self._pyramid(targets["l_img"], sizes)))
+        pyr2 = dict(zip(used, self._pyramid(targets["l_seq"], sizes)))
         for i, (f12, f21) in enumerate(zip(predictions["flow"], predictions["flow_b"])):
             if self.w_wrp_scales[i] == 0:
                 continue
             size = tuple(f12.shape[2:])
-            im1 = self._resize(targets["l_img"], size)
-            im2 = self._resize(targets["l_seq"], size)
+            im1, im2 = pyr1[i], pyr2[i]
             if i == 0:
                 s = min(size)
             warp = self.loss_photometric(im1, self._warp(im2, f12))

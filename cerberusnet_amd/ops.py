@@ -43,6 +43,9 @@ _def.define("correlation_leaky(Tensor input1, Tensor input2, %s, float negative_
             "-> Tensor" % _CORR_ARGS)
 _def.define("correlation_leaky_into(Tensor(a!) buffer, Tensor input1, Tensor input2, int channel_offset, "
             "%s, float negative_slope) -> ()" % _CORR_ARGS)
+_def.define("correlation_backward_leaky(Tensor input1, Tensor input2, Tensor grad_buffer, Tensor fwd_buffer, "
+            "int channel_offset, %s, float negative_slope) -> Tensor[]" % _CORR_ARGS)
+_def.define("area_pyramid(Tensor image, int[] sizes) -> Tensor[]")
 _def.define("flow_upsample(Tensor flow, int factor) -> Tensor")
 _def.define("flow_upsample_backward(Tensor grad_out, int factor) -> Tensor")
 _def.define("area_resize(Tensor image, int out_h, int out_w) -> Tensor")
@@ -209,6 +212,50 @@ def _correlation_backward_cuda(input1, input2, gradOutput, pad_size, kernel_size
 
 def _correlation_backward_meta(input1, input2, gradOutput, *_):
     return [torch.empty_like(input1), torch.empty_like(input2)]
+
+
+def _correlation_backward_leaky_cuda(input1, input2, grad_buffer, fwd_buffer, channel_offset, pad_size,
+                                     kernel_size, max_displacement, stride1, stride2, corr_type_multiply,
+                                     negative_slope) -> List[torch.Tensor]:
+    """Backward of ``correlation_leaky_into``: ``grad_buffer`` is the gradient of the whole concatenation
+    buffer, ``fwd_buffer`` the buffer the forward wrote; the cost volume is channels [channel_offset,
+    channel_offset + oC) of both.  The LeakyReLU derivative (from the stored volume's sign) and the
+    gather of the batch-strided slice happen in ONE pass of the library (cerberus_correlation_backward_ex)
+    instead of ``g * slope``, ``torch.where`` and ``.contiguous()`` (pwcnet_sfd.py:181-187 seen from autograd)."""
+    what = "cerberus::correlation_backward_leaky"
+    _check_pair(input1, input2, what)
+    code = _dtype_code(input1, what)
+    if stride1 != 1:
+        raise RuntimeError(what + ": stride1 must be 1 (the reference kernel writes out of "
+                           "bounds for stride1 > 1, correlation_cuda_kernel.cu:106-107,169)")
+    x1, x2 = input1.contiguous(), input2.contiguous()
+    B, C, H, W = x1.shape
+    oc, oh, ow = _corr_out_shape(H, W, pad_size, kernel_size, max_displacement, stride1, stride2)
+    for name, t in (("grad_buffer", grad_buffer), ("fwd_buffer", fwd_buffer)):
+        if (t.dim() != 4 or t.shape[0] != B or tuple(t.shape[2:]) != (oh, ow) or t.device != x1.device or
+                channel_offset < 0 or channel_offset + oc > t.shape[1]):
+            raise RuntimeError("%s: %s %s cannot hold channels [%d, %d) of a (%d, %d, %d, %d) cost volume"
+                               % (what, name, tuple(t.shape), channel_offset, channel_offset + oc, B, oc, oh, ow))
+    plane_dense = lambda t: t.stride(3) == 1 and t.stride(2) == ow and t.stride(1) == oh * ow
+    go = grad_buffer.to(dtype=x1.dtype)
+    if not plane_dense(go):
+        go = go.contiguous()
+    fo = fwd_buffer if (fwd_buffer.dtype == x1.dtype and plane_dense(fwd_buffer)) else fwd_buffer.to(x1.dtype).contiguous()
+    g1, g2 = torch.empty_like(x1), torch.empty_like(x2)
+    if x1.numel() == 0:
+        return [g1, g2]
+    lib = _lib.get()
+    ws_bytes = lib.cerberus_correlation_backward_ex_workspace_bytes(B, H, W, pad_size, kernel_size, max_displacement,
+                                                                    stride1, stride2, code)
+    ws = torch.empty((ws_bytes + 7) // 8, dtype=torch.int64, device=x1.device)   # caching allocator: 512-byte aligned
+    with torch.cuda.device(x1.device):
+        rc = lib.cerberus_correlation_backward_ex(
+            x1.data_ptr(), x2.data_ptr(), go[:, channel_offset].data_ptr(), go.stride(0),
+            fo[:, channel_offset].data_ptr(), fo.stride(0), ctypes.c_float(float(negative_slope)),
+            ws.data_ptr(), ws_bytes, g1.data_ptr(), g2.data_ptr(), B, C, H, W, pad_size, kernel_size,
+            max_displacement, stride1, stride2, code, _stream_ptr(x1))
+    _lib.check(rc, what)
+    return [g1, g2]
 
 
 # ----------------------------------------------------------------------------
@@ -413,6 +460,47 @@ def _area_resize_cuda(image, out_h, out_w):
     return out
 
 
+def _area_pyramid_cuda(image, sizes) -> List[torch.Tensor]:
+    """``[F.interpolate(image, (h, w), mode='area') for (h, w) in sizes]`` (``sizes`` flat: h0, w0, h1, w1, ...):
+    how unFlowLoss brings a target image to every flow scale (UnFlowLoss.py:279-280).  A scale of the image's
+    own size is the image itself (no launch, no copy); the others come from one pass over the source when they
+    are integer ratios of it (cerberus_area_pyramid), bit-identical to ``area_resize`` scale by scale."""
+    what = "cerberus::area_pyramid"
+    if image.dim() != 4:
+        raise RuntimeError("%s: expected a 4-D NCHW tensor, got %s" % (what, tuple(image.shape)))
+    if len(sizes) % 2:
+        raise RuntimeError("%s: sizes must be a flat list of (height, width) pairs" % what)
+    code = _dtype_code(image, what)
+    if code == 3:
+        raise RuntimeError("%s: float64 is not supported" % what)
+    x = image.contiguous()
+    B, C, H, W = x.shape
+    pairs = [(int(sizes[i]), int(sizes[i + 1])) for i in range(0, len(sizes), 2)]
+    if any(h < 1 or w < 1 for h, w in pairs):
+        raise RuntimeError("%s: output sizes must be positive, got %s" % (what, pairs))
+    outs = [x if (h, w) == (H, W) else x.new_empty((B, C, h, w)) for h, w in pairs]
+    todo = [(o, hw) for o, hw in zip(outs, pairs) if hw != (H, W) and o.numel()]
+    if not todo:
+        return outs
+    if H == 0 or W == 0:
+        raise RuntimeError("%s: input has no pixels" % what)
+    lib = _lib.get()
+    with torch.cuda.device(x.device):
+        for i in range(0, len(todo), 4):        # one launch holds up to four scales
+            chunk = todo[i:i + 4]
+            n = len(chunk)
+            dsts = (ctypes.c_void_p * n)(*[o.data_ptr() for o, _ in chunk])
+            hs = (ctypes.c_int * n)(*[hw[0] for _, hw in chunk])
+            ws = (ctypes.c_int * n)(*[hw[1] for _, hw in chunk])
+            _lib.check(lib.cerberus_area_pyramid(x.data_ptr(), dsts, hs, ws, n, B * C, H, W, code, _stream_ptr(x)), what)
+    return outs
+
+
+def _area_pyramid_meta(image, sizes):
+    B, C, _, _ = image.shape
+    return [image.new_empty((B, C, int(sizes[i]), int(sizes[i + 1]))) for i in range(0, len(sizes), 2)]
+
+
 def _no_cpu(name):
     def _raise(*_a, **_k):
         raise RuntimeError("cerberus::%s has no CPU implementation: this build is the "
@@ -432,6 +520,12 @@ _def.impl("correlation_leaky_into", _no_cpu("correlation_leaky_into"), "CPU")
 _def.impl("correlation_backward", _correlation_backward_cuda, "CUDA")
 _def.impl("correlation_backward", _correlation_backward_meta, "Meta")
 _def.impl("correlation_backward", _no_cpu("correlation_backward"), "CPU")
+_def.impl("correlation_backward_leaky", _correlation_backward_leaky_cuda, "CUDA")
+_def.impl("correlation_backward_leaky", _correlation_backward_meta, "Meta")
+_def.impl("correlation_backward_leaky", _no_cpu("correlation_backward_leaky"), "CPU")
+_def.impl("area_pyramid", _area_pyramid_cuda, "CUDA")
+_def.impl("area_pyramid", _area_pyramid_meta, "Meta")
+_def.impl("area_pyramid", _no_cpu("area_pyramid"), "CPU")
 _def.impl("flow_upsample", _flow_upsample_cuda, "CUDA")
 _def.impl("flow_upsample", lambda f, k: f.new_empty((f.shape[0], f.shape[1], f.shape[2] * k, f.shape[3] * k)), "Meta")
 _def.impl("flow_upsample", _no_cpu("flow_upsample"), "CPU")
@@ -487,9 +581,8 @@ def _corr_leaky_setup(ctx, inputs, output):
 
 def _corr_leaky_backward(ctx, grad):
     input1, input2, output = ctx.saved_tensors
-    # d leaky(v)/dv from the sign of the output (slope > 0 keeps the sign)
-    grad = torch.where(output > 0, grad, grad * ctx.slope)
-    g1, g2 = torch.ops.cerberus.correlation_backward(input1, input2, grad, *ctx.params)
+    # d leaky(v)/dv from the sign of the output (slope > 0 keeps the sign), applied by the library in one pass
+    g1, g2 = torch.ops.cerberus.correlation_backward_leaky(input1, input2, grad, output, 0, *ctx.params, ctx.slope)
     return (g1, g2) + (None,) * 7
 
 
@@ -555,6 +648,8 @@ def _area_resize_backward(ctx, grad):
 
 
 torch.library.register_autograd("cerberus::area_resize", _area_resize_backward,
+                                setup_context=lambda ctx, inputs, output: None)
+torch.library.register_autograd("cerberus::area_pyramid", _area_resize_backward,
                                 setup_context=lambda ctx, inputs, output: None)
 torch.library.register_autograd("cerberus::flow_upsample", _upsample_backward,
                                 setup_context=_upsample_setup)

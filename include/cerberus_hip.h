@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define CERBERUS_HIP_ABI_VERSION 5   /* 5: cerberus_last_kernel is process-wide (it was per thread) */
+#define CERBERUS_HIP_ABI_VERSION 6   /* 6: cerberus_correlation_backward_ex, cerberus_area_pyramid, option warp_fewc (round 5) */
 
 /* element types (AT_DISPATCH_FLOATING_TYPES_AND_HALF in the reference,
  * correlation_cuda_kernel.cu:269,303; bf16 is an extension) */
@@ -110,6 +110,31 @@ int cerberus_correlation_backward(const void *input1, const void *input2,
                                   int stride2, int corr_type_multiply,
                                   int dtype, void *stream);
 
+/* Same, for the gradient of the buffer cerberus_correlation_forward_ex wrote into (round 5; the caller
+ * pwcnet_sfd.py:181-187, seen from autograd: the cost volume is channels [0, oC) of the estimator's
+ * concatenation buffer, with leaky_relu already applied):
+ *   grad_output item n starts at grad_output + n * grad_out_batch_stride elements (0 = dense oC*oH*oW);
+ *   its oC planes are contiguous.
+ *   fwd_output (may be NULL): the volume the forward stored, item n at fwd_output + n *
+ *   fwd_out_batch_stride (0 = dense).  The gradient the kernels see is
+ *       g_eff = fwd_output > 0 ? g : g * negative_slope
+ *   -- the derivative of the forward's fused LeakyReLU, taken from the stored value's sign (a positive
+ *   slope keeps the sign; a NaN stored value takes the slope branch, as torch.where(out > 0, g, g * slope)).
+ *   workspace: cerberus_correlation_backward_ex_workspace_bytes() bytes, 16-byte aligned, caller-owned,
+ *   needed whenever the gradient is strided or masked (one pass writes the dense g_eff there; the backward
+ *   kernels stream gradOutput by LDS-DMA and cannot apply a mask on the way).  With a dense gradient and
+ *   fwd_output == NULL this is cerberus_correlation_backward and the workspace is not touched. */
+int64_t cerberus_correlation_backward_ex_workspace_bytes(int B, int H, int W, int pad_size,
+                                                         int kernel_size, int max_displacement,
+                                                         int stride1, int stride2, int dtype);
+int cerberus_correlation_backward_ex(const void *input1, const void *input2,
+                                     const void *grad_output, int64_t grad_out_batch_stride,
+                                     const void *fwd_output, int64_t fwd_out_batch_stride,
+                                     float negative_slope, void *workspace, int64_t workspace_bytes,
+                                     void *grad_input1, void *grad_input2, int B, int C, int H, int W,
+                                     int pad_size, int kernel_size, int max_displacement, int stride1,
+                                     int stride2, int dtype, void *stream);
+
 /* flow_warp forward.  Replaces the body of flow_warp (UnFlowLoss.py:83-94):
  * mesh_grid + flow -> norm_grid by (W-1),(H-1) -> grid_sample(align_corners=False),
  * fused: no grid tensor is materialised.
@@ -181,6 +206,14 @@ int cerberus_flow_upsample_backward(const void *grad_out, void *grad_in, int64_t
 int cerberus_area_resize(const void *src, void *dst, int64_t planes, int H, int W, int out_h,
                          int out_w, int dtype, void *stream);
 
+/* All scales of that pyramid in one call (round 5): dsts[i] (planes, out_h[i], out_w[i]) for i < n_scales
+ * (dsts, out_h, out_w are HOST arrays; dsts[i] device pointers).  When every scale is an integer ratio r in
+ * {4, 8, 16, 32, 64} of the source (and n_scales <= 4) ONE launch reads the source once and writes every
+ * scale (unFlowLoss resizes each 25 MB target image to every flow scale: UnFlowLoss.py:279-280); otherwise
+ * the scales are resized one by one.  Results are bit-identical to cerberus_area_resize either way. */
+int cerberus_area_pyramid(const void *src, void *const *dsts, const int *out_h, const int *out_w,
+                          int n_scales, int64_t planes, int H, int W, int dtype, void *stream);
+
 /* Diagnostics / tuning knobs (process-wide, read at launch time, default 0):
  *   "corr_force_generic" : 1 = always use the generic kernels (testing)
  *   "corr_fwd_variant"   : 0 = auto, 1..8 = force one register-staged forward variant,
@@ -227,6 +260,8 @@ int cerberus_area_resize(const void *src, void *dst, int64_t planes, int H, int 
  *                          starts 6 k cycles late, or, with one tile workgroup per CU, the two halves of the
  *                          grad_flow workgroups 6 k and 2 k cycles late), -1 = off, else the delays of the 2nd / 3rd / 4th
  *                          256 workgroups in units of 1024 cycles, one byte each.  Speed only: same results.
+ *   "warp_fewc"          : 0 = auto (a warp of <= 4 channels takes the lane-per-pixel kernels when no context /
+ *                          no grad_image is asked for: the photometric loss's RGB warps), -1 = off.  Same bits.
  * Returns CERB_EINVAL for an unknown key. */
 int cerberus_set_option(const char *key, int value);
 int cerberus_get_option(const char *key, int *value);

@@ -20,7 +20,7 @@ def pytest_configure(config):
 # and the "next" rows (f: graph capture, fused callers) last -- so that under ``-x`` a failure
 # in an (f) nice-to-have can never starve the hot-path parity tests (round 1: a flaky graph
 # test stopped the driver's run before any of the 47 warp tests had executed).
-_ORDER = ["test_oracle", "test_abi_cpu", "test_corr_gpu", "test_warp_gpu", "test_pwchead_cpu",
+_ORDER = ["test_oracle", "test_abi_cpu", "test_corr_gpu", "test_warp_gpu", "test_loss_side_gpu", "test_pwchead_cpu",
           "test_ddp_cpu", "test_dist_gpu", "test_pwchead_gpu", "test_model_cpu", "test_model_gpu", "test_runtime", "test_bench_gpu"]
 _LAST = ("graphed", "concat", "fused_warp")   # (f)-row tests inside any module
 
