@@ -172,6 +172,10 @@ int corr_coarse_backward(const void *in1, const void *in2, const void *gout, voi
 int corr_mfma_forward(const void *in1, const void *in2, void *out, const CorrGeom &g, float slope,
                       int64_t obs, int dtype, hipStream_t s);
 
+// fp32 forward as a persistent, cross-item pipelined grid (corr_fwd_pipe.hip); CERB_EUNSUPPORTED unless C % 8 == 0
+int corr_fwd_pipe(const void *in1, const void *in2, void *out, const CorrGeom &g, float slope, int64_t obs,
+                  hipStream_t s);
+
 int64_t warp_context_bytes(int B, int H, int W);
 int64_t warp_backward_workspace_bytes(int B, int C, int H, int W);
 int warp_forward(const void *image, const void *flow, void *out, void *ctx, int64_t ctx_size,

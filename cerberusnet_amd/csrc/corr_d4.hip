@@ -1917,6 +1917,14 @@ int fwd_dispatch(const void *x1, const void *x2, void *o, const CorrGeom &g, flo
                     return launch_fwd_dma<FwdDma4>("corr_fwd_d4_dma_4x64", x1, x2, o, g, slope, obs, s);
             }
             break;
+        case 17:   // the persistent, cross-item pipelined forward (corr_fwd_pipe.hip)
+            if constexpr (sizeof(T) == 4) {
+                if (vec && dma_ok(g)) {
+                    const int rc = corr_fwd_pipe(x1, x2, o, g, slope, obs, s);
+                    if (rc != CERB_EUNSUPPORTED) return rc;
+                }
+            }
+            break;
         case 10: case 11: case 12: case 13:
             if constexpr (sizeof(T) == 4) {
                 if (vec && dma_ok(g)) {
