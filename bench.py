@@ -163,6 +163,53 @@ class Workload:
             else:
                 keep.append(g2)
 
+    def _levels_fwd(self, lv, levels):
+        ops = torch.ops.cerberus
+        for l in levels:
+            t = lv[l]
+            if l > 0:
+                t["warped"], t["ctx"] = ops.flow_warp_ctx(t["f2"], t["flow"], 1, 0)
+            else:
+                t["warped"] = t["f2"]
+            t["out"] = ops.correlation(t["f1"], t["warped"], *CORR_P)
+
+    def _levels_bwd(self, lv, levels, keep):
+        ops = torch.ops.cerberus
+        for l in levels:
+            t = lv[l]
+            g1, g2 = ops.correlation_backward(t["f1"], t["warped"], t["gout"], *CORR_P)
+            keep.append(g1)
+            if l > 0:
+                keep += ops.flow_warp_backward_ctx(t["f2"], t["flow"], t["ctx"], g2, 1, 0, True, True)
+            else:
+                keep.append(g2)
+
+    def step_hybrid(self, streams, ncoarse=2):
+        """the two flow directions STACKED into one batched call per op on the `ncoarse` coarsest levels
+        (where a launch is priced by its latency, not its bytes: one launch instead of two), two streams above.  The
+        level order is the head's (coarse to fine forward, fine to coarse backward), so the stacked launches sit at
+        the two ends of the step."""
+        if getattr(self, "stacked", None) is None:
+            self.stacked = []
+            for a, b in zip(*self.dirs):
+                self.stacked.append({k: (torch.cat([a[k], b[k]], 0) if a[k] is not None else None)
+                                     for k in ("f1", "f2", "gout", "flow")})
+        keep = []
+        main = torch.cuda.current_stream()
+        n = len(self.levels)
+        coarse, fine = list(range(ncoarse)), list(range(ncoarse, n))
+        self._levels_fwd(self.stacked, coarse)
+        side = streams[0]
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            self._levels_fwd(self.dirs[1], fine)
+            self._levels_bwd(self.dirs[1], list(reversed(fine)), keep)
+        self._levels_fwd(self.dirs[0], fine)
+        self._levels_bwd(self.dirs[0], list(reversed(fine)), keep)
+        main.wait_stream(side)
+        self._levels_bwd(self.stacked, list(reversed(coarse)), keep)
+        return keep
+
     def serial_step(self, skip=None):
         """Both directions on the current stream; `skip` leaves one launch of direction 0 out."""
         keep = []
@@ -908,7 +955,16 @@ def model_step_mode(args, device, rank, world, dist, quiet=False):
     from cerberusnet_amd.nnet_models import CerberusBase, cerberus_flow_config
     from cerberusnet_amd.synth import fill_parameters, hash_uniform
     B, H, W = args.pairs, args.height, args.width
-    model = CerberusBase(**cerberus_flow_config()).to(device).train()
+    backend = getattr(args, "model_backend", "hip")          # "torch": the reference's own fallback ops (CorrelationTorch + grid_sample) on the GPU
+    if getattr(args, "miopen_find", False):
+        # MIOpen's find mode (what torch.backends.cudnn.benchmark means on ROCm): every convolution shape is timed
+        # once with a workspace it may use; without it PyTorch's immediate mode takes the solver of the find-db whose
+        # workspace it then cannot provide and falls back to GEMM (round 4's stderr: "IsEnoughWorkspace ...
+        # GemmBwdRest / GemmWrwUniversal" on every step)
+        torch.backends.cudnn.benchmark = True
+    model = CerberusBase(**cerberus_flow_config(correlation_backend=backend)).to(device).train()
+    if getattr(args, "channels_last", True):
+        model = model.to(memory_format=torch.channels_last)
     fill_parameters(model.backbone, 400)                  # the same weights on every rank
     fill_parameters(model.flow, 500)
     l_img = torch.from_numpy(hash_uniform((B, 3, H, W), 11 + 1000 * rank, -2.0, 2.0)).to(device)
@@ -916,7 +972,9 @@ def model_step_mode(args, device, rank, world, dist, quiet=False):
     # (CERB_FORCE_DIST=1 on one GPU: a one-rank RCCL group, the model really under DDP -- the self-test of this path)
     net = wrap_ddp(model, device, force=dist is not None, sync_bn=args.sync_bn) if dist is not None else model
     ddp = net is not model
-    loss_fn = unFlowLoss(weights={"l1": 0.15, "ssim": 0.85}, consistency=True)
+    loss_fn = unFlowLoss(weights={"l1": 0.15, "ssim": 0.85}, consistency=True, backend=backend)
+    if getattr(args, "channels_last", True):
+        l_img, l_seq = l_img.contiguous(memory_format=torch.channels_last), l_seq.contiguous(memory_format=torch.channels_last)
     params = [p for p in model.parameters() if p.requires_grad]
     opt = torch.optim.Adam(params, lr=1e-4, betas=(0.9, 0.99), weight_decay=1e-6)
     amp = args.dtype in ("f16", "bf16")
@@ -972,9 +1030,36 @@ def model_step_mode(args, device, rank, world, dist, quiet=False):
             single = {"pairs_per_s_per_gpu": round(B * args.steps / ds, 2), "ms_per_step": round(1e3 * ds / args.steps, 4),
                       "what": "the same training step on every rank's GPU with the gradient all-reduce switched off "
                               "(DistributedDataParallel.no_sync), slowest rank, timed after the DDP region: "
-                              "value / (n_gpus x this) is the scaling of the DDP step on this node"}
+                              "value / (n_gpus x this) is the scaling of the DDP step on this node"
+                              + ("; NOT collective-free: --sync-bn keeps SyncBatchNorm's all-reduces in this pass too" if args.sync_bn else "")
+                              + "; the optimizer steps on the rank's own (unreduced) gradients here: ranks diverge after this pass, which is why it runs last"}
         except Exception as exc:  # a side report: never fail the line on it
             single = {"error": repr(exc)[:200]}
+    # the same step with the hot-path ops swapped for the reference's own stock-PyTorch fallback (CorrelationTorch +
+    # grid_sample + F.interpolate: SURVEY 8(d) "the same model with the op swapped") and under bf16 autocast, in THIS process
+    # (same model, MIOpen's solvers already chosen): a side table, one rank only
+    table = None
+    if getattr(args, "model_table", False) and world == 1 and not ddp:
+        table = {}
+        head = model.flow
+        for tag, bk, dt_ in (("f32_hip", "hip", None), ("f32_torch", "torch", None), ("bf16_hip", "hip", torch.bfloat16),
+                             ("bf16_torch", "torch", torch.bfloat16)):
+            try:
+                head.correlation_backend, loss_fn.backend = bk, bk
+                amp, adt = dt_ is not None, dt_
+                scaler = torch.amp.GradScaler("cuda", enabled=False)
+                for _ in range(2):
+                    step()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(5):
+                    step()
+                torch.cuda.synchronize()
+                ms = (time.perf_counter() - t0) / 5 * 1e3
+                table[tag] = {"ms_per_step": round(ms, 2), "pairs_per_s": round(B / ms * 1e3, 2)}
+            except Exception as exc:
+                table[tag] = {"error": repr(exc)[:160]}
+        head.correlation_backend, loss_fn.backend = backend, backend
     if rank != 0:
         return None
     nparam = sum(p.numel() for p in params)
@@ -990,7 +1075,8 @@ def model_step_mode(args, device, rank, world, dist, quiet=False):
                         "%d synthetic %dx%d frame pairs per GPU: backbone on both frames, flow head in both directions, "
                         "unFlowLoss, backward, Adam%s" % (nparam, B, W, H, "; autocast " + args.dtype if amp else ""),
             "pairs_per_gpu": B, "frame": [H, W], "parameters": nparam, "gradient_bytes_per_step": 4 * nparam,
-            "launch": "eager",
+            "launch": "eager", "backend": backend, "miopen_find": bool(getattr(args, "miopen_find", False)),
+            "channels_last": bool(getattr(args, "channels_last", True)),
             "sharding": ("image pairs sharded over ranks; DistributedDataParallel over RCCL (64 MB buckets, static graph): "
                          "%.1f MB of gradients all-reduced inside every step, overlapped with backward" % (4e-6 * nparam)
                          if ddp else "one rank"),
@@ -1004,6 +1090,10 @@ def model_step_mode(args, device, rank, world, dist, quiet=False):
     }
     if single is not None:
         result["single_gpu_step"] = single
+    if table is not None:
+        result["backend_table"] = dict(table, what="5 steps each after 2 warm-up steps, same process and model: the hot-path ops as "
+                                       "this package's HIP kernels (hip) or as the reference's stock-PyTorch fallback on the same GPU "
+                                       "(torch: CorrelationTorch + grid_sample + F.interpolate), fp32 and bf16 autocast")
     if not quiet:
         print(json.dumps(result), flush=True)
     return result
@@ -1028,6 +1118,10 @@ def main():
     ap.add_argument("--no-stagger", action="store_true",
                     help="two streams: start both directions together (default: the second one forks after the first "
                          "direction's first launch, so that the streams pair different kernels)")
+    ap.add_argument("--stack-coarse", type=int, default=1, metavar="N",
+                    help="the two flow directions as ONE batched call per op on the N coarsest levels (where a launch is priced by "
+                         "its latency), two streams above (VERDICT r4 #8; default 1: level 0 stacked, -6.7 us per step; 2 loses; "
+                         "0 = rounds 1-4: every level on two streams)")
     ap.add_argument("--chains", type=int, default=1,
                     help="split each direction's batch into this many independent sub-batches, "
                          "one HIP stream each")
@@ -1057,6 +1151,18 @@ def main():
                          "gradient all-reduce runs inside the step it can hide behind")
     ap.add_argument("--stack-directions", action="store_true",
                     help="--step head: run both flow directions as one stacked pass (PWCNetHead.forward_both)")
+    ap.add_argument("--model-backend", choices=["hip", "torch"], default="hip",
+                    help="--step model: the hot-path ops of the host model: this package's HIP kernels, or the reference's "
+                         "own stock-PyTorch fallback (CorrelationTorch + grid_sample) on the same GPU")
+    ap.add_argument("--miopen-find", action="store_true",
+                    help="--step model: torch.backends.cudnn.benchmark = True (MIOpen find mode: ~4 minutes of solver "
+                         "compilation on a fresh box, then 147.8 instead of 172.6 ms per fp32 step, 134.5 instead of 147.1 bf16)")
+    ap.add_argument("--nchw", dest="channels_last", action="store_false",
+                    help="--step model: NCHW weights and inputs (round 4's layout: MIOpen's immediate mode then falls back to "
+                         "GEMM solvers with workspace warnings on every step and 16.6 ms per step go to layout transposes)")
+    ap.add_argument("--model-table", action="store_true",
+                    help="--step model at N = 1: after the timed region also time the step with the stock-PyTorch fallback ops and "
+                         "under bf16 autocast (`backend_table`)")
     ap.add_argument("--trace-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-cold", action="store_true", help="skip the cold (HBM-resident inputs) per-kernel pass")
     ap.add_argument("--sync-bn", action="store_true",
@@ -1135,20 +1241,22 @@ def main():
     # ---- warm-up (eager), then capture the step into a hipGraph ----
     streams = None if args.serial_directions else [torch.cuda.Stream()
                                                    for _ in range(max(1, len(wl.dirs) - 1))]
+    hybrid = bool(args.stack_coarse and streams and len(wl.dirs) == 2)
+    step_fn = (lambda: wl.step_hybrid(streams, args.stack_coarse)) if hybrid else (lambda: wl.step(streams))
     for _ in range(max(1, args.warmup if args.no_graph else 3)):
-        wl.step(streams)
+        step_fn()
     torch.cuda.synchronize()
     graph = None
     if not args.no_graph:
         cap = torch.cuda.Stream()
         cap.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(cap):
-            wl.step(streams)
+            step_fn()
         torch.cuda.current_stream().wait_stream(cap)
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
-            held = wl.step(streams)  # noqa: F841  keep outputs alive for the graph's pool
-    run = graph.replay if graph is not None else (lambda: wl.step(streams))
+            held = step_fn()  # noqa: F841  keep outputs alive for the graph's pool
+    run = graph.replay if graph is not None else step_fn
 
     # ---- per-kernel pass (rank 0 only): every launch of the step timed on its own ----
     # R back-to-back launches of ONE kernel are captured into a hipGraph (no host launch gaps between them) and
@@ -1289,10 +1397,13 @@ def main():
                             "directions, fwd+bwd" % (cfg, args.width, args.height, args.dtype, args.pairs),
                 "pairs_per_gpu": args.pairs, "levels_CHW": [list(s) for s in wl.levels],
                 "flow_field": args.flow,
+                "stack_coarse": args.stack_coarse if hybrid else 0,
                 "launch": ("hipGraph replay" if graph is not None else "eager") +
                           (", directions fused into one batched call" if args.fuse_directions else
                            ", %d streams (one per flow direction%s%s)" % (
                                len(streams) + 1, " and sub-batch" if args.chains > 1 else "",
+                               ("; the %d coarsest level(s) as one call for both directions (8 items) at the two ends of the step"
+                                % args.stack_coarse) if hybrid else
                                ", the second forks after the first one's first launch" if wl.stagger else "")
                            if streams else ", 1 stream"),
                 "sharding": ("image pairs sharded over ranks, no data-path collective in the ops; value = "
@@ -1439,8 +1550,11 @@ def main():
             try:    # the host model's training step on this GPU: the N = 1 point of the DDP scaling curve
                 margs = argparse.Namespace(**vars(args))
                 margs.steps, margs.warmup = 10, 3
+                margs.model_table = True
                 m = model_step_mode(margs, device, 0, 1, None, quiet=True)
                 extra_lines["model_step"] = {k: m[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup")}
+                extra_lines["model_step"]["backend_table"] = m.get("backend_table")
+                extra_lines["model_step"]["settings"] = {k: m["config"][k] for k in ("channels_last", "miopen_find", "backend")}
                 extra_lines["model_step"]["workload"] = m["config"]["workload"]
                 extra_lines["model_step"]["note"] = ("what `bench.py --gpus N` (N > 1) times per rank under "
                                                      "DistributedDataParallel; compare N > 1 lines with this figure")
