@@ -71,8 +71,9 @@ __device__ __forceinline__ void static_for(F &&f) {
 
 // SPR  4-pixel strips per image row (W = 4 * SPR); a wave holds RW = 64 / SPR lane-rows
 // NWV  waves per workgroup = channel groups of CW = 4 that share the gradOutput stream
-template <int SPR_, int NWV_, int FLAGS_ = 0, int CW_ = 4>
+template <int SPR_, int NWV_, int FLAGS_ = 0, int CW_ = 4, int NIT_ = 1>
 struct StripCfg {
+    static constexpr int NIT = NIT_;   // work items a workgroup walks one after the other (round 5 experiment: 2 -> half the grid)
     // timing-experiment flags (-DCERB_ABLATE builds): 1 gradOutput DMA non-temporal, 2 x loads non-temporal, 4 no FMAs,
     // 8 no loads / DMAs, 16 no LDS reads, 32 natural step order, 64 no step barrier, 256 no stores (all but 1, 2, 32: wrong results)
     static constexpr int FLAGS = FLAGS_;
@@ -83,7 +84,7 @@ struct StripCfg {
     static constexpr int NSLOT = 4;
     // waves per SIMD the register allocator leaves room for: two 8-wave workgroups per CU on the 256-wide level
     // (one round of 512 workgroups at 4 pairs); the narrower levels have fewer workgroups than that anyway
-    static constexpr int WPS = (SPR_ == 64 || CW_ < 4) ? 4 : 2;
+    static constexpr int WPS = NIT_ > 1 ? 2 : (SPR_ == 64 || CW_ < 4) ? 4 : 2;
     static constexpr int PITCH = W * 4;                  // bytes per staged gradOutput row
     static constexpr int ENTRY = RW * PITCH;             // one (j, dx) plane: RW rows
     static constexpr int SLOT = NR * kND * ENTRY;        // one step
@@ -294,7 +295,9 @@ void corr_bwd_d4_strip_kernel(const float *__restrict__ x1, const float *__restr
 
     // (row block, channel block, side) with the side fastest: the two workgroups that stream
     // the same gradOutput rows are neighbours in the XCD-contiguous order
-    int bid = xcd_chunk(blockIdx.x, gridDim.x);
+    for (int item = 0; item < K::NIT; ++item) {
+    if (K::NIT > 1 && item > 0) __builtin_amdgcn_s_barrier();   // the previous item's last slot has been read by every wave
+    int bid = xcd_chunk(blockIdx.x, gridDim.x) * K::NIT + item;
     const int side = __builtin_amdgcn_readfirstlane(bid & 1); bid >>= 1;
     const int cb = __builtin_amdgcn_readfirstlane(bid % ncb); bid /= ncb;
     const int yb = __builtin_amdgcn_readfirstlane(bid % nyb);
@@ -383,6 +386,7 @@ void corr_bwd_d4_strip_kernel(const float *__restrict__ x1, const float *__restr
     };
     if (side == 0) run(std::integral_constant<int, 0>{});
     else run(std::integral_constant<int, 1>{});
+    }
 #endif
 }
 
@@ -390,8 +394,10 @@ template <typename K>
 int launch_strip(const char *name, const void *in1, const void *in2, const void *goutp, void *g1p,
                  void *g2p, const CorrGeom &g, hipStream_t s) {
     const int nyb = g.H / K::ROWS, ncb = g.C / K::CWG;
-    const int64_t blocks = static_cast<int64_t>(g.B) * nyb * ncb * 2;
+    int64_t blocks = static_cast<int64_t>(g.B) * nyb * ncb * 2;
     if (blocks > 0x7fffffff) return CERB_ETOOLARGE;
+    if (blocks % K::NIT) return CERB_EUNSUPPORTED;
+    blocks /= K::NIT;
     static std::atomic<uint64_t> lds_done{0};
     int rc;
     if ((rc = ensure_lds(corr_bwd_d4_strip_kernel<K>, K::LDS_BYTES, &lds_done))) return rc;
@@ -446,6 +452,13 @@ int corr_strip_backward(const void *in1, const void *in2, const void *gout, void
             case 256: CERB_STRIP(64, 8, 256, "corr_bwd_d4_strip_w256_f256"); break;
             default: break;
         }
+#endif
+#ifdef CERB_EXPERIMENTS
+        // round 5, measured and rejected (profiles/r05_sol_skeleton.txt): every workgroup walks TWO items (both gradients of its
+        // rows and channels) on half the grid -- item 1's stores drain under item 2 -- at the 2 waves per SIMD that leaves:
+        // 41.9 vs 33.6 us at 4 pairs, 70.4 vs 66.3 at 8.  Test builds only.
+        if (option(OPT_CORR_BWD_CSLICE) == 2 && g.H % 2 == 0 && g.C % 32 == 0)
+            return launch_strip<StripCfg<64, 8, 0, 4, 2>>("corr_bwd_d4_strip_w256_2items", in1, in2, gout, gin1, gin2, g, s);
 #endif
         CERB_STRIP(64, 8, 0, "corr_bwd_d4_strip_w256");
     } else if (g.W == 128) {
