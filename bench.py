@@ -677,7 +677,7 @@ def loss_side_times(pairs, width, height, device, reps=12):
     from cerberusnet_amd.synth import hash_uniform
     ops = torch.ops.cerberus
     B, H, W = pairs, height, width
-    scales = [(H, W), (H // 4, W // 4), (H // 8, W // 8), (H // 16, W // 16)]      # w_wrp_scales [1, 1, 1, 1, 0]
+    scales = [(H, W), (H // 2, W // 2), (H // 4, W // 4), (H // 8, W // 8)]        # the flow list of the host model's head at this frame size (w_wrp_scales [1, 1, 1, 1, 0])
     t = lambda shape, seed, lo=-1.0, hi=1.0: torch.from_numpy(hash_uniform(shape, seed, lo, hi)).to(device)
     out = {}
 

@@ -36,22 +36,27 @@ __host__ __device__ inline float ratio(int in, int out) {
     return out > 1 ? static_cast<float>(in - 1) / static_cast<float>(out - 1) : 0.0f;
 }
 
+// One workgroup per output row (grid-stride over planes x rows): the row's vertical tap is wave-uniform, the index
+// arithmetic 32-bit (round 2 decomposed a 64-bit flat index per element: 22.6 us for the 16.8 MB of the x 4 upsample).
 template <typename T>
 __global__ __launch_bounds__(256) void upsample_fwd_kernel(const T *__restrict__ in, T *__restrict__ out,
                                                            int64_t planes, int H, int W, int oH, int oW,
                                                            float factor) {
     const float ry = ratio(H, oH), rx = ratio(W, oW);
-    const int64_t total = planes * oH * oW;
-    for (int64_t idx = blockIdx.x * 256ll + threadIdx.x; idx < total; idx += static_cast<int64_t>(gridDim.x) * 256) {
-        const int ox = static_cast<int>(idx % oW);
-        const int oy = static_cast<int>((idx / oW) % oH);
-        const int64_t pl = idx / (static_cast<int64_t>(oW) * oH);
-        const Tap ty = tap_of(oy, ry, H), tx = tap_of(ox, rx, W);
-        const T *p = in + pl * H * W;
-        const float v00 = ld(p + ty.i0 * W + tx.i0), v01 = ld(p + ty.i0 * W + tx.i1);
-        const float v10 = ld(p + ty.i1 * W + tx.i0), v11 = ld(p + ty.i1 * W + tx.i1);
-        const float v = ty.l0 * (tx.l0 * v00 + tx.l1 * v01) + ty.l1 * (tx.l0 * v10 + tx.l1 * v11);
-        st(out + idx, v * factor);
+    const int64_t rows = planes * oH;
+    for (int64_t row = blockIdx.x; row < rows; row += gridDim.x) {
+        const int oy = static_cast<int>(row % oH);
+        const int64_t pl = row / oH;
+        const Tap ty = tap_of(oy, ry, H);
+        const T *p0 = in + pl * H * W + static_cast<int64_t>(ty.i0) * W, *p1 = in + pl * H * W + static_cast<int64_t>(ty.i1) * W;
+        T *o = out + row * oW;
+        for (int ox = threadIdx.x; ox < oW; ox += 256) {
+            const Tap tx = tap_of(ox, rx, W);
+            const float v00 = ld(p0 + tx.i0), v01 = ld(p0 + tx.i1);
+            const float v10 = ld(p1 + tx.i0), v11 = ld(p1 + tx.i1);
+            const float v = ty.l0 * (tx.l0 * v00 + tx.l1 * v01) + ty.l1 * (tx.l0 * v10 + tx.l1 * v11);
+            st(o + ox, v * factor);
+        }
     }
 }
 
@@ -66,44 +71,159 @@ __device__ __forceinline__ int last_dst(int i, float r, int out) {
     return min(out - 1, static_cast<int>(ceilf(static_cast<float>(i + 1) / r)) + 1);
 }
 
+// Round 5: one workgroup per INPUT row (grid-stride over planes x rows).  The candidate output rows and their vertical
+// weights are the same for the whole row (wave-uniform, computed once), the taps of a thread's candidate columns are
+// computed once (they were recomputed for every candidate row: ~144 tap evaluations per element at factor 4), only the
+// matching columns are loaded, index arithmetic is 32-bit.  Same products, same order of additions: identical bits.
+// (In the host model's training step this kernel ran 14.8 times at 18.8 us on average -- the largest item of this
+// package's kernel time once the loss side was fixed: profiles/r05_kernel_stats_step_model.csv.)
+constexpr int kUpMaxCand = 16;   // candidate outputs per axis kept in registers: 2 * factor + 4 <= 16 up to factor 6
+constexpr int kUpMaxRows = 10;   // matching output rows staged in LDS (2 * factor + 1 <= 9 at factor 4)
+constexpr int kUpMaxW = 1024;    // widest output row the LDS copy takes (40 KB for the ten rows)
+
 template <typename T>
 __global__ __launch_bounds__(256) void upsample_bwd_kernel(const T *__restrict__ gout, T *__restrict__ gin,
                                                            int64_t planes, int H, int W, int oH, int oW,
                                                            float factor) {
+    __shared__ __attribute__((aligned(16))) float s_g[kUpMaxRows * kUpMaxW];
     const float ry = ratio(H, oH), rx = ratio(W, oW);
-    const int64_t total = planes * H * W;
-    for (int64_t idx = blockIdx.x * 256ll + threadIdx.x; idx < total; idx += static_cast<int64_t>(gridDim.x) * 256) {
-        const int x = static_cast<int>(idx % W);
-        const int y = static_cast<int>((idx / W) % H);
-        const int64_t pl = idx / (static_cast<int64_t>(W) * H);
+    const int64_t rows = planes * H;
+    for (int64_t rowi = blockIdx.x; rowi < rows; rowi += gridDim.x) {
+        const int y = static_cast<int>(rowi % H);
+        const int64_t pl = rowi / H;
         const T *g = gout + pl * oH * oW;
-        float acc = 0.f;
-        // candidate output rows / columns: every dst whose taps (i0, i1) contain this index;
-        // the exact taps are recomputed, so the conservative bounds only cost a few iterations
+        // candidate output rows: every dst whose taps (i0, i1) contain this row; the exact taps are recomputed, so the
+        // conservative bounds only cost a few iterations
         const int y_lo = first_dst(y, ry, oH), y_hi = last_dst(y, ry, oH);
-        const int x_lo = first_dst(x, rx, oW), x_hi = last_dst(x, rx, oW);
-        for (int oy = y_lo; oy <= y_hi; ++oy) {
-            const Tap ty = tap_of(oy, ry, H);
-            const float wy = (ty.i0 == y ? ty.l0 : 0.f) + (ty.i1 == y ? ty.l1 : 0.f);
-            if (ty.i0 != y && ty.i1 != y) continue;
-            float row = 0.f;
-            for (int ox = x_lo; ox <= x_hi; ++ox) {
-                const Tap tx = tap_of(ox, rx, W);
-                if (tx.i0 != x && tx.i1 != x) continue;
-                const float wx = (tx.i0 == x ? tx.l0 : 0.f) + (tx.i1 == x ? tx.l1 : 0.f);
-                row += wx * ld(g + oy * oW + ox);
+        // the matching output rows (wave-uniform), in ascending order: their gradient rows are copied into LDS with
+        // coalesced 16-byte loads -- a lane's candidate columns lie `factor` elements from its neighbour's, and read
+        // straight from global memory every gather instruction touched factor x the cache lines (24.8 us for the x 4
+        // upsample's 16.8 MB) -- and the gathers below read LDS.  Same values, same order: identical bits.
+        int nrow = 0;
+        __shared__ int s_row[kUpMaxRows];
+        __shared__ float s_wy[kUpMaxRows];
+        // (factor 2: the direct gather is as fast -- 9.4 vs 11.3 us at 4 x 2 x 128 x 256 -- and stays)
+        const bool staged = oW >= 3 * W && oW % 4 == 0 && oW <= kUpMaxW && (reinterpret_cast<uintptr_t>(gout) & (4 * sizeof(T) - 1)) == 0;
+        if (staged) {
+            for (int oy = y_lo; oy <= y_hi && nrow < kUpMaxRows + 1; ++oy) {
+                const Tap ty = tap_of(oy, ry, H);
+                if (ty.i0 != y && ty.i1 != y) continue;
+                if (nrow < kUpMaxRows && threadIdx.x == 0) {
+                    s_row[nrow] = oy;
+                    s_wy[nrow] = (ty.i0 == y ? ty.l0 : 0.f) + (ty.i1 == y ? ty.l1 : 0.f);
+                }
+                ++nrow;
             }
-            acc += wy * row;
         }
-        st(gin + idx, acc * factor);
+        if (staged && nrow <= kUpMaxRows) {
+            __syncthreads();              // s_row / s_wy written; the previous row's LDS reads are over
+            const int q4 = oW / 4;
+            for (int i = threadIdx.x; i < nrow * q4; i += 256) {
+                const int r = i / q4, c4 = i - r * q4;
+                const T *src = g + static_cast<int64_t>(s_row[r]) * oW + 4 * c4;
+                float4 v;
+                if constexpr (sizeof(T) == 4) {
+                    v = *reinterpret_cast<const float4 *>(src);
+                } else {
+                    const uint2 raw = *reinterpret_cast<const uint2 *>(src);
+                    T e[4];
+                    __builtin_memcpy(e, &raw, 8);
+                    v = make_float4(ld(&e[0]), ld(&e[1]), ld(&e[2]), ld(&e[3]));
+                }
+                *reinterpret_cast<float4 *>(s_g + r * kUpMaxW + 4 * c4) = v;
+            }
+            __syncthreads();
+            for (int x = threadIdx.x; x < W; x += 256) {
+                const int x_lo = first_dst(x, rx, oW), x_hi = last_dst(x, rx, oW);
+                float acc = 0.f;
+                if (x_hi - x_lo < kUpMaxCand) {
+                    float wx[kUpMaxCand];
+                    unsigned hits = 0;
+#pragma unroll
+                    for (int j = 0; j < kUpMaxCand; ++j) {
+                        const int ox = min(x_lo + j, oW - 1);
+                        const Tap tx = tap_of(ox, rx, W);
+                        const bool hit = x_lo + j <= x_hi && (tx.i0 == x || tx.i1 == x);
+                        wx[j] = (tx.i0 == x ? tx.l0 : 0.f) + (tx.i1 == x ? tx.l1 : 0.f);
+                        hits |= hit ? (1u << j) : 0u;
+                    }
+                    for (int r = 0; r < nrow; ++r) {
+                        const float *grow = s_g + r * kUpMaxW + x_lo;
+                        float row = 0.f;
+#pragma unroll
+                        for (int j = 0; j < kUpMaxCand; ++j)
+                            if ((hits >> j) & 1u) row += wx[j] * grow[j];
+                        acc += s_wy[r] * row;
+                    }
+                } else {
+                    for (int r = 0; r < nrow; ++r) {
+                        float row = 0.f;
+                        for (int ox = x_lo; ox <= x_hi; ++ox) {
+                            const Tap tx = tap_of(ox, rx, W);
+                            if (tx.i0 != x && tx.i1 != x) continue;
+                            const float wx = (tx.i0 == x ? tx.l0 : 0.f) + (tx.i1 == x ? tx.l1 : 0.f);
+                            row += wx * s_g[r * kUpMaxW + ox];
+                        }
+                        acc += s_wy[r] * row;
+                    }
+                }
+                st(gin + rowi * W + x, acc * factor);
+            }
+            __syncthreads();              // the next input row overwrites s_row / s_g
+            continue;
+        }
+        for (int x = threadIdx.x; x < W; x += 256) {
+            const int x_lo = first_dst(x, rx, oW), x_hi = last_dst(x, rx, oW);
+            float acc = 0.f;
+            if (x_hi - x_lo < kUpMaxCand) {
+                // column weights once; bit j of `hits`: candidate column x_lo + j has a tap on x
+                float wx[kUpMaxCand];
+                unsigned hits = 0;
+#pragma unroll
+                for (int j = 0; j < kUpMaxCand; ++j) {
+                    const int ox = min(x_lo + j, oW - 1);
+                    const Tap tx = tap_of(ox, rx, W);
+                    const bool hit = x_lo + j <= x_hi && (tx.i0 == x || tx.i1 == x);
+                    wx[j] = (tx.i0 == x ? tx.l0 : 0.f) + (tx.i1 == x ? tx.l1 : 0.f);
+                    hits |= hit ? (1u << j) : 0u;
+                }
+                for (int oy = y_lo; oy <= y_hi; ++oy) {
+                    const Tap ty = tap_of(oy, ry, H);
+                    if (ty.i0 != y && ty.i1 != y) continue;
+                    const float wy = (ty.i0 == y ? ty.l0 : 0.f) + (ty.i1 == y ? ty.l1 : 0.f);
+                    const T *grow = g + static_cast<int64_t>(oy) * oW + x_lo;
+                    float row = 0.f;
+#pragma unroll
+                    for (int j = 0; j < kUpMaxCand; ++j)
+                        if ((hits >> j) & 1u) row += wx[j] * ld(grow + j);
+                    acc += wy * row;
+                }
+            } else {
+                for (int oy = y_lo; oy <= y_hi; ++oy) {
+                    const Tap ty = tap_of(oy, ry, H);
+                    const float wy = (ty.i0 == y ? ty.l0 : 0.f) + (ty.i1 == y ? ty.l1 : 0.f);
+                    if (ty.i0 != y && ty.i1 != y) continue;
+                    float row = 0.f;
+                    for (int ox = x_lo; ox <= x_hi; ++ox) {
+                        const Tap tx = tap_of(ox, rx, W);
+                        if (tx.i0 != x && tx.i1 != x) continue;
+                        const float wx = (tx.i0 == x ? tx.l0 : 0.f) + (tx.i1 == x ? tx.l1 : 0.f);
+                        row += wx * ld(g + static_cast<int64_t>(oy) * oW + ox);
+                    }
+                    acc += wy * row;
+                }
+            }
+            st(gin + rowi * W + x, acc * factor);
+        }
     }
 }
 
 template <typename T>
 int launch(bool fwd, const void *a, void *b, int64_t planes, int H, int W, int oH, int oW, float factor,
            hipStream_t s) {
-    const int64_t total = planes * (fwd ? static_cast<int64_t>(oH) * oW : static_cast<int64_t>(H) * W);
-    const unsigned blocks = static_cast<unsigned>(std::min<int64_t>((total + 255) / 256, 8192));
+    // one workgroup per output row (forward) / input row (backward), grid-stride beyond 64 K rows
+    const int64_t rows = planes * (fwd ? oH : H);
+    const unsigned blocks = static_cast<unsigned>(std::max<int64_t>(1, std::min<int64_t>(rows, 65536)));
     if (fwd)
         hipLaunchKernelGGL(upsample_fwd_kernel<T>, dim3(blocks), dim3(256), 0, s, static_cast<const T *>(a),
                            static_cast<T *>(b), planes, H, W, oH, oW, factor);
@@ -154,8 +274,8 @@ int launch_area(const void *a, void *b, int64_t planes, int H, int W, int oH, in
 // workgroup owns a band of RMAX source rows x SEG columns of one plane (32 KB), copies it into LDS with ONE round
 // of coalesced 16-byte loads, and writes the outputs of EVERY scale that lie in the band from there: one trip to
 // HBM per workgroup, whatever the number of scales (the first version read the windows from global memory scale
-// after scale -- 8 dependent round trips per workgroup: 15.5 us; this one: see profiles/).  Integer ratios that are
-// multiples of 4 only; one thread per output element adds its window in row-major order and divides by kh, then
+// after scale -- 8 dependent round trips per workgroup: 15.5 us; this one: see profiles/).  Integer ratios 2, 4, ... 64
+// (the model's loss pyramid is 1/2, 1/4, 1/8 of the frame); one thread per output element adds its window in row-major order and divides by kh, then
 // kw, exactly as area_resize_kernel (and ATen's CPU kernel) does: bit-identical to the per-scale launches.  The
 // scales are walked coarsest first, so that the longest chains of adds (a 16 x 16 window: 256) start first.
 constexpr int kPyrMax = 4;
@@ -168,6 +288,12 @@ struct AreaPyr {
 
 template <int R>
 __device__ __forceinline__ float area_window_sum(const float *__restrict__ q, int pitch) {
+    if constexpr (R == 2) {
+        const float2 a = *reinterpret_cast<const float2 *>(q), b = *reinterpret_cast<const float2 *>(q + pitch);
+        float sum = 0.f;
+        sum += a.x; sum += a.y; sum += b.x; sum += b.y;
+        return sum;
+    }
     float sum = 0.f;
     constexpr int kRowsInFlight = R <= 8 ? R : 4;
 #pragma unroll kRowsInFlight
@@ -223,6 +349,7 @@ __global__ __launch_bounds__(256) void area_pyramid_kernel(const T *__restrict__
         const float *q = band + oy * r * xw + ox * r;
         float sum;
         switch (r) {
+            case 2: sum = area_window_sum<2>(q, xw); break;
             case 4: sum = area_window_sum<4>(q, xw); break;
             case 8: sum = area_window_sum<8>(q, xw); break;
             case 16: sum = area_window_sum<16>(q, xw); break;
@@ -236,7 +363,7 @@ __global__ __launch_bounds__(256) void area_pyramid_kernel(const T *__restrict__
 
 }  // namespace
 
-// CERB_EUNSUPPORTED when a scale is not an integer ratio in {4, 8, 16, 32, 64} of the source (the caller then resizes
+// CERB_EUNSUPPORTED when a scale is not an integer ratio in {2, 4, 8, 16, 32, 64} of the source (the caller then resizes
 // scale by scale with area_resize)
 int area_pyramid(const void *src, void *const *dsts, const int *out_h, const int *out_w, int n, int64_t planes, int H,
                  int W, int dtype, hipStream_t s) {
@@ -246,7 +373,7 @@ int area_pyramid(const void *src, void *const *dsts, const int *out_h, const int
     int rmax = 0;
     for (int i = 0; i < n; ++i) {
         const int r = H / out_h[i];
-        if (r * out_h[i] != H || r * out_w[i] != W || !(r == 4 || r == 8 || r == 16 || r == 32 || r == 64))
+        if (r * out_h[i] != H || r * out_w[i] != W || !(r == 2 || r == 4 || r == 8 || r == 16 || r == 32 || r == 64))
             return CERB_EUNSUPPORTED;
         // insertion by descending ratio
         int at = i;
@@ -256,7 +383,7 @@ int area_pyramid(const void *src, void *const *dsts, const int *out_h, const int
         rmax = std::max(rmax, r);
     }
     const size_t esz = dtype == CERB_F32 ? 4 : 2;
-    if (H % rmax || W % rmax || (reinterpret_cast<uintptr_t>(src) & (4 * esz - 1))) return CERB_EUNSUPPORTED;
+    if (H % rmax || W % rmax || W % 4 || (reinterpret_cast<uintptr_t>(src) & (4 * esz - 1))) return CERB_EUNSUPPORTED;
     // a band of RMAX rows x SEG columns fills the workgroup's LDS: 16 x 512 for the loss pyramid (768 workgroups for
     // 12 planes of 512 x 1024); SEG is a multiple of every ratio
     const int seg = std::min(W, kPyrBand / rmax);

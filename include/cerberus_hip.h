@@ -208,7 +208,7 @@ int cerberus_area_resize(const void *src, void *dst, int64_t planes, int H, int 
 
 /* All scales of that pyramid in one call (round 5): dsts[i] (planes, out_h[i], out_w[i]) for i < n_scales
  * (dsts, out_h, out_w are HOST arrays; dsts[i] device pointers).  When every scale is an integer ratio r in
- * {4, 8, 16, 32, 64} of the source (and n_scales <= 4) ONE launch reads the source once and writes every
+ * {2, 4, 8, 16, 32, 64} of the source (and n_scales <= 4) ONE launch reads the source once and writes every
  * scale (unFlowLoss resizes each 25 MB target image to every flow scale: UnFlowLoss.py:279-280); otherwise
  * the scales are resized one by one.  Results are bit-identical to cerberus_area_resize either way. */
 int cerberus_area_pyramid(const void *src, void *const *dsts, const int *out_h, const int *out_w,

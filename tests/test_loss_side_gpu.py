@@ -136,7 +136,7 @@ def test_full_resolution_loss_warp_every_item():
 # ---- the loss pyramid -----------------------------------------------------------------------------------------
 def test_area_pyramid_is_bit_identical_to_torch_cpu_per_scale():
     x = hash_uniform((2, 3, 512, 1024), 902, -2.0, 2.0)
-    sizes = [(512, 1024), (128, 256), (64, 128), (32, 64)]          # unFlowLoss's four scales (w_wrp_scales)
+    sizes = [(512, 1024), (256, 512), (128, 256), (64, 128)]        # unFlowLoss's four scales under the host model's head
     outs = ca.area_pyramid(dev(x), sizes)
     assert outs[0].data_ptr() != 0 and torch.equal(outs[0].cpu(), torch.from_numpy(x))     # identity: the image itself
     for o, size in zip(outs, sizes):
@@ -144,7 +144,7 @@ def test_area_pyramid_is_bit_identical_to_torch_cpu_per_scale():
         assert o.shape == ref.shape and torch.equal(o.cpu(), ref)
     # five scales incl. the coarsest one (two launches), a ragged width, and sizes the one-pass kernel does not take
     x2 = hash_uniform((1, 2, 128, 1280), 903, -2.0, 2.0)
-    for sizes in ([(32, 320), (16, 160), (8, 80), (4, 40), (2, 20)], [(64, 640), (32, 320)], [(100, 130), (32, 320)],
+    for sizes in ([(32, 320), (16, 160), (8, 80), (4, 40), (2, 20)], [(64, 640), (32, 320)], [(100, 130), (32, 320)], [(128, 640)],
                   [(7, 5)], []):
         outs = ca.area_pyramid(dev(x2), sizes)
         assert len(outs) == len(sizes)

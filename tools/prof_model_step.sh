@@ -1,10 +1,12 @@
 #!/bin/bash
 # GPU box: rocprofv3 kernel stats of the host model's training step (bench.py --step model): where its time goes
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+TAG=${1:-r05}
 mkdir -p gpurun_out/profiles
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/profiles/_model -- python3 bench.py --step model --steps 6 --warmup 2 > gpurun_out/profiles/r04_bench_under_rocprof_step_model.json 2> gpurun_out/profiles/_model.err
-python3 - <<'PY'
-import csv, glob, collections
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/profiles/_model -- python3 bench.py --step model --steps 6 --warmup 2 > gpurun_out/profiles/${TAG}_bench_under_rocprof_step_model.json 2> gpurun_out/profiles/_model.err
+python3 - "$TAG" <<'PY'
+import csv, glob, collections, sys
+tag = sys.argv[1]
 p = glob.glob("gpurun_out/profiles/_model/**/*kernel_trace.csv", recursive=True)[0]
 rows = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"]), r["Kernel_Name"]) for r in csv.DictReader(open(p))]
 rows.sort()
@@ -20,9 +22,9 @@ for _, d, n in win:
     acc[key][0] += 1; acc[key][1] += d
 tot = sum(v[1] for v in acc.values())
 span = (win[-1][0] + win[-1][1] - win[0][0])
-ours = {k: v for k, v in acc.items() if any(t in k for t in ("corr_fwd", "corr_bwd", "warp_fwd", "warp_bwd", "flow_upsample", "area_resize"))}
+ours = {k: v for k, v in acc.items() if "at::native" not in k and any(t in k for t in ("corr_fwd", "corr_bwd", "corr_grad_prep", "warp_fwd", "warp_bwd", "warp_fewc", "upsample_fwd_kernel", "upsample_bwd_kernel", "area_resize", "area_pyramid", "warp_context"))}
 top = sorted(acc.items(), key=lambda kv: -kv[1][1])
-out = open("gpurun_out/profiles/r04_kernel_stats_step_model.csv", "w")
+out = open("gpurun_out/profiles/%s_kernel_stats_step_model.csv" % tag, "w")
 out.write("# rocprofv3 --kernel-trace of `bench.py --step model` (HRNetV2-W32 + PWC flow head training step, 4 pairs, fp32): the LAST FOUR steps of the run\n")
 out.write("# (MIOpen's find-mode kernels of the first steps excluded); per step: launches, ms of kernel time, share\n")
 out.write("kernel,launches_per_step,ms_per_step,percent\n")
@@ -35,6 +37,6 @@ so = sum(v[1] for v in ours.values())
 out.write("# kernel time per step %.1f ms in %.0f launches; wall per step in this window %.1f ms; this package's kernels %.3f ms per step = %.2f %% of the kernel time\n"
           % (tot / steps / 1e6, sum(v[0] for v in acc.values()) / steps, span / steps / 1e6, so / steps / 1e6, 100.0 * so / tot))
 out.close()
-print(open("gpurun_out/profiles/r04_kernel_stats_step_model.csv").read())
+print(open("gpurun_out/profiles/%s_kernel_stats_step_model.csv" % tag).read())
 PY
 rm -rf gpurun_out/profiles/_model gpurun_out/profiles/_model.err
