@@ -75,7 +75,8 @@ template <int SPR_, int NWV_, int FLAGS_ = 0, int CW_ = 4, int NIT_ = 1>
 struct StripCfg {
     static constexpr int NIT = NIT_;   // work items a workgroup walks one after the other (round 5 experiment: 2 -> half the grid)
     // timing-experiment flags (-DCERB_ABLATE builds): 1 gradOutput DMA non-temporal, 2 x loads non-temporal, 4 no FMAs,
-    // 8 no loads / DMAs, 16 no LDS reads, 32 natural step order, 64 no step barrier, 256 no stores (all but 1, 2, 32: wrong results)
+    // 8 no loads / DMAs, 16 no LDS reads, 32 natural step order, 64 no step barrier, 256 no stores (all but 1, 2, 32, 512: wrong results),
+    // 512 experiment: a step's memory instructions inside its FMA stream instead of behind it (slower: see step())
     static constexpr int FLAGS = FLAGS_;
     static constexpr int SPR = SPR_, W = 4 * SPR_, RW = 64 / SPR_;
     static constexpr int NR = 2, CW = CW_, NWV = NWV_, CWG = CW * NWV_;
@@ -154,15 +155,27 @@ struct StripBwd {
                 dst[c] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, vo, c * plane * 4, (K::FLAGS & 2) ? 2 : 0));
     }
 
+    // one channel of load_x (the interleaved schedule of step() issues them one at a time)
+    __device__ __forceinline__ void load_x1(int S, bool live, f4 (&dst)[K::CW], int c) {
+        const int row = row0 + S;
+        int vo = voff0 + S * (K::W * 4);
+        vo = (live && static_cast<unsigned>(row) < static_cast<unsigned>(H)) ? vo : kDead;
+        if constexpr (!(K::FLAGS & 8))
+            dst[c] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, vo, c * plane * 4, (K::FLAGS & 2) ? 2 : 0));
+    }
+
     // gradOutput planes of step S -> ring slot `slot`.  Plane k = j * 9 + dx is requested by wave
     // k % NWV.  Every wave issues the SAME number of DMA instructions per step, unconditionally
     // (a wave without a plane to fetch sends an out-of-range request to a scratch row): the
     // compiler's vmcnt bookkeeping for the x loads then knows exactly how many younger
     // operations exist, and never waits for a request that has just been issued.
     __device__ __forceinline__ void issue_g(int S, bool live, int slot) {
-        const int lr = lane / K::SPR, sx = lane % K::SPR;
 #pragma unroll
-        for (int q = 0; q < K::NDMA; ++q) {
+        for (int q = 0; q < K::NDMA; ++q) issue_g1(S, live, slot, q);
+    }
+    __device__ __forceinline__ void issue_g1(int S, bool live, int slot, int q) {
+        const int lr = lane / K::SPR, sx = lane % K::SPR;
+        {
             const int k = wave + K::NWV * q;                    // wave-uniform
             const int j = k >= kND ? 1 : 0, dx = k - j * kND;
             const int dyi = S - j;                              // vertical displacement index of the block
@@ -208,8 +221,8 @@ struct StripBwd {
     }
 
     // the nine (j, dx) blocks of output row j: 4 gradOutput values just in time, 16 FMAs each
-    template <int J>
-    __device__ __forceinline__ void row_blocks(const float (&win)[K::CW][12], unsigned lds_cur) {
+    template <int J, typename Hook>
+    __device__ __forceinline__ void row_blocks(const float (&win)[K::CW][12], unsigned lds_cur, Hook &&hook) {
         constexpr int DEPTH = 2;                              // reads in flight (3: no gain, 7 more VGPRs)
         f4 gq[DEPTH + 1];
         auto issue = [&](auto bc) {
@@ -228,6 +241,7 @@ struct StripBwd {
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
                     if (!(K::FLAGS & 4) || (c == 0 && dx == 0)) fmac(acc[J][c][i], win[c][i + dx], g[i]);
+            hook(bc);
         });
     }
 
@@ -262,12 +276,38 @@ struct StripBwd {
         asm volatile("" : "+v"(win[0][0]), "+v"(win[1][3]), "+v"(win[3][11]));
         STRIP_STAMP(3 + 4 * t);
 #endif
-        if (S <= kND - 1) row_blocks<0>(win, lds_cur);        // dy = S - 4
-        if (S >= 1) row_blocks<1>(win, lds_cur);              // dy = S - 5
+        // Round 5 experiment (FLAGS & 512, -DCERB_ABLATE builds; measured and rejected): the step's vector-memory instructions --
+        // CW x rows for step t+2, NDMA gradOutput DMAs for step t+3 -- issued INSIDE the FMA stream, one every few dx blocks,
+        // instead of all together behind it.  The idea came from the ablations (profiles/r05_sol_skeleton.txt): without FMAs the
+        // launch takes 17.7 us, without loads 24.2, with both 34.3 -- the parts add.  Interleaved: 40.7 vs 34.5 us (8 pairs: 75 vs
+        // 64): a wave that meets a busy texture path stalls AT the memory instruction, now in the middle of its FMAs, and the x
+        // rows requested early need 16 registers beside the windows still in use (128 VGPRs + 8 spilled).
+        auto mem_hook0 = [&](auto bc) {      // output row 0's blocks carry the x rows: channel c behind block floor(9 c / CW)
+            constexpr int dx = decltype(bc)::value;
+            if constexpr (K::FLAGS & 512)
+                static_for<0, K::CW>([&](auto cc) {
+                    constexpr int c = decltype(cc)::value;
+                    if constexpr ((c * kND) / K::CW == dx) load_x1(S2, live2, xs[XSET], c);
+                });
+        };
+        auto mem_hook1 = [&](auto bc) {      // output row 1's blocks carry the DMAs: instruction q behind block floor(9 q / NDMA)
+            constexpr int dx = decltype(bc)::value;
+            if constexpr (K::FLAGS & 512)
+                static_for<0, K::NDMA>([&](auto qc) {
+                    constexpr int q = decltype(qc)::value;
+                    if constexpr ((q * kND) / K::NDMA == dx) issue_g1(S3, live3, s3, q);
+                });
+        };
+        const bool has0 = S <= kND - 1, has1 = S >= 1;
+        if (has0) row_blocks<0>(win, lds_cur, mem_hook0);        // dy = S - 4
+        else if constexpr (K::FLAGS & 512) load_x(S2, live2, xs[XSET]);
+        if (has1) row_blocks<1>(win, lds_cur, mem_hook1);        // dy = S - 5
+        else if constexpr (K::FLAGS & 512) issue_g(S3, live3, s3);
         STRIP_STAMP(4 + 4 * t);
-
-        load_x(S2, live2, xs[XSET]);
-        issue_g(S3, live3, s3);
+        if constexpr (!(K::FLAGS & 512)) {   // the schedule that measures best: everything behind the FMAs
+            load_x(S2, live2, xs[XSET]);
+            issue_g(S3, live3, s3);
+        }
         // the gradOutput planes of the next step (requested two steps ago) have landed once only
         // the requests of the previous and of this step may still be in flight; nobody reads
         // slot `cur` after the barrier
@@ -450,6 +490,8 @@ int corr_strip_backward(const void *in1, const void *in2, const void *gout, void
             case 32: CERB_STRIP(64, 8, 32, "corr_bwd_d4_strip_w256_f32"); break;
             case 64: CERB_STRIP(64, 8, 64, "corr_bwd_d4_strip_w256_f64"); break;
             case 256: CERB_STRIP(64, 8, 256, "corr_bwd_d4_strip_w256_f256"); break;
+            case 512: CERB_STRIP(64, 8, 512, "corr_bwd_d4_strip_w256_f512"); break;   // experiment: memory instructions inside the FMA stream
+            case 516: CERB_STRIP(64, 8, 516, "corr_bwd_d4_strip_w256_f516"); break;
             default: break;
         }
 #endif
