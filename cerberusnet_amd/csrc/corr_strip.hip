@@ -250,7 +250,11 @@ struct StripBwd {
     // finished with) and the planes of step t+3 (S3, into the slot last read a step ago): the
     // vector-memory instructions (~130 cycles each when all waves of a CU issue together) are
     // spread over the waves' staggered arrivals at the barrier instead of following it.
-    template <int XSET>
+    // LATE (round 5, guide "two waves that run the same program with one barrier per block: try a stagger"): the second half of a
+    // workgroup's waves issues its step's gradOutput DMAs (LATE & 1) / x rows (LATE & 2) BEFORE its FMAs, the first half behind
+    // them: the two waves a workgroup has on a SIMD are then in complementary phases -- one queueing at the texture path,
+    // one on the FMA pipe -- instead of both doing the same thing at the same time.  Same instructions, same counts per step.
+    template <int XSET, int LATE = 0>
     __device__ __forceinline__ void step(int S, int S1, int S2, int S3, bool live2, bool live3, int cur, int nxt,
                                          int s3, int t) {
         // ---- 12-float windows of the CW channels: [left strip | own | right strip] ----
@@ -298,6 +302,8 @@ struct StripBwd {
                     if constexpr ((q * kND) / K::NDMA == dx) issue_g1(S3, live3, s3, q);
                 });
         };
+        if constexpr (LATE & 2) load_x(S2, live2, xs[XSET]);
+        if constexpr (LATE & 1) issue_g(S3, live3, s3);
         const bool has0 = S <= kND - 1, has1 = S >= 1;
         if (has0) row_blocks<0>(win, lds_cur, mem_hook0);        // dy = S - 4
         else if constexpr (K::FLAGS & 512) load_x(S2, live2, xs[XSET]);
@@ -305,8 +311,8 @@ struct StripBwd {
         else if constexpr (K::FLAGS & 512) issue_g(S3, live3, s3);
         STRIP_STAMP(4 + 4 * t);
         if constexpr (!(K::FLAGS & 512)) {   // the schedule that measures best: everything behind the FMAs
-            load_x(S2, live2, xs[XSET]);
-            issue_g(S3, live3, s3);
+            if constexpr (!(LATE & 2)) load_x(S2, live2, xs[XSET]);
+            if constexpr (!(LATE & 1)) issue_g(S3, live3, s3);
         }
         // the gradOutput planes of the next step (requested two steps ago) have landed once only
         // the requests of the previous and of this step may still be in flight; nobody reads
@@ -350,8 +356,11 @@ void corr_bwd_d4_strip_kernel(const float *__restrict__ x1, const float *__restr
     float *dst = (side == 0 ? gin1 : gin2) + (static_cast<int64_t>(b) * C + c0) * plane;
     const float *gob = gout + static_cast<int64_t>(b) * (kND * kND) * plane;
 
-    auto run = [&](auto sidec) {
+    // (two whole copies of the body per side rather than a branch around the step loop: state shared across such a branch
+    // -- 32 accumulators, two x-row sets -- made the register allocator spill 106 registers)
+    auto run = [&](auto sidec, auto latec) {
         constexpr int SIDE = decltype(sidec)::value;
+        constexpr int LATE = decltype(latec)::value;
         StripBwd<K, SIDE> st;
         st.rsrc_x = uniform_rsrc(src, K::CW * plane * 4);
         st.rsrc_g = uniform_rsrc(gob, kND * kND * plane * 4);
@@ -396,10 +405,10 @@ void corr_bwd_d4_strip_kernel(const float *__restrict__ x1, const float *__restr
         int cur = 0, nxt = 1, n2 = 2, n3 = 3;
 #pragma unroll 1
         for (int t = 0; t < 10; t += 2) {
-            st.template step<0>(S, S1, S2, S3, t + 2 < 10, t + 3 < 10, cur, nxt, n3, t);
+            st.template step<0, LATE>(S, S1, S2, S3, t + 2 < 10, t + 3 < 10, cur, nxt, n3, t);
             S = S1; S1 = S2; S2 = S3; S3 = next(S3);
             { const int q = cur; cur = nxt; nxt = n2; n2 = n3; n3 = q; }
-            st.template step<1>(S, S1, S2, S3, t + 3 < 10, t + 4 < 10, cur, nxt, n3, t + 1);
+            st.template step<1, LATE>(S, S1, S2, S3, t + 3 < 10, t + 4 < 10, cur, nxt, n3, t + 1);
             S = S1; S1 = S2; S2 = S3; S3 = next(S3);
             { const int q = cur; cur = nxt; nxt = n2; n2 = n3; n3 = q; }
         }
@@ -424,8 +433,16 @@ void corr_bwd_d4_strip_kernel(const float *__restrict__ x1, const float *__restr
         if ((threadIdx.x & 63) == 0 && blockIdx.x < 512) g_strip_life[blockIdx.x][threadIdx.x >> 6][2] = __builtin_amdgcn_s_memrealtime();
 #endif
     };
-    if (side == 0) run(std::integral_constant<int, 0>{});
-    else run(std::integral_constant<int, 1>{});
+    constexpr int kLate = (K::FLAGS & 1024) ? 1 : (K::FLAGS & 2048) ? 3 : 0;
+    using Early = std::integral_constant<int, 0>;
+    using Late = std::integral_constant<int, kLate>;
+    if (kLate != 0 && wave >= K::NWV / 2) {
+        if (side == 0) run(std::integral_constant<int, 0>{}, Late{});
+        else run(std::integral_constant<int, 1>{}, Late{});
+    } else {
+        if (side == 0) run(std::integral_constant<int, 0>{}, Early{});
+        else run(std::integral_constant<int, 1>{}, Early{});
+    }
     }
 #endif
 }
@@ -492,6 +509,8 @@ int corr_strip_backward(const void *in1, const void *in2, const void *gout, void
             case 256: CERB_STRIP(64, 8, 256, "corr_bwd_d4_strip_w256_f256"); break;
             case 512: CERB_STRIP(64, 8, 512, "corr_bwd_d4_strip_w256_f512"); break;   // experiment: memory instructions inside the FMA stream
             case 516: CERB_STRIP(64, 8, 516, "corr_bwd_d4_strip_w256_f516"); break;
+            case 1024: CERB_STRIP(64, 8, 1024, "corr_bwd_d4_strip_w256_f1024"); break;   // waves 4-7: DMAs before the FMAs
+            case 2048: CERB_STRIP(64, 8, 2048, "corr_bwd_d4_strip_w256_f2048"); break;   // waves 4-7: DMAs and x rows before the FMAs
             default: break;
         }
 #endif
