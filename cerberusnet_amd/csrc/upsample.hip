@@ -284,6 +284,7 @@ struct AreaPyr {
     void *dst[kPyrMax];
     int ratio[kPyrMax];          // descending
     int n;
+    int vec;                     // outputs per thread: 4 where every scale's rows take 16-byte stores, else 1
 };
 
 template <int R>
@@ -334,30 +335,51 @@ __global__ __launch_bounds__(256) void area_pyramid_kernel(const T *__restrict__
         *reinterpret_cast<float4 *>(band + row * xw + 4 * c4) = v;
     }
     __syncthreads();
+    // one thread = VEC horizontally adjacent outputs of one scale (VEC = 4 where rows allow 16-byte stores: a store of one
+    // dword per lane is issue-bound, and the 1/2 scale alone is 2048 outputs per band), each summed on its own in row-major order
+    const int vec = pyr.vec;
     int total = 0;
-    for (int s = 0; s < pyr.n; ++s) total += (rmax / pyr.ratio[s]) * (xw / pyr.ratio[s]);
+    for (int s = 0; s < pyr.n; ++s) total += (rmax / pyr.ratio[s]) * (xw / pyr.ratio[s]) / vec;
     for (int i = threadIdx.x; i < total; i += 256) {
         int s = 0, j = i;
         for (; s < pyr.n - 1; ++s) {
-            const int cnt = (rmax / pyr.ratio[s]) * (xw / pyr.ratio[s]);
+            const int cnt = (rmax / pyr.ratio[s]) * (xw / pyr.ratio[s]) / vec;
             if (j < cnt) break;
             j -= cnt;
         }
         const int r = pyr.ratio[s];
-        const int rows = rmax / r, cols = xw / r, oW = W / r, oH = H / r;
-        const int oy = j / cols, ox = j - oy * cols;
+        const int rows = rmax / r, cols = xw / r / vec, oW = W / r, oH = H / r;
+        const int oy = j / cols, ox = (j - oy * cols) * vec;
         const float *q = band + oy * r * xw + ox * r;
-        float sum;
-        switch (r) {
-            case 2: sum = area_window_sum<2>(q, xw); break;
-            case 4: sum = area_window_sum<4>(q, xw); break;
-            case 8: sum = area_window_sum<8>(q, xw); break;
-            case 16: sum = area_window_sum<16>(q, xw); break;
-            case 32: sum = area_window_sum<32>(q, xw); break;
-            default: sum = area_window_sum<64>(q, xw); break;
+        float sum[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (k >= vec) break;
+            switch (r) {
+                case 2: sum[k] = area_window_sum<2>(q + k * r, xw); break;
+                case 4: sum[k] = area_window_sum<4>(q + k * r, xw); break;
+                case 8: sum[k] = area_window_sum<8>(q + k * r, xw); break;
+                case 16: sum[k] = area_window_sum<16>(q + k * r, xw); break;
+                case 32: sum[k] = area_window_sum<32>(q + k * r, xw); break;
+                default: sum[k] = area_window_sum<64>(q + k * r, xw); break;
+            }
+            sum[k] = sum[k] / static_cast<float>(r) / static_cast<float>(r);
         }
         T *dst = static_cast<T *>(pyr.dst[s]) + pl * oH * oW + (static_cast<int64_t>(bnd) * rows + oy) * oW + xs / r + ox;
-        st(dst, sum / static_cast<float>(r) / static_cast<float>(r));
+        if (vec == 4) {
+            if constexpr (sizeof(T) == 4) {
+                *reinterpret_cast<float4 *>(dst) = make_float4(sum[0], sum[1], sum[2], sum[3]);
+            } else {
+                T e[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) st(&e[k], sum[k]);
+                uint2 raw;
+                __builtin_memcpy(&raw, e, 8);
+                *reinterpret_cast<uint2 *>(dst) = raw;
+            }
+        } else {
+            st(dst, sum[0]);
+        }
     }
 }
 
@@ -388,6 +410,12 @@ int area_pyramid(const void *src, void *const *dsts, const int *out_h, const int
     // 12 planes of 512 x 1024); SEG is a multiple of every ratio
     const int seg = std::min(W, kPyrBand / rmax);
     const int nseg = (W + seg - 1) / seg;
+    pyr.vec = 4;
+    for (int i = 0; i < n; ++i) {
+        const int r = pyr.ratio[i];
+        // every segment of every scale a whole number of 4-output groups, 16-byte aligned in memory
+        if ((W / r) % 4 || (seg / r) % 4 || ((W % seg) / r) % 4 || (reinterpret_cast<uintptr_t>(pyr.dst[i]) & (4 * esz - 1))) pyr.vec = 1;
+    }
     const int64_t blocks = planes * (H / rmax) * nseg;
     if (blocks > 0x7fffffff) return CERB_ETOOLARGE;
     const dim3 grid(static_cast<unsigned>(blocks));
