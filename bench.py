@@ -1014,27 +1014,33 @@ def model_step_mode(args, device, rank, world, dist, quiet=False):
     # region: the per-GPU rate the scaling of `value` is to be read against, measured on this node in this run
     single = None
     if ddp:
+        # every rank reaches the two collectives below whether or not its own pass failed (an exception on one rank
+        # must not leave the others hanging in the timing all-reduce): the first carries an error flag, the second the time
+        err, ds = None, 0.0
         try:
             with net.no_sync():
                 for _ in range(2):
                     step()
-                fence()
+                torch.cuda.synchronize()
                 t0 = time.perf_counter()
                 for _ in range(args.steps):
                     step()
-                fence()
+                torch.cuda.synchronize()
                 ds = time.perf_counter() - t0
-            t = torch.tensor([ds], dtype=torch.float64, device=device)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            ds = float(t.item())
+        except Exception as exc:  # a side report: never fail the line on it
+            err = exc
+        t = torch.tensor([1.0 if err is not None else 0.0, ds], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        if float(t[0].item()) > 0:
+            single = {"error": repr(err)[:200] if err is not None else "another rank failed in this pass"}
+        else:
+            ds = float(t[1].item())
             single = {"pairs_per_s_per_gpu": round(B * args.steps / ds, 2), "ms_per_step": round(1e3 * ds / args.steps, 4),
                       "what": "the same training step on every rank's GPU with the gradient all-reduce switched off "
                               "(DistributedDataParallel.no_sync), slowest rank, timed after the DDP region: "
                               "value / (n_gpus x this) is the scaling of the DDP step on this node"
                               + ("; NOT collective-free: --sync-bn keeps SyncBatchNorm's all-reduces in this pass too" if args.sync_bn else "")
                               + "; the optimizer steps on the rank's own (unreduced) gradients here: ranks diverge after this pass, which is why it runs last"}
-        except Exception as exc:  # a side report: never fail the line on it
-            single = {"error": repr(exc)[:200]}
     # the same step with the hot-path ops swapped for the reference's own stock-PyTorch fallback (CorrelationTorch +
     # grid_sample + F.interpolate: SURVEY 8(d) "the same model with the op swapped") and under bf16 autocast, in THIS process
     # (same model, MIOpen's solvers already chosen): a side table, one rank only

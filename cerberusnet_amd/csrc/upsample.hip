@@ -319,20 +319,32 @@ __global__ __launch_bounds__(256) void area_pyramid_kernel(const T *__restrict__
     const int64_t pl = id / nband;
     const int xs = sg * seg, xw = min(seg, W - xs);
     const T *src = in + pl * H * W + static_cast<int64_t>(bnd) * rmax * W + xs;
+    // the band -> LDS: every thread's loads (up to 8 x 16 bytes) are ALL issued before the first is written to LDS (a loop that
+    // loads, converts and stores cell by cell is a chain of dependent trips to HBM: 4 - 8 of them per workgroup, 17 us)
     const int cpr = xw / 4, cells = rmax * cpr;
-    for (int k = threadIdx.x; k < cells; k += 256) {
+    constexpr int kCells = kPyrBand / 4 / 256;
+    float4 v[kCells];
+#pragma unroll
+    for (int i = 0; i < kCells; ++i) {
+        const int k = min(static_cast<int>(threadIdx.x) + 256 * i, cells - 1);
         const int row = k / cpr, c4 = k - row * cpr;
         const T *q = src + static_cast<int64_t>(row) * W + 4 * c4;
-        float4 v;
         if constexpr (sizeof(T) == 4) {
-            v = *reinterpret_cast<const float4 *>(q);
+            v[i] = *reinterpret_cast<const float4 *>(q);
         } else {
             const uint2 raw = *reinterpret_cast<const uint2 *>(q);
             T e[4];
             __builtin_memcpy(e, &raw, 8);
-            v = make_float4(ld(&e[0]), ld(&e[1]), ld(&e[2]), ld(&e[3]));
+            v[i] = make_float4(ld(&e[0]), ld(&e[1]), ld(&e[2]), ld(&e[3]));
         }
-        *reinterpret_cast<float4 *>(band + row * xw + 4 * c4) = v;
+    }
+#pragma unroll
+    for (int i = 0; i < kCells; ++i) {
+        const int k = static_cast<int>(threadIdx.x) + 256 * i;
+        if (k < cells) {
+            const int row = k / cpr, c4 = k - row * cpr;
+            *reinterpret_cast<float4 *>(band + row * xw + 4 * c4) = v[i];
+        }
     }
     __syncthreads();
     // one thread = VEC horizontally adjacent outputs of one scale (VEC = 4 where rows allow 16-byte stores: a store of one
