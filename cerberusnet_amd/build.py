@@ -18,7 +18,7 @@ LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(CSRC, "_obj")
 LIB = os.path.join(LIBDIR, "libcerberus_hip.so")
 ARCH = "gfx950"
-SOURCES = ["api.hip", "corr_generic.hip", "corr_d4.hip", "corr_strip.hip", "corr_coarse.hip", "corr_fwd_pipe.hip", "corr_mfma.hip", "corr_grad_prep.hip", "warp.hip", "upsample.hip"]
+SOURCES = ["api.hip", "corr_generic.hip", "corr_d4.hip", "corr_d4_bwd.hip", "corr_strip.hip", "corr_coarse.hip", "corr_fwd_pipe.hip", "corr_mfma.hip", "corr_grad_prep.hip", "warp.hip", "upsample.hip"]
 CXXFLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-Wall",
             "-Wno-unused-function", "-fno-fast-math",
             "-fhip-fp32-correctly-rounded-divide-sqrt"]

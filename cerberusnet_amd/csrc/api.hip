@@ -1,6 +1,6 @@
 // api.hip -- the extern "C" surface declared in include/cerberus_hip.h.
-// Argument validation + dispatch only; kernels live in corr_d4.hip,
-// corr_generic.hip and warp.hip.
+// Argument validation + dispatch only; kernels live in corr_d4.hip / corr_d4_bwd.hip / corr_strip.hip / corr_coarse.hip /
+// corr_mfma.hip / corr_generic.hip, corr_grad_prep.hip, warp.hip and upsample.hip.
 #include <atomic>
 #include <cstring>
 
