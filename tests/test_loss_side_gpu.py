@@ -153,6 +153,23 @@ def test_area_pyramid_is_bit_identical_to_torch_cpu_per_scale():
             assert torch.equal(o.cpu(), ref), size
 
 
+def test_area_pyramid_narrow_rows_take_the_one_output_per_thread_path():
+    """Output rows that are not a whole number of 4-element groups (16-byte stores impossible) and rows that are, ratios
+    2 / 4 / 8, several segments per row: the same bits as torch's CPU kernel either way."""
+    for shape, sizes in (((1, 2, 32, 40), [(16, 20), (8, 10)]),        # 10-wide rows: one output per thread for every scale
+                         ((1, 2, 32, 40), [(16, 20)]),                 # 20-wide rows: four per thread
+                         ((2, 1, 64, 2304), [(32, 1152), (16, 576), (8, 288)]),   # three 1024 / 1024 / 256-column segments per row
+                         ((1, 1, 8, 8), [(4, 4), (2, 2), (1, 1)])):
+        x = hash_uniform(shape, 905, -2.0, 2.0)
+        outs = ca.area_pyramid(dev(x), sizes)
+        for o, size in zip(outs, sizes):
+            ref = torch.nn.functional.interpolate(torch.from_numpy(x), size, mode="area")
+            if size == (1, 1):
+                assert rel_err(o.cpu().numpy(), ref.numpy()) < TOL     # ATen sums a 1 x 1 output with its vectorised mean
+            else:
+                assert torch.equal(o.cpu(), ref), (shape, size)
+
+
 def test_area_pyramid_16_bit_and_errors():
     x = dev(hash_uniform((1, 3, 64, 128), 904, -2.0, 2.0))
     for dt, tol in [(torch.float16, 1e-3), (torch.bfloat16, 8e-3)]:
