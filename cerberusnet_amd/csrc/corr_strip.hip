@@ -497,7 +497,7 @@ int corr_strip_backward(const void *in1, const void *in2, const void *gout, void
         return launch_strip<StripCfg<SPR, NWV, FL>>(NAME, in1, in2, gout, gin1, gin2, g, s)
     if (g.W == 256) {
 #ifdef CERB_ABLATE
-        switch (option(OPT_CORR_BWD_CSLICE)) {   // timing experiments (tools/_strip_exp.py): flags of StripCfg
+        switch (option(OPT_CORR_BWD_CSLICE)) {   // timing experiments (tools/strip_exp.py): flags of StripCfg
             case 1: CERB_STRIP(64, 8, 1, "corr_bwd_d4_strip_w256_f1"); break;
             case 4: CERB_STRIP(64, 8, 4, "corr_bwd_d4_strip_w256_f4"); break;
             case 8: CERB_STRIP(64, 8, 8, "corr_bwd_d4_strip_w256_f8"); break;

@@ -222,7 +222,9 @@ int cerberus_area_pyramid(const void *src, void *const *dsts, const int *out_h, 
  *                          C <= 64; auto uses it for 16 < C <= 64), 15 = the coarse-level kernel (fp32, and
  *                          fp16 / bf16 storage with C > 64; W = 16 / 32 / 64 and a channel count its lane
  *                          layout divides: corr_coarse.hip; auto uses it there up to 2560 (row, displacement
- *                          row) workgroups), 16 = auto without it
+ *                          row) workgroups), 16 = auto without it, 17 = the persistent, cross-item pipelined forward
+ *                          (fp32, C % 8 == 0: corr_fwd_pipe.hip; built and measured in round 5, slower than the tile
+ *                          kernels: never picked by auto; with it, "corr_bwd_cslice" > 0 sets its number of workgroups)
  *   "corr_bwd_variant"   : 0 = auto, 1 = all 81 displacements per lane (register-staged),
  *                          3 = three displacement groups, 4 / 5 = LDS-DMA with the 8x64 /
  *                          16x32 tile (fp32, W % 4 == 0), 8 = displacement-row streaming,
