@@ -523,6 +523,13 @@ int corr_strip_backward(const void *in1, const void *in2, const void *gout, void
 #endif
         CERB_STRIP(64, 8, 0, "corr_bwd_d4_strip_w256");
     } else if (g.W == 128) {
+#ifdef CERB_ABLATE
+        // occupancy experiments at the 128-wide level (256 eight-wave workgroups of 32 channels = 2 waves per SIMD at 4 pairs)
+        if (option(OPT_CORR_BWD_CSLICE) == 2002 && g.H % 4 == 0 && g.C % 16 == 0)
+            return launch_strip<StripCfg<32, 8, 0, 2>>("corr_bwd_d4_strip_w128_cw2", in1, in2, gout, gin1, gin2, g, s);
+        if (option(OPT_CORR_BWD_CSLICE) == 2004 && g.H % 4 == 0 && g.C % 16 == 0)
+            return launch_strip<StripCfg<32, 4, 0, 4>>("corr_bwd_d4_strip_w128_nwv4", in1, in2, gout, gin1, gin2, g, s);
+#endif
         CERB_STRIP(32, 8, 0, "corr_bwd_d4_strip_w128");
     } else if (g.W == 64) {
         CERB_STRIP(16, 8, 0, "corr_bwd_d4_strip_w64");
