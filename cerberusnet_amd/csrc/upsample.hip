@@ -284,7 +284,7 @@ struct AreaPyr {
     void *dst[kPyrMax];
     int ratio[kPyrMax];          // descending
     int n;
-    int vec;                     // outputs per thread: 4 where every scale's rows take 16-byte stores, else 1
+    int vec;                     // 4: the 1/2 scale's rows take 16-byte stores (four outputs per thread there), else 1
 };
 
 template <int R>
@@ -323,11 +323,12 @@ __global__ __launch_bounds__(256) void area_pyramid_kernel(const T *__restrict__
     // loads, converts and stores cell by cell is a chain of dependent trips to HBM: 4 - 8 of them per workgroup, 17 us)
     const int cpr = xw / 4, cells = rmax * cpr;
     constexpr int kCells = kPyrBand / 4 / 256;
+    const float inv_cpr = 1.0f / static_cast<float>(cpr);
     float4 v[kCells];
 #pragma unroll
     for (int i = 0; i < kCells; ++i) {
         const int k = min(static_cast<int>(threadIdx.x) + 256 * i, cells - 1);
-        const int row = k / cpr, c4 = k - row * cpr;
+        const int row = static_cast<int>((static_cast<float>(k) + 0.5f) * inv_cpr), c4 = k - row * cpr;
         const T *q = src + static_cast<int64_t>(row) * W + 4 * c4;
         if constexpr (sizeof(T) == 4) {
             v[i] = *reinterpret_cast<const float4 *>(q);
@@ -342,55 +343,65 @@ __global__ __launch_bounds__(256) void area_pyramid_kernel(const T *__restrict__
     for (int i = 0; i < kCells; ++i) {
         const int k = static_cast<int>(threadIdx.x) + 256 * i;
         if (k < cells) {
-            const int row = k / cpr, c4 = k - row * cpr;
+            const int row = static_cast<int>((static_cast<float>(k) + 0.5f) * inv_cpr), c4 = k - row * cpr;
             *reinterpret_cast<float4 *>(band + row * xw + 4 * c4) = v[i];
         }
     }
     __syncthreads();
-    // one thread = VEC horizontally adjacent outputs of one scale (VEC = 4 where rows allow 16-byte stores: a store of one
-    // dword per lane is issue-bound, and the 1/2 scale alone is 2048 outputs per band), each summed on its own in row-major order
-    const int vec = pyr.vec;
-    int total = 0;
-    for (int s = 0; s < pyr.n; ++s) total += (rmax / pyr.ratio[s]) * (xw / pyr.ratio[s]) / vec;
-    for (int i = threadIdx.x; i < total; i += 256) {
-        int s = 0, j = i;
-        for (; s < pyr.n - 1; ++s) {
-            const int cnt = (rmax / pyr.ratio[s]) * (xw / pyr.ratio[s]) / vec;
-            if (j < cnt) break;
-            j -= cnt;
-        }
+    // The 1/2 scale (2048 outputs per band): a thread owns FOUR horizontally adjacent outputs -- two 16-byte LDS reads per
+    // source row, one 16-byte store (a store of one dword per lane is issue-bound).  The coarser scales: ONE output per
+    // thread, so that neighbouring lanes read neighbouring 16-byte cells of the band (four adjacent outputs per thread put
+    // the lanes 64 / 128 bytes apart: 4- to 8-way bank conflicts, and the window sums took 9.4 of the launch's 14.8 us).
+    // Every output is summed on its own in row-major order either way.
+    const bool vec2 = pyr.vec == 4 && pyr.ratio[pyr.n - 1] == 2;       // ratios are sorted descending: 2 can only be last
+    // (index arithmetic: scale by scale, row = unit / columns by one float multiply -- exact for the <= 8192 units of a band;
+    // a flat index over all scales cost a search and two integer divisions per output: 3.6 us of the launch)
+    for (int s = 0; s < pyr.n; ++s) {
         const int r = pyr.ratio[s];
-        const int rows = rmax / r, cols = xw / r / vec, oW = W / r, oH = H / r;
-        const int oy = j / cols, ox = (j - oy * cols) * vec;
-        const float *q = band + oy * r * xw + ox * r;
-        float sum[4];
+        const int rows = rmax / r, oW = W / r, oH = H / r;
+        T *dbase = static_cast<T *>(pyr.dst[s]) + pl * oH * oW + static_cast<int64_t>(bnd) * rows * oW + xs / r;
+        if (vec2 && s == pyr.n - 1) {
+            const int cols = xw / 8;                       // groups of four outputs
+            const float inv_cols = 1.0f / static_cast<float>(cols);
+            for (int j = threadIdx.x; j < rows * cols; j += 256) {
+                const int oy = static_cast<int>((static_cast<float>(j) + 0.5f) * inv_cols), ox = (j - oy * cols) * 4;
+                const float *q = band + oy * 2 * xw + ox * 2;
+                const float4 a0 = *reinterpret_cast<const float4 *>(q), a1 = *reinterpret_cast<const float4 *>(q + 4);
+                const float4 b0 = *reinterpret_cast<const float4 *>(q + xw), b1 = *reinterpret_cast<const float4 *>(q + xw + 4);
+                float o[4];
+                { float t = 0.f; t += a0.x; t += a0.y; t += b0.x; t += b0.y; o[0] = t / 2.f / 2.f; }
+                { float t = 0.f; t += a0.z; t += a0.w; t += b0.z; t += b0.w; o[1] = t / 2.f / 2.f; }
+                { float t = 0.f; t += a1.x; t += a1.y; t += b1.x; t += b1.y; o[2] = t / 2.f / 2.f; }
+                { float t = 0.f; t += a1.z; t += a1.w; t += b1.z; t += b1.w; o[3] = t / 2.f / 2.f; }
+                T *dst = dbase + static_cast<int64_t>(oy) * oW + ox;
+                if constexpr (sizeof(T) == 4) {
+                    *reinterpret_cast<float4 *>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+                } else {
+                    T e[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            if (k >= vec) break;
-            switch (r) {
-                case 2: sum[k] = area_window_sum<2>(q + k * r, xw); break;
-                case 4: sum[k] = area_window_sum<4>(q + k * r, xw); break;
-                case 8: sum[k] = area_window_sum<8>(q + k * r, xw); break;
-                case 16: sum[k] = area_window_sum<16>(q + k * r, xw); break;
-                case 32: sum[k] = area_window_sum<32>(q + k * r, xw); break;
-                default: sum[k] = area_window_sum<64>(q + k * r, xw); break;
+                    for (int k = 0; k < 4; ++k) st(&e[k], o[k]);
+                    uint2 raw;
+                    __builtin_memcpy(&raw, e, 8);
+                    *reinterpret_cast<uint2 *>(dst) = raw;
+                }
             }
-            sum[k] = sum[k] / static_cast<float>(r) / static_cast<float>(r);
+            continue;
         }
-        T *dst = static_cast<T *>(pyr.dst[s]) + pl * oH * oW + (static_cast<int64_t>(bnd) * rows + oy) * oW + xs / r + ox;
-        if (vec == 4) {
-            if constexpr (sizeof(T) == 4) {
-                *reinterpret_cast<float4 *>(dst) = make_float4(sum[0], sum[1], sum[2], sum[3]);
-            } else {
-                T e[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) st(&e[k], sum[k]);
-                uint2 raw;
-                __builtin_memcpy(&raw, e, 8);
-                *reinterpret_cast<uint2 *>(dst) = raw;
+        const int cols = xw / r;
+        const float inv_cols = 1.0f / static_cast<float>(cols);
+        for (int j = threadIdx.x; j < rows * cols; j += 256) {
+            const int oy = static_cast<int>((static_cast<float>(j) + 0.5f) * inv_cols), ox = j - oy * cols;
+            const float *q = band + oy * r * xw + ox * r;
+            float sum;
+            switch (r) {
+                case 2: sum = area_window_sum<2>(q, xw); break;
+                case 4: sum = area_window_sum<4>(q, xw); break;
+                case 8: sum = area_window_sum<8>(q, xw); break;
+                case 16: sum = area_window_sum<16>(q, xw); break;
+                case 32: sum = area_window_sum<32>(q, xw); break;
+                default: sum = area_window_sum<64>(q, xw); break;
             }
-        } else {
-            st(dst, sum[0]);
+            st(dbase + static_cast<int64_t>(oy) * oW + ox, sum / static_cast<float>(r) / static_cast<float>(r));
         }
     }
 }
@@ -425,8 +436,8 @@ int area_pyramid(const void *src, void *const *dsts, const int *out_h, const int
     pyr.vec = 4;
     for (int i = 0; i < n; ++i) {
         const int r = pyr.ratio[i];
-        // every segment of every scale a whole number of 4-output groups, 16-byte aligned in memory
-        if ((W / r) % 4 || (seg / r) % 4 || ((W % seg) / r) % 4 || (reinterpret_cast<uintptr_t>(pyr.dst[i]) & (4 * esz - 1))) pyr.vec = 1;
+        // the 1/2 scale in groups of four outputs: every segment a whole number of groups, rows 16-byte aligned in memory
+        if (r == 2 && ((W / r) % 4 || (seg / r) % 4 || ((W % seg) / r) % 4 || (reinterpret_cast<uintptr_t>(pyr.dst[i]) & (4 * esz - 1)))) pyr.vec = 1;
     }
     const int64_t blocks = planes * (H / rmax) * nseg;
     if (blocks > 0x7fffffff) return CERB_ETOOLARGE;
