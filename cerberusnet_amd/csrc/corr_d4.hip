@@ -594,9 +594,9 @@ template <typename T>
 int fwd_dispatch(const void *x1, const void *x2, void *o, const CorrGeom &g, float slope,
                  int64_t obs, bool vec, hipStream_t s) {
     if constexpr (sizeof(T) == 2) {
-        // 16-bit storage, 16 < C <= 64: the matrix-core kernel (corr_mfma.hip; 14 forces it); variants 1-8 keep the VALU kernels
+        // 16-bit storage, 16 < C <= 128: the matrix-core kernel (corr_mfma.hip; 14 forces it); variants 1-8 keep the VALU kernels
         const int v = option(OPT_CORR_FWD_VARIANT);
-        if (vec && dma_ok(g) && g.C <= 64 && option(OPT_CORR_NO_MFMA) == 0 && (v == 14 || (v == 0 && g.C > 16)))   // <= 16 channels fill half an MFMA: no gain
+        if (vec && dma_ok(g) && g.C <= 128 && option(OPT_CORR_NO_MFMA) == 0 && (v == 14 || (v == 0 && g.C > 16)))   // <= 16 channels fill half an MFMA: no gain
             return corr_mfma_forward(x1, x2, o, g, slope, obs,
                                      std::is_same<T, __half>::value ? CERB_F16 : CERB_BF16, s);
     }
@@ -604,7 +604,7 @@ int fwd_dispatch(const void *x1, const void *x2, void *o, const CorrGeom &g, flo
         // coarse levels (W <= 64): independent waves, no loader, one barrier (corr_coarse.hip); 15 forces it, 16 keeps it off
         // (4 pairs: 7.0 vs 11.6 us at 256 x 16 x 32, 8.1 vs 10.8 us at 128 x 32 x 64; the tile kernels catch up
         // once a launch has more than ~2500 (row, displacement row) workgroups).  16-bit storage: the same kernel
-        // with the loads widened (the matrix-core kernel above keeps 16 < C <= 64)
+        // with the loads widened (the matrix-core kernel above keeps 16 < C <= 128)
         const int v = option(OPT_CORR_FWD_VARIANT);
         const bool coarse_auto = g.W <= 64 && static_cast<int64_t>(g.B) * g.H * kND <= 2560;   // 8 pairs of 128 x 32 x 64: 12.5 vs 13.0 us
         if (vec && dma_ok(g) && (v == 15 || (v == 0 && coarse_auto))) {

@@ -373,12 +373,12 @@ __global__ __launch_bounds__(BwdMfmaCfg::THREADS, 2) void corr_bwd_d4_mfma_kerne
 // by its column so that the 16 lanes of an operand read start in different banks.
 // A wave owns one row: per dy 8 MFMAs; the wanted diagonals are scaled, LeakyReLU'd, rounded
 // and passed through a per-wave LDS tile to become whole 128 / 64-byte plane rows.
-// NKB = 32-channel blocks held at once (C <= 32 NKB); the tile is 4 rows x 64 / NKB pixels.
+// NKB = 32-channel blocks held at once (C <= 32 NKB; 1, 2 or 4); the tile is 4 rows x 64 / NKB pixels.
 // (Walking down a column of tiles as the backward does -- x2 rows in a ring, the next tile's rows
 // prefetched -- was measured and dropped: 32x256x512 55.6 -> 53.5 us, but 32x128x256 16.4 -> 18.2
 // and 64x64x128 9.7 -> 11.3: the forward's traffic is dominated by its 81-plane output, not by
 // the window halo.)
-template <int NKB_>
+template <int NKB_, int DS_ = (NKB_ == 4 ? 3 : 2)>
 struct FwdMfmaCfg {
     static constexpr int NKB = NKB_, NSEG = 4 / NKB, TW = 16 * NSEG, TH = 4;
     static constexpr int PIXB = 64 * NKB;                      // bytes per pixel (all channels)
@@ -388,10 +388,16 @@ struct FwdMfmaCfg {
     static constexpr int WIN_B = WR * WROW, X1_B = TH * XROW;
     static constexpr int TP = TW + 1;                          // T row pitch: odd, so a diagonal of D spreads over the banks
     static constexpr int T_B = (kND * TP + 64) * 4;            // per wave: 9 planes x TW pixels fp32 + 64 dump slots
-    static constexpr int THREADS = 64 * TH;
-    static constexpr size_t LDS_BYTES = WIN_B + X1_B;          // the T tiles reuse the x1 tile's LDS
-    static_assert(TH * T_B <= X1_B, "T tiles fit the x1 tile");
-    static_assert(NKB == 1 || NKB == 2, "channel blocks");
+    // DS waves share a row of the tile, each taking 9 / DS of the vertical displacements: more waves per staged window (the
+    // same MFMAs and stores; identical bits).  NKB = 4 (65 .. 128 channels; round 5): the window alone is 75 KB -- one
+    // workgroup per CU -- and three waves per row make twelve per window.  Measured (4 pairs, fp16, us, DS = 1 / 2 / 3):
+    // 128 x 64 x 128 18.1 / 16.3 / 15.2 (the vector kernel: 22.8), 64 x 128 x 256 27.1 / 22.9 / 22.6, 64 x 64 x 128 10.2 / 8.2 / 8.4,
+    // 32 x 256 x 512 53.7 / 49.6 / 59.9, 32 x 128 x 256 16.7 / 15.6 / 17.2
+    static constexpr int DS = DS_;                             // waves per row
+    static constexpr int DPW = (kND + DS - 1) / DS;            // vertical displacements per wave
+    static constexpr int THREADS = 64 * TH * DS;
+    static constexpr size_t LDS_BYTES = WIN_B + (X1_B > TH * DS * T_B ? X1_B : TH * DS * T_B);   // the T tiles reuse the x1 tile's LDS
+    static_assert(NKB == 1 || NKB == 2 || NKB == 4, "channel blocks");
     // Byte offset, inside a row, of 16-byte chunk ci (8 channels) of the pixel at column col.
     // Two access patterns must both spread over the banks: the operand reads (16 lanes = 16
     // consecutive columns, same chunk) and the transposing writes (16 lanes = columns 4 apart).
@@ -404,7 +410,7 @@ struct FwdMfmaCfg {
 };
 
 template <typename K, typename T>
-__global__ __launch_bounds__(K::THREADS, 2) void corr_fwd_d4_mfma_kernel(
+__global__ __launch_bounds__(K::THREADS, K::NKB == 4 ? 1 : 2) void corr_fwd_d4_mfma_kernel(
     const T *__restrict__ x1, const T *__restrict__ x2, T *__restrict__ out, int C, int H, int W,
     int tiles_x, int tiles_y, float slope, int64_t out_bstride, int dbg) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -484,14 +490,15 @@ __global__ __launch_bounds__(K::THREADS, 2) void corr_fwd_d4_mfma_kernel(
 
     // ---- this wave's row ----
     const int p = lane & 15, kg = lane >> 4;
-    const int y = y0 + wave;
+    const int row = wave % K::TH, part = wave / K::TH;   // (uniform: wave is)
+    const int y = y0 + row;
     u4v a[K::NSEG][K::NKB];
 #pragma unroll
     for (int s = 0; s < K::NSEG; ++s)
 #pragma unroll
         for (int kb = 0; kb < K::NKB; ++kb) {
             const int col = 16 * s + p;
-            a[s][kb] = *reinterpret_cast<const u4v *>(x1t + wave * K::XROW + K::pix(col, 4 * kb + kg));
+            a[s][kb] = *reinterpret_cast<const u4v *>(x1t + row * K::XROW + K::pix(col, 4 * kb + kg));
         }
     __syncthreads();   // every wave holds its x1 operands in registers: the tile's LDS becomes the T tiles
     float *tt = reinterpret_cast<float *>(x1t + wave * K::T_B);
@@ -513,8 +520,8 @@ __global__ __launch_bounds__(K::THREADS, 2) void corr_fwd_d4_mfma_kernel(
     const int st_px = lane % K::TW, st_dx = lane / K::TW;
     const int st_voff = (y < H && x0 + st_px < W) ? (st_dx * plane + y * W + x0 + st_px) * 2 : kDead;
 #pragma unroll 1
-    for (int dyi = 0; dyi < kND; ++dyi) {
-        const unsigned char *wrow = win + (wave + dyi) * K::WROW;
+    for (int dyi = part * K::DPW; dyi < min(kND, (part + 1) * K::DPW); ++dyi) {
+        const unsigned char *wrow = win + (row + dyi) * K::WROW;
         f4v acc[K::NSEG][2];
 #pragma unroll
         for (int s = 0; s < K::NSEG; ++s)
@@ -529,7 +536,7 @@ __global__ __launch_bounds__(K::THREADS, 2) void corr_fwd_d4_mfma_kernel(
                 }
             }
         if (dbg & 4) {   // no T tile, no stores: one store keeps the MFMAs alive
-            if (dyi == 8 && acc[0][0][0] + acc[K::NSEG - 1][1][3] == 123.f) tt[0] = 1.f;
+            if (dyi == min(kND, (part + 1) * K::DPW) - 1 && acc[0][0][0] + acc[K::NSEG - 1][1][3] == 123.f) tt[0] = 1.f;
             continue;
         }
         // the T tile is written by one set of lanes and read back by another (same wave): fence as
@@ -582,6 +589,8 @@ int fwd_pick(const void *in1, const void *in2, void *out, const CorrGeom &g, flo
         return launch_fwd_mfma<FwdMfmaCfg<1>, T>("corr_fwd_d4_mfma_4x64", in1, in2, out, g, slope, obs, s);
     if (g.C <= 64)
         return launch_fwd_mfma<FwdMfmaCfg<2>, T>("corr_fwd_d4_mfma_4x32", in1, in2, out, g, slope, obs, s);
+    if (g.C <= 128)
+        return launch_fwd_mfma<FwdMfmaCfg<4>, T>("corr_fwd_d4_mfma_4x16", in1, in2, out, g, slope, obs, s);
     return CERB_EUNSUPPORTED;
 }
 
@@ -623,7 +632,7 @@ int corr_mfma_backward(const void *in1, const void *in2, const void *gout, void 
     }
 }
 
-// forward, 16-bit storage, C <= 64 (CERB_EUNSUPPORTED otherwise: the caller keeps its VALU kernels)
+// forward, 16-bit storage, C <= 128 (CERB_EUNSUPPORTED otherwise: the caller keeps its VALU kernels)
 int corr_mfma_forward(const void *in1, const void *in2, void *out, const CorrGeom &g, float slope,
                       int64_t obs, int dtype, hipStream_t s) {
     switch (dtype) {

@@ -700,15 +700,17 @@ def test_mfma_backward_equals_the_valu_backward_up_to_output_rounding(dtype, ulp
 
 @pytest.mark.parametrize("dtype,ulp", [(torch.float16, 2.0 ** -10), (torch.bfloat16, 2.0 ** -7)])
 def test_mfma_forward_equals_the_valu_forward_up_to_output_rounding(dtype, ulp):
-    """16-bit storage, C <= 64: the forward runs on the matrix cores (pixel x window-column
+    """16-bit storage, C <= 128: the forward runs on the matrix cores (pixel x window-column
     products per 32 channels, the wanted diagonals extracted through a per-wave LDS tile).  Same
     exact products, fp32 sums, one rounding: at most one unit of the output's last place from
-    the VALU kernel.  Covers both tile shapes (C <= 32: 4 x 64, C <= 64: 4 x 32), ragged tiles,
-    odd channel counts, LeakyReLU fused, the strided (concat-buffer) output, and NaN / Inf
-    reaching exactly the same outputs."""
+    the VALU kernel.  Covers the three tile shapes (C <= 32: 4 x 64, C <= 64: 4 x 32, C <= 128:
+    4 x 16 -- round 5), ragged tiles, odd channel counts, LeakyReLU fused, the strided
+    (concat-buffer) output, and NaN / Inf reaching exactly the same outputs; small shapes also
+    against the oracle."""
     p = (4, 1, 4, 1, 1, 1)
     for k, shp in enumerate([(2, 32, 9, 68), (1, 24, 17, 132), (3, 7, 5, 12), (1, 64, 33, 64),
-                             (2, 40, 6, 200), (1, 33, 4, 36)]):
+                             (2, 40, 6, 200), (1, 33, 4, 36), (2, 128, 9, 36), (1, 65, 17, 68),
+                             (3, 100, 5, 12), (1, 96, 33, 132), (4, 128, 32, 64)]):
         B, C, H, W = shp
         a1 = hash_uniform(shp, 940 + k)
         a2 = hash_uniform(shp, 950 + k)
@@ -734,6 +736,14 @@ def test_mfma_forward_equals_the_valu_forward_up_to_output_rounding(dtype, ulp):
         assert float((out[fin].float() - ref[fin].float()).abs().max()) <= ulp * scale, shp
         assert torch.equal(buf[:, 3:84].view(torch.int16), out.view(torch.int16))
         assert float(buf[:, :3].abs().max()) == 0.0 and float(buf[:, 84:].abs().max()) == 0.0
+        if H * W * C <= 45000:
+            c1, c2 = np.where(np.isfinite(a1), a1, 0.0), np.where(np.isfinite(a2), a2, 0.0)
+            y1 = torch.from_numpy(c1.astype(np.float32)).to(dtype)
+            y2 = torch.from_numpy(c2.astype(np.float32)).to(dtype)
+            got = torch.ops.cerberus.correlation(y1.to(DEV), y2.to(DEV), *p)
+            assert _lib.last_kernel(0).startswith("corr_fwd_d4_mfma") or C <= 16
+            want = oracle.corr_forward_ref(y1.double().numpy(), y2.double().numpy(), 4, 1, 4, 1, 1)
+            assert rel_err(got.double().cpu().numpy(), want) < (2e-3 if dtype == torch.float16 else 1.6e-2), shp
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
@@ -936,14 +946,15 @@ def test_coarse_level_kernels_against_the_oracle(shape):
 def test_coarse_level_forward_with_16bit_storage_against_the_oracle(dtype, tol, shape):
     """fp16 / bf16 storage through the coarse-level forward (loads widened on use, fp32 arithmetic, one rounding on
     store), fused LeakyReLU into a wider 16-bit buffer: against the fp64 oracle on the rounded inputs, as the default
-    dispatch picks it (config 5's coarsest level is the last shape) and forced."""
+    dispatch picks it (config 5's coarsest level is the last shape; since round 5 the matrix-core forward takes
+    C <= 128) and forced."""
     B, C, H, W = shape
     x1 = torch.from_numpy(hash_uniform(shape, 441)).to(dtype)
     x2 = torch.from_numpy(hash_uniform(shape, 442)).to(dtype)
     p = (4, 1, 4, 1, 1)
     ref = oracle.corr_forward_ref(x1.double().numpy(), x2.double().numpy(), *p)
     out = torch.ops.cerberus.correlation(x1.to(DEV), x2.to(DEV), *p, 1)
-    assert _lib.last_kernel(0) == "corr_fwd_d4_coarse_%d" % W, _lib.last_kernel(0)
+    assert _lib.last_kernel(0) == ("corr_fwd_d4_mfma_4x16" if C <= 128 else "corr_fwd_d4_coarse_%d" % W), _lib.last_kernel(0)
     assert out.dtype == dtype
     assert rel_err(out.double().cpu().numpy(), ref) < tol
     buf = torch.full((B, 90, H, W), 7.5, device=DEV, dtype=dtype)

@@ -19,8 +19,9 @@ img = torch.from_numpy(hash_uniform((B, C, H, W), 1)).cuda()
 go = torch.from_numpy(hash_uniform((B, C, H, W), 2)).cuda()
 fl = Workload._flow(B, H, W, 3, kind, "cuda")
 _, ctx = ops.flow_warp_ctx(img, fl, 1, 0)
+want_flow = (sys.argv[3] if len(sys.argv) > 3 else "flow") == "flow"     # "tiles": grad_image alone
 for _ in range(5):
-    ops.flow_warp_backward_ctx(img, fl, ctx, go, 1, 0, True, True)
+    ops.flow_warp_backward_ctx(img, fl, ctx, go, 1, 0, True, want_flow)
 torch.cuda.synchronize()
 lib = _lib.get()
 buf = np.zeros((64, 16), dtype=np.uint64)
