@@ -1170,7 +1170,7 @@ template <typename T>
 int bwd_dispatch(const void *x1, const void *x2, const void *go, void *g1, void *g2,
                  const CorrGeom &g, bool vec, hipStream_t s) {
     if constexpr (sizeof(T) == 2) {
-        // 16-bit storage: the matrix-core kernel (corr_mfma.hip); variants 1-3 keep the VALU kernels
+        // 16-bit storage: the matrix-core kernel (corr_mfma.hip; 11: its row-per-wave form of rounds 2-4); variants 1-3 keep the VALU kernels
         const int v = option(OPT_CORR_BWD_VARIANT);
         if (vec && dma_ok(g) && option(OPT_CORR_NO_MFMA) == 0 && (v == 0 || v == 11))
             return corr_mfma_backward(x1, x2, go, g1, g2, g,

@@ -28,7 +28,9 @@
 // is one ds_read_b128 too.
 //
 // Work decomposition: a workgroup = 4 waves = 4 consecutive rows x 64 pixels x 32 channels of
-// one side; a wave owns one row: D = 4 segments x 2 channel blocks x 4 VGPRs.  LDS: the
+// one side; a wave owns one row (corr_bwd_d4_mfma_kernel, rounds 2-4; variant 11) or -- the default since
+// round 5, corr_bwd_d4_mfma_seg_kernel below -- one 16-pixel segment of all four rows:
+// D = 4 segments (rows) x 2 channel blocks x 4 VGPRs.  LDS: the
 // 12 x 72 source window of the 32 channels (62 KB, channel stride = 16 B mod 128 B: the 16
 // channels of a B read start in different banks) + the A rows (12 KB): 2 workgroups / CU.
 //
@@ -357,6 +359,332 @@ __global__ __launch_bounds__(BwdMfmaCfg::THREADS, 2) void corr_bwd_d4_mfma_kerne
 #endif
 }
 
+// ----------------------------------------------------------------------------------------------
+// Round 5: the same tile with a wave per 16-pixel SEGMENT (all four rows) instead of a wave per row.
+// Why: the compute phase of the kernel above is bound by LDS operand reads, not by the matrix cores
+// (per tile and wave 72 B reads + 36 A reads of 1 KB each against 72 MFMAs of 16 cycles: the CU's
+// 128 B / clk feed four SIMDs).  A window row r serves the outputs (row, ey) with row + ey = r, and a
+// wave that owns all four rows of its segment keeps the B operands of four consecutive window rows in
+// registers: per displacement step ey it reads ONE new window row (2 B reads) and the four band rows
+// (4 A reads) for its eight MFMAs -- 24 + 36 reads per tile instead of 72 + 36.  gradOutput is loaded
+// by lane = (row, pixel of the segment); a lane's nine band values go out as five packed dwords; the
+// four rows' A blocks are skewed by 32 bytes so that they start in different banks.  Same products,
+// same fp32 accumulation order per output (ey ascending, one MFMA per ey): identical bits.
+struct BwdSegCfg : BwdMfmaCfg {
+    static constexpr int ABLK = 16 * AROW + 16;             // halves per (wave, row) block of band rows: 16 pixels + 32 B skew
+    static constexpr size_t LDS_BYTES = 2 * (WIN + TH * TH * ABLK);
+};
+
+// (SIDE is a template parameter so that each side's body is straight-line code: with the side's two load patterns as
+// run-time branches inside the displacement loop the compiler's wait-count pass lost track of the loads in flight and
+// waited for each row of values right after requesting it -- 71 -> 92 us at 32 x 256 x 512)
+template <typename T, int SIDE>
+__device__ __forceinline__ void corr_bwd_seg_body(
+    const T *__restrict__ x1, const T *__restrict__ x2, const T *__restrict__ gout,
+    T *__restrict__ gin1, T *__restrict__ gin2, int C, int H, int W, int tiles_x, int tiles_y,
+    int nslice, int nwalk) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    using K = BwdSegCfg;
+    extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
+    unsigned short *win = smem;                 // [CS][WR ring slots][WC] halves, channel stride CSTR
+    unsigned short *arow = smem + K::WIN;       // [wave = segment][row][16 pixels][AROW] (+ skew)
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+
+    const int walks_y = (tiles_y + nwalk - 1) / nwalk;
+    int bid = xcd_chunk(blockIdx.x, gridDim.x);
+    constexpr int side = SIDE; bid >>= 1;   // 0: gradInput1
+    const int slice = __builtin_amdgcn_readfirstlane(bid % nslice); bid /= nslice;
+    const int tx = __builtin_amdgcn_readfirstlane(bid % tiles_x); bid /= tiles_x;
+    const int wy = __builtin_amdgcn_readfirstlane(bid % walks_y);
+    const int b = __builtin_amdgcn_readfirstlane(bid / walks_y);
+    const int ty_begin = wy * nwalk, ty_end = min(tiles_y, ty_begin + nwalk);
+    const int x0 = tx * K::TW;
+    const int c_begin = slice * K::CS;
+    const int plane = H * W;
+
+    const T *src = (side == 0 ? x2 : x1) + static_cast<int64_t>(b) * C * plane;
+    T *dst = (side == 0 ? gin1 : gin2) + static_cast<int64_t>(b) * C * plane;
+    const __amdgpu_buffer_rsrc_t rsrc_src = uniform_rsrc(src, C * plane * 2);
+    const __amdgpu_buffer_rsrc_t rsrc_dst = uniform_rsrc(dst, C * plane * 2);
+    const __amdgpu_buffer_rsrc_t rsrc_go =
+        uniform_rsrc(gout + static_cast<int64_t>(b) * (kND * kND) * plane, kND * kND * plane * 2);
+
+    // ---- gradOutput: lane = (row of the tile, pixel of this wave's segment) ----
+    // A wave-level load instruction costs the address path ~9 cycles per CU whether its lanes fetch 2 or 4 bytes
+    // (tools/ubench/vmem_rate.hip), and 81 halfword loads per lane and tile made this path the kernel's largest single
+    // cost.  Two neighbouring lanes (pixels 2m, 2m + 1) therefore fetch DWORDS -- both pixels of one plane each, two
+    // different planes -- and swap halves (one DPP move + one v_perm at the time the values are used):
+    //   side 0 (no shifts): planes (0,1) (2,3) (4,5) (6,7) (8,-) of a displacement row: 5 loads instead of 9;
+    //   side 1 (plane ex is read at column x + ex): the even shifts pair up the same way -- (0,2) (4,6) (8,-) -- the odd
+    //   ones would pair lanes (2m - 1, 2m) across the segment's ends and stay halfword loads: 7 instead of 9.
+    const int grow = lane >> 4, gp = lane & 15;
+    const int gx = x0 + 16 * wave + gp;
+    const bool odd = gp & 1;
+    const int g_step = side ? -plane * 2 : plane * 2;   // plane step per ex
+    // Per-lane byte offsets: column + the plane's distance from the LOWEST plane of the displacement row (the scalar offset
+    // of all its loads), so that every offset is non-negative and one SGPR serves a row.  An invalid column is 2^30 (a batch
+    // item is smaller: out of range whatever is added), an invalid row 2^31.
+    constexpr int NRAW = 7;
+    constexpr int kDeadCol = 0x40000000;
+    const int pstep = plane * 2;
+    int g_off[NRAW];
+    {
+        const int pc = gx & ~1;                           // first column of the pair's dword at shift 0
+        auto col = [&](int c, int planes) { return (c >= 0 && c < W) ? c * 2 + planes * pstep : kDeadCol; };
+        if (!side) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) g_off[k] = col(pc, 2 * k + (odd ? 1 : 0));
+            g_off[4] = odd ? kDeadCol : col(pc, 8);
+            g_off[5] = g_off[6] = kDeadCol;
+        } else {       // plane ex of the row lies (8 - ex) planes above its lowest
+            g_off[0] = odd ? col(pc - 2, 6) : col(pc - 4, 8);     // planes ex = 2 | 0
+            g_off[1] = odd ? col(pc + 2, 2) : col(pc, 4);         // planes ex = 6 | 4
+            g_off[2] = odd ? kDeadCol : col(pc + 4, 0);           // plane ex = 8
+#pragma unroll
+            for (int k = 0; k < 4; ++k) g_off[3 + k] = col(gx + 2 * k + 1 - kD, 7 - 2 * k);   // planes ex = 1, 3, 5, 7: halfwords
+        }
+    }
+    unsigned raw[kND][5];            // the dwords (side 1: the first three)
+    unsigned short rawh[kND][4];     // side 1: the halfwords of the odd shifts
+    auto load_g_row = [&](int j, int y) {     // the nine values of displacement row j; y: this lane's row
+        const int yy = side ? y + j - kD : y;
+        const bool rok = yy >= 0 && yy < H && y < H;
+        const int lowest = side ? kND * kND - 1 - j * kND - (kND - 1) : j * kND;
+        const int base_s = __builtin_amdgcn_readfirstlane(lowest * pstep);
+        const int row_off = rok ? yy * W * 2 : kDead;
+        if (!side) {
+#pragma unroll
+            for (int k = 0; k < 5; ++k) raw[j][k] = __builtin_amdgcn_raw_buffer_load_b32(rsrc_go, g_off[k] + row_off, base_s, 0);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) raw[j][k] = __builtin_amdgcn_raw_buffer_load_b32(rsrc_go, g_off[k] + row_off, base_s, 0);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) rawh[j][k] = __builtin_amdgcn_raw_buffer_load_b16(rsrc_go, g_off[3 + k] + row_off, base_s, 0);
+        }
+    };
+    // (this lane's value, the value of the partner's plane) from the dwords the two lanes of a pair fetched
+    const unsigned swap_sel = odd ? 0x03020706u : 0x05040100u;
+    auto exchange = [&](unsigned own) {
+        const unsigned partner = static_cast<unsigned>(__builtin_amdgcn_mov_dpp(static_cast<int>(own), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+        return __builtin_amdgcn_perm(partner, own, swap_sel);
+    };
+#pragma unroll
+    for (int j = 0; j < kND; ++j) load_g_row(j, ty_begin * K::TH + grow);   // in flight during the window copy
+
+    // ---- first tile: the whole 12-row window -> ring; zero the A rows ----
+    unsigned short *my_blk = arow + (wave * K::TH + grow) * K::ABLK;   // this lane's (wave, row) block
+    {
+        constexpr int POS = K::WR * K::UPR;
+        static_assert(POS <= K::THREADS, "one unit position per thread");
+        const int y0 = ty_begin * K::TH;
+        const int row = tid / K::UPR, un = tid % K::UPR;
+        const int sy = y0 - kD + row, sx = x0 - kD + 4 * un;
+        const bool ok = tid < POS && un < (K::TW + 2 * kD) / 4 && sy >= 0 && sy < H && sx >= 0 && sx < W;
+        const int w_voff = ok ? (sy * W + sx) * 2 : kDead;
+        const int slot = (y0 + row) % K::WR;                // ring slot of window row (sy + 4)
+        u2v v[K::CS];
+#pragma unroll
+        for (int ch = 0; ch < K::CS; ++ch) {
+            v[ch] = u2v{0, 0};
+            if (c_begin + ch < C)                           // uniform
+                v[ch] = __builtin_amdgcn_raw_buffer_load_b64(rsrc_src, w_voff, (c_begin + ch) * plane * 2, 0);
+        }
+        if (tid < POS) {
+            unsigned short *w = win + slot * K::WC + un * 4;
+#pragma unroll
+            for (int ch = 0; ch < K::CS; ++ch) *reinterpret_cast<u2v *>(w + ch * K::CSTR) = v[ch];
+        }
+        unsigned short *mine = my_blk + gp * K::AROW;
+#pragma unroll
+        for (int i = 0; i < K::AROW / 8; ++i) *reinterpret_cast<u4v *>(mine + 8 * i) = u4v{0, 0, 0, 0};
+    }
+    __syncthreads();
+
+    // next tile's 4 new rows: thread -> (unit position of the 4 x 20 units, every 3rd channel)
+    constexpr int NPOS = K::TH * K::UPR, NCG = K::THREADS / NPOS, NPF = (K::CS + NCG - 1) / NCG;
+    const int pf_pos = tid % NPOS, pf_cg = tid / NPOS;      // pf_cg == NCG: idle thread
+    const int pf_row = pf_pos / K::UPR, pf_un = pf_pos % K::UPR;
+    const int pf_sx = x0 - kD + 4 * pf_un;
+    const bool pf_col_ok = pf_cg < NCG && pf_un < (K::TW + 2 * kD) / 4 && pf_sx >= 0 && pf_sx < W;
+
+    const int p = lane & 15, kg = lane >> 4;
+    // band slots gp .. gp + 8 of this lane's A row, as five dwords starting at the even slot gp & ~1 (the half below an odd
+    // gp and the half above an even gp + 8 lie outside every band: they stay zero)
+    unsigned *my_band = reinterpret_cast<unsigned *>(my_blk + gp * K::AROW + (gp & ~1));
+    const unsigned short *a_rd = arow + wave * K::TH * K::ABLK + p * K::AROW + 8 * (kg < 3 ? kg : 0);
+    const unsigned short *b_lane = win + p * K::CSTR + 8 * kg + 16 * wave;
+    const float inv_nelems = 1.0f / static_cast<float>(C);
+
+    for (int ty = ty_begin; ty < ty_end; ++ty) {
+        const int y0 = ty * K::TH;
+        const bool more = ty + 1 < ty_end;
+        u2v pf[NPF];
+        if (more) {
+            const int sy = y0 + K::TH + kD + pf_row;
+            const int base = (pf_col_ok && sy < H) ? (sy * W + pf_sx) * 2 : kDead;
+#pragma unroll
+            for (int k = 0; k < NPF; ++k) {
+                const int ch = pf_cg + NCG * k;
+                const bool on = ch < K::CS && c_begin + ch < C;
+                pf[k] = __builtin_amdgcn_raw_buffer_load_b64(rsrc_src, on ? base + (c_begin + ch) * plane * 2 : kDead, 0, 0);
+            }
+        }
+        f4v acc[K::TH][K::CB];
+#pragma unroll
+        for (int r = 0; r < K::TH; ++r)
+#pragma unroll
+            for (int cb = 0; cb < K::CB; ++cb) acc[r][cb] = f4v{0.f, 0.f, 0.f, 0.f};
+        auto wave_lds_fence = [] {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        };
+        auto write_band = [&](int eyi) {
+            unsigned pk[5];       // (value 2k, value 2k + 1) of this lane's pixel
+            if (!side) {
+#pragma unroll
+                for (int k = 0; k < 5; ++k) pk[k] = exchange(raw[eyi][k]);
+            } else {
+                const unsigned xa = exchange(raw[eyi][0]), xb = exchange(raw[eyi][1]);   // (v0, v2), (v4, v6)
+                pk[0] = __builtin_amdgcn_perm(rawh[eyi][0], xa, 0x05040100u);
+                pk[1] = __builtin_amdgcn_perm(rawh[eyi][1], xa, 0x05040302u);
+                pk[2] = __builtin_amdgcn_perm(rawh[eyi][2], xb, 0x05040100u);
+                pk[3] = __builtin_amdgcn_perm(rawh[eyi][3], xb, 0x05040302u);
+                pk[4] = exchange(raw[eyi][2]);
+            }
+            wave_lds_fence();
+            unsigned prev = 0;
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {       // an odd pixel's dwords start one slot lower: (value 2k - 1, value 2k)
+                my_band[k] = odd ? __builtin_amdgcn_alignbit(pk[k], prev, 16) : pk[k];
+                prev = pk[k];
+            }
+            wave_lds_fence();
+        };
+        auto read_a = [&](u4v (&a)[K::TH]) {
+#pragma unroll
+            for (int r = 0; r < K::TH; ++r) {
+                a[r] = *reinterpret_cast<const u4v *>(a_rd + r * K::ABLK);
+                if (kg == 3) a[r] = u4v{0, 0, 0, 0};   // k = 24..31: outside every band
+            }
+        };
+        // B operands of window rows t .. t + 3 (ring slots), both channel blocks: a sliding register window
+        const int slot0 = __builtin_amdgcn_readfirstlane(y0 % K::WR);    // ring slot of window row 0 (image row y0 - 4)
+        auto read_b = [&](int r, u4v (&bw)[K::CB]) {
+            int sl = slot0 + r;
+            sl = sl >= K::WR ? sl - K::WR : sl;
+            const unsigned short *b_rd = b_lane + sl * K::WC;
+#pragma unroll
+            for (int cb = 0; cb < K::CB; ++cb) bw[cb] = *reinterpret_cast<const u4v *>(b_rd + cb * 16 * K::CSTR);
+        };
+        u4v bwin[K::TH][K::CB];
+        u4v a_cur[K::TH], a_nxt[K::TH];
+        // The next tile's gradOutput values are requested row by row, each as soon as its registers are free (its band has
+        // been written): every row of values gets a whole tile period to arrive.  (Requested together behind the MFMA loop,
+        // as the kernel above does, the trip to memory was exposed once per tile.)
+        const int ly = y0 + grow;                                    // this lane's row as a gradOutput / redo pixel
+        write_band(0);
+        if (more) load_g_row(0, ly + K::TH);
+        read_a(a_cur);
+#pragma unroll
+        for (int r = 0; r < K::TH - 1; ++r) read_b(r, bwin[r]);
+#pragma unroll
+        for (int eyi = 0; eyi < kND; ++eyi) {
+            read_b(eyi + K::TH - 1, bwin[(eyi + K::TH - 1) % K::TH]);
+            if (eyi + 1 < kND) {
+                write_band(eyi + 1);
+                if (more) load_g_row(eyi + 1, ly + K::TH);
+                read_a(a_nxt);
+            }
+#pragma unroll
+            for (int r = 0; r < K::TH; ++r)
+#pragma unroll
+                for (int cb = 0; cb < K::CB; ++cb)
+                    acc[r][cb] = Mma<T>::run(a_cur[r], bwin[(r + eyi) % K::TH][cb], acc[r][cb]);
+#pragma unroll
+            for (int r = 0; r < K::TH; ++r) a_cur[r] = a_nxt[r];
+        }
+        // ---- non-finite results: redo this segment exactly (see the kernel above) ----
+        f4v tot = acc[0][0];
+#pragma unroll
+        for (int r = 0; r < K::TH; ++r)
+#pragma unroll
+            for (int cb = 0; cb < K::CB; ++cb)
+                if (r + cb) tot += acc[r][cb];
+        const float tsum = (tot[0] + tot[1]) + (tot[2] + tot[3]);
+        const bool bad = (__float_as_uint(tsum) & 0x7F800000u) == 0x7F800000u;
+        const bool redo = __builtin_amdgcn_ballot_w64(bad) != 0;   // wave-uniform
+        if (redo) {
+            const int x = gx;
+            for (int c = 0; c < K::CS && c_begin + c < C; ++c) {
+                const unsigned short *wc = win + c * K::CSTR + 16 * wave + gp;
+                float sum = 0.f;
+                int sl = (y0 + grow) % K::WR;
+#pragma unroll 1
+                for (int j = 0; j < kND; ++j) {
+                    const int yy = side ? ly + j - kD : ly;
+                    const bool rok = yy >= 0 && yy < H && ly < H;
+                    const int d0 = side ? kND * kND - 1 - j * kND : j * kND;
+                    const int plane_off = __builtin_amdgcn_readfirstlane(d0 * plane * 2);
+#pragma unroll
+                    for (int i = 0; i < kND; ++i) {
+                        const int xx = side ? gx + i - kD : gx;
+                        const unsigned short gb = __builtin_amdgcn_raw_buffer_load_b16(
+                            rsrc_go, (rok && xx >= 0 && xx < W) ? (yy * W + xx) * 2 : kDead, plane_off + i * g_step, 0);
+                        sum = fmaf(Mma<T>::widen(gb), Mma<T>::widen(wc[sl * K::WC + i]), sum);
+                    }
+                    sl = sl + 1 == K::WR ? 0 : sl + 1;
+                }
+                __builtin_amdgcn_raw_buffer_store_b16(
+                    static_cast<unsigned short>(Mma<T>::pack2(sum * inv_nelems, 0.f)), rsrc_dst,
+                    (x < W && ly < H) ? ((c_begin + c) * plane + ly * W + x) * 2 : kDead, 0, 0);
+            }
+        }
+        // ---- D[pixel][channel] -> gradInput[c][y][x]: 4 consecutive pixels of one channel per lane ----
+        if (!redo) {
+#pragma unroll
+            for (int cb = 0; cb < K::CB; ++cb) {
+                const int c = c_begin + cb * 16 + p;
+#pragma unroll
+                for (int r = 0; r < K::TH; ++r) {
+                    const int x = x0 + 16 * wave + 4 * kg, y = y0 + r;
+                    const f4v d = acc[r][cb];
+                    const u2v o = {Mma<T>::pack2(d[0] * inv_nelems, d[1] * inv_nelems),
+                                   Mma<T>::pack2(d[2] * inv_nelems, d[3] * inv_nelems)};
+                    __builtin_amdgcn_raw_buffer_store_b64(
+                        o, rsrc_dst, (c < C && x < W && y < H) ? (c * plane + y * W + x) * 2 : kDead, 0, 0);
+                }
+            }
+        }
+        if (!more) break;
+        // ---- ring update: the new rows replace the 4 oldest (rows y0 - 4 .. y0 - 1) ----
+        __syncthreads();   // every wave is done reading this tile's window
+        if (pf_cg < NCG) {
+            const int nslot = (y0 + K::TH + 2 * kD + pf_row) % K::WR;   // window row (y0 + 8 + pf_row) + 4
+            unsigned short *w = win + nslot * K::WC + pf_un * 4;
+#pragma unroll
+            for (int k = 0; k < NPF; ++k) {
+                const int ch = pf_cg + NCG * k;
+                if (ch < K::CS) *reinterpret_cast<u2v *>(w + ch * K::CSTR) = pf[k];
+            }
+        }
+        __syncthreads();
+    }
+#endif
+}
+
+template <typename T>
+__global__ __launch_bounds__(BwdSegCfg::THREADS, 2) void corr_bwd_d4_mfma_seg_kernel(
+    const T *__restrict__ x1, const T *__restrict__ x2, const T *__restrict__ gout,
+    T *__restrict__ gin1, T *__restrict__ gin2, int C, int H, int W, int tiles_x, int tiles_y,
+    int nslice, int nwalk) {
+    if (xcd_chunk(blockIdx.x, gridDim.x) & 1)    // uniform: consecutive workgroups are the two sides of one tile column
+        corr_bwd_seg_body<T, 1>(x1, x2, gout, gin1, gin2, C, H, W, tiles_x, tiles_y, nslice, nwalk);
+    else
+        corr_bwd_seg_body<T, 0>(x1, x2, gout, gin1, gin2, C, H, W, tiles_x, tiles_y, nslice, nwalk);
+}
+
 // ============================================================================
 // forward
 // ============================================================================
@@ -596,8 +924,8 @@ int fwd_pick(const void *in1, const void *in2, void *out, const CorrGeom &g, flo
 
 template <typename T>
 int launch(const void *in1, const void *in2, const void *gout, void *gin1, void *gin2,
-           const CorrGeom &g, hipStream_t s) {
-    using K = BwdMfmaCfg;
+           const CorrGeom &g, hipStream_t s, bool seg) {
+    using K = BwdSegCfg;
     const int tiles_x = (g.W + K::TW - 1) / K::TW, tiles_y = (g.H + K::TH - 1) / K::TH;
     const int nslice = (g.C + K::CS - 1) / K::CS;
     // tiles a workgroup walks down: as many as still leave ~512 workgroups = ONE round of 2 per
@@ -609,11 +937,21 @@ int launch(const void *in1, const void *in2, const void *gout, void *gin1, void 
     if (const int forced = option(OPT_CORR_BWD_CSLICE)) nwalk = std::max(1, std::min(forced, tiles_y));
     const int64_t blocks = cols * ((tiles_y + nwalk - 1) / nwalk);
     if (blocks > 0x7fffffff) return CERB_ETOOLARGE;
+    if (seg) {
+        static std::atomic<uint64_t> lds_done_seg{0};
+        if (const int rc = ensure_lds(corr_bwd_d4_mfma_seg_kernel<T>, K::LDS_BYTES, &lds_done_seg)) return rc;
+        note_kernel(1, "corr_bwd_d4_mfma_seg_4x64");
+        hipLaunchKernelGGL((corr_bwd_d4_mfma_seg_kernel<T>), dim3(static_cast<unsigned>(blocks)), dim3(K::THREADS),
+                           K::LDS_BYTES, s, static_cast<const T *>(in1), static_cast<const T *>(in2),
+                           static_cast<const T *>(gout), static_cast<T *>(gin1), static_cast<T *>(gin2), g.C,
+                           g.H, g.W, tiles_x, tiles_y, nslice, nwalk);
+        return launch_status();
+    }
     static std::atomic<uint64_t> lds_done{0};
-    if (const int rc = ensure_lds(corr_bwd_d4_mfma_kernel<T>, K::LDS_BYTES, &lds_done)) return rc;
+    if (const int rc = ensure_lds(corr_bwd_d4_mfma_kernel<T>, BwdMfmaCfg::LDS_BYTES, &lds_done)) return rc;
     note_kernel(1, "corr_bwd_d4_mfma_4x64");
     hipLaunchKernelGGL((corr_bwd_d4_mfma_kernel<T>), dim3(static_cast<unsigned>(blocks)), dim3(K::THREADS),
-                       K::LDS_BYTES, s, static_cast<const T *>(in1), static_cast<const T *>(in2),
+                       BwdMfmaCfg::LDS_BYTES, s, static_cast<const T *>(in1), static_cast<const T *>(in2),
                        static_cast<const T *>(gout), static_cast<T *>(gin1), static_cast<T *>(gin2), g.C,
                        g.H, g.W, tiles_x, tiles_y, nslice, nwalk, debug_mask());
     return launch_status();
@@ -626,8 +964,8 @@ int launch(const void *in1, const void *in2, const void *gout, void *gin1, void 
 int corr_mfma_backward(const void *in1, const void *in2, const void *gout, void *gin1, void *gin2,
                        const CorrGeom &g, int dtype, hipStream_t s) {
     switch (dtype) {
-        case CERB_F16: return launch<__half>(in1, in2, gout, gin1, gin2, g, s);
-        case CERB_BF16: return launch<hip_bfloat16>(in1, in2, gout, gin1, gin2, g, s);
+        case CERB_F16: return launch<__half>(in1, in2, gout, gin1, gin2, g, s, option(OPT_CORR_BWD_VARIANT) != 11);
+        case CERB_BF16: return launch<hip_bfloat16>(in1, in2, gout, gin1, gin2, g, s, option(OPT_CORR_BWD_VARIANT) != 11);
         default: return CERB_EUNSUPPORTED;
     }
 }

@@ -228,7 +228,8 @@ int cerberus_area_pyramid(const void *src, void *const *dsts, const int *out_h, 
  *   "corr_bwd_variant"   : 0 = auto, 1 = all 81 displacements per lane (register-staged),
  *                          3 = three displacement groups, 4 / 5 = LDS-DMA with the 8x64 /
  *                          16x32 tile (fp32, W % 4 == 0), 8 = displacement-row streaming,
- *                          11 = the matrix-core kernel (fp16 / bf16 storage; auto uses it),
+ *                          11 = the matrix-core kernel in its row-per-wave form of rounds 2-4 (fp16 / bf16 storage; auto
+ *                          uses the segment-per-wave form of round 5: same bits, 8-12 % faster),
  *                          12 = whole image rows per wavefront (fp32, W in {256, 128, 64}; auto uses
  *                          it where such a map has enough workgroups for the chip; 13 = auto, but not
  *                          on 64-wide maps), 14 = the coarse-level kernel (fp32, W = 16 / 32 / 64,

@@ -680,7 +680,7 @@ def test_mfma_backward_equals_the_valu_backward_up_to_output_rounding(dtype, ulp
         x2 = torch.from_numpy(hash_uniform(shp, 920 + k)).to(dtype).to(DEV)
         go = torch.from_numpy(hash_uniform((B, 81, H, W), 930 + k)).to(dtype).to(DEV)
         g1, g2 = torch.ops.cerberus.correlation_backward(x1, x2, go, *p)
-        assert _lib.last_kernel(1) == "corr_bwd_d4_mfma_4x64", _lib.last_kernel(1)
+        assert _lib.last_kernel(1) == "corr_bwd_d4_mfma_seg_4x64", _lib.last_kernel(1)
         _lib.set_option("corr_bwd_variant", 1)
         try:
             v1, v2 = torch.ops.cerberus.correlation_backward(x1, x2, go, *p)
@@ -768,7 +768,7 @@ def test_mfma_backward_keeps_nonfinite_values_local(dtype):
     x2 = torch.from_numpy(a2).to(dtype).to(DEV)
     go = torch.from_numpy(g).to(dtype).to(DEV)
     g1, g2 = torch.ops.cerberus.correlation_backward(x1, x2, go, *p)
-    assert _lib.last_kernel(1) == "corr_bwd_d4_mfma_4x64"
+    assert _lib.last_kernel(1) == "corr_bwd_d4_mfma_seg_4x64"
     _lib.set_option("corr_bwd_variant", 1)
     try:
         v1, v2 = torch.ops.cerberus.correlation_backward(x1, x2, go, *p)
@@ -783,6 +783,31 @@ def test_mfma_backward_keeps_nonfinite_values_local(dtype):
         assert torch.equal(torch.sign(a[torch.isinf(b)]), torch.sign(b[torch.isinf(b)]))
         scale = float(b[fin].float().abs().max())
         assert float((a[fin].float() - b[fin].float()).abs().max()) <= ulp * scale
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_mfma_backward_segment_per_wave_equals_row_per_wave_bit_for_bit(dtype):
+    """Round 5: the matrix-core backward with a wave per 16-pixel segment (window rows kept in registers across the
+    displacement steps, gradOutput fetched as dwords by lane pairs that swap halves, the odd shifts of side 1 as
+    halfwords) runs the same MFMAs on the same operands in the same order as the row-per-wave kernel it replaces
+    (variant 11): identical bits on finite data -- ragged tiles, every border, several walks, channel slices."""
+    p = (4, 1, 4, 1, 1, 1)
+    for k, shp in enumerate([(2, 32, 9, 68), (1, 24, 17, 132), (3, 7, 5, 12), (1, 64, 33, 64), (1, 256, 16, 32),
+                             (2, 40, 4, 200), (2, 40, 13, 132), (4, 32, 128, 256), (1, 33, 70, 260)]):
+        B, C, H, W = shp
+        x1 = torch.from_numpy(hash_uniform(shp, 1910 + k)).to(dtype).to(DEV)
+        x2 = torch.from_numpy(hash_uniform(shp, 1920 + k)).to(dtype).to(DEV)
+        go = torch.from_numpy(hash_uniform((B, 81, H, W), 1930 + k)).to(dtype).to(DEV)
+        g1, g2 = torch.ops.cerberus.correlation_backward(x1, x2, go, *p)
+        assert _lib.last_kernel(1) == "corr_bwd_d4_mfma_seg_4x64", _lib.last_kernel(1)
+        _lib.set_option("corr_bwd_variant", 11)
+        try:
+            r1, r2 = torch.ops.cerberus.correlation_backward(x1, x2, go, *p)
+            assert _lib.last_kernel(1) == "corr_bwd_d4_mfma_4x64", _lib.last_kernel(1)
+        finally:
+            _lib.set_option("corr_bwd_variant", 0)
+        assert torch.equal(g1.view(torch.int16), r1.view(torch.int16)), shp
+        assert torch.equal(g2.view(torch.int16), r2.view(torch.int16)), shp
 
 
 @pytest.mark.parametrize("dtype,ulp", [(torch.float16, 2.0 ** -10), (torch.bfloat16, 2.0 ** -7)])
