@@ -813,7 +813,7 @@ def test_mfma_backward_segment_per_wave_equals_row_per_wave_bit_for_bit(dtype):
 @pytest.mark.parametrize("dtype,ulp", [(torch.float16, 2.0 ** -10), (torch.bfloat16, 2.0 ** -7)])
 def test_seeded_random_shape_sweep_16bit_tuned_vs_generic(dtype, ulp):
     """40 seeded random shapes in 16-bit storage: whatever the dispatcher picks (matrix-core
-    forward for 16 < C <= 64, vector forward otherwise, matrix-core backward walking 1..n tiles,
+    forward for 16 < C <= 128, vector forward otherwise, matrix-core backward walking 1..n tiles,
     generic kernels when W % 4 != 0) against the generic 16-bit kernels (fp32 accumulation, same
     exact products), forward and both gradients: at most two units of the output's last place."""
     rng = np.random.RandomState(20241003)
@@ -1125,7 +1125,7 @@ def test_config5_16bit_levels_against_the_oracle_at_full_size(lvl, dtype, tol):
     g1, g2 = torch.ops.cerberus.correlation_backward(x1.to(DEV), x2.to(DEV), go.to(DEV), *p, 1)
     bwd_name = _lib.last_kernel(1)
     assert "mfma" in bwd_name, bwd_name
-    if 16 < C <= 64:
+    if 16 < C <= 128:
         assert "mfma" in fwd_name, fwd_name
     a1, a2, ag = x1.double().numpy(), x2.double().numpy(), go.double().numpy()
     assert rel_err(out.double().cpu().numpy(), oracle.corr_forward_ref(a1, a2, *p)) < tol
