@@ -236,11 +236,19 @@ def _correlation_backward_leaky_cuda(input1, input2, grad_buffer, fwd_buffer, ch
                 channel_offset < 0 or channel_offset + oc > t.shape[1]):
             raise RuntimeError("%s: %s %s cannot hold channels [%d, %d) of a (%d, %d, %d, %d) cost volume"
                                % (what, name, tuple(t.shape), channel_offset, channel_offset + oc, B, oc, oh, ow))
-    plane_dense = lambda t: t.stride(3) == 1 and t.stride(2) == ow and t.stride(1) == oh * ow
+    # plane-dense AND one item per batch stride: an expanded gradient (``out.sum(0)`` hands over ``grad.expand(...)``
+    # with batch stride 0) has dense planes but B items in ONE item's storage -- the library would read past it
+    # (ADVICE r5), so it is materialised like any other non-dense layout
+    def usable(t):
+        return (t.stride(3) == 1 and t.stride(2) == ow and t.stride(1) == oh * ow and
+                (B == 1 or t.stride(0) >= t.shape[1] * oh * ow))
     go = grad_buffer.to(dtype=x1.dtype)
-    if not plane_dense(go):
+    if not usable(go):
         go = go.contiguous()
-    fo = fwd_buffer if (fwd_buffer.dtype == x1.dtype and plane_dense(fwd_buffer)) else fwd_buffer.to(x1.dtype).contiguous()
+    fo = fwd_buffer if (fwd_buffer.dtype == x1.dtype and usable(fwd_buffer)) else fwd_buffer.to(x1.dtype).contiguous()
+    # the real batch stride always (the C ABI reads 0 as "dense": never hand it a Python-side 0)
+    go_bs = go.stride(0) if B > 1 else go.shape[1] * oh * ow
+    fo_bs = fo.stride(0) if B > 1 else fo.shape[1] * oh * ow
     g1, g2 = torch.empty_like(x1), torch.empty_like(x2)
     if x1.numel() == 0:
         return [g1, g2]
@@ -250,8 +258,8 @@ def _correlation_backward_leaky_cuda(input1, input2, grad_buffer, fwd_buffer, ch
     ws = torch.empty((ws_bytes + 7) // 8, dtype=torch.int64, device=x1.device)   # caching allocator: 512-byte aligned
     with torch.cuda.device(x1.device):
         rc = lib.cerberus_correlation_backward_ex(
-            x1.data_ptr(), x2.data_ptr(), go[:, channel_offset].data_ptr(), go.stride(0),
-            fo[:, channel_offset].data_ptr(), fo.stride(0), ctypes.c_float(float(negative_slope)),
+            x1.data_ptr(), x2.data_ptr(), go[:, channel_offset].data_ptr(), go_bs,
+            fo[:, channel_offset].data_ptr(), fo_bs, ctypes.c_float(float(negative_slope)),
             ws.data_ptr(), ws_bytes, g1.data_ptr(), g2.data_ptr(), B, C, H, W, pad_size, kernel_size,
             max_displacement, stride1, stride2, code, _stream_ptr(x1))
     _lib.check(rc, what)
@@ -463,7 +471,7 @@ def _area_resize_cuda(image, out_h, out_w):
 def _area_pyramid_cuda(image, sizes) -> List[torch.Tensor]:
     """``[F.interpolate(image, (h, w), mode='area') for (h, w) in sizes]`` (``sizes`` flat: h0, w0, h1, w1, ...):
     how unFlowLoss brings a target image to every flow scale (UnFlowLoss.py:279-280).  A scale of the image's
-    own size is the image itself (no launch, no copy); the others come from one pass over the source when they
+    own size is a copy of the image; the others come from one pass over the source when they
     are integer ratios of it (cerberus_area_pyramid), bit-identical to ``area_resize`` scale by scale."""
     what = "cerberus::area_pyramid"
     if image.dim() != 4:
@@ -478,7 +486,9 @@ def _area_pyramid_cuda(image, sizes) -> List[torch.Tensor]:
     pairs = [(int(sizes[i]), int(sizes[i + 1])) for i in range(0, len(sizes), 2)]
     if any(h < 1 or w < 1 for h, w in pairs):
         raise RuntimeError("%s: output sizes must be positive, got %s" % (what, pairs))
-    outs = [x if (h, w) == (H, W) else x.new_empty((B, C, h, w)) for h, w in pairs]
+    # a scale of the image's own size is a COPY (F.interpolate returns one; a custom op must not return an alias of
+    # its input: ADVICE r5) -- unFlowLoss asks for it at most once per step and only on pyramids that start at 1/1
+    outs = [x.clone() if (h, w) == (H, W) else x.new_empty((B, C, h, w)) for h, w in pairs]
     todo = [(o, hw) for o, hw in zip(outs, pairs) if hw != (H, W) and o.numel()]
     if not todo:
         return outs

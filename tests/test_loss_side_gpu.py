@@ -281,6 +281,38 @@ def test_concat_backward_equals_the_three_pass_formula(dtype, tol):
     assert rel_err(h2.float().cpu().numpy(), r2.float().cpu().numpy()) <= tol
 
 
+def test_concat_backward_takes_an_expanded_gradient():
+    """``correlation_leaky(...).sum(0)`` hands the backward ``grad.expand(...)`` -- dense planes, batch
+    stride 0.  The library reads a batch stride of 0 as "dense" and would walk B items out of one item's storage; the
+    binding must materialise such a gradient.  Against the same call on the materialised gradient, bit for bit."""
+    shape = (3, 16, 12, 20)
+    x1 = dev(hash_uniform(shape, 66)).requires_grad_(True)
+    x2 = dev(hash_uniform(shape, 67)).requires_grad_(True)
+    w = dev(hash_uniform((81, 12, 20), 68))
+    y = torch.ops.cerberus.correlation_leaky(x1, x2, *CORR_P, 0.1)
+    (y.sum(0) * w).sum().backward()                              # the gradient arrives as w.expand(3, 81, 12, 20)
+    g1, g2 = x1.grad.clone(), x2.grad.clone()
+    x1.grad = x2.grad = None
+    y = torch.ops.cerberus.correlation_leaky(x1, x2, *CORR_P, 0.1)
+    y.backward(w.expand(3, 81, 12, 20).contiguous())
+    assert torch.equal(g1, x1.grad) and torch.equal(g2, x2.grad)
+    # the raw op with an expanded gradient AND an expanded stored volume
+    fwd = y.detach()[:1].expand(3, 81, 12, 20)
+    r = torch.ops.cerberus.correlation_backward_leaky(x1.detach(), x2.detach(), w.expand(3, 81, 12, 20), fwd, 0, *CORR_P, 0.1)
+    q = torch.ops.cerberus.correlation_backward_leaky(x1.detach(), x2.detach(), w.expand(3, 81, 12, 20).contiguous(),
+                                                      fwd.contiguous(), 0, *CORR_P, 0.1)
+    assert torch.equal(r[0], q[0]) and torch.equal(r[1], q[1])
+
+
+def test_area_pyramid_identity_scale_is_a_copy_not_an_alias():
+    """a custom op must not return its input; F.interpolate returns a copy as well."""
+    x = dev(hash_uniform((1, 3, 16, 32), 69))
+    outs = torch.ops.cerberus.area_pyramid(x, [16, 32, 8, 16])
+    assert torch.equal(outs[0], x) and outs[0].data_ptr() != x.data_ptr()
+    outs[0].zero_()
+    assert float(x.abs().sum()) > 0
+
+
 def test_unflow_loss_uses_the_pyramid_and_matches_the_torch_backend():
     """unFlowLoss on the HIP ops (one pyramid pass per image, context-free RGB warps) against its own stock-op backend."""
     from cerberusnet_amd.loss_functions.UnFlowLoss import unFlowLoss

@@ -5,10 +5,11 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 TAG=${1:-r05}
 OUT=gpurun_out/profiles
 mkdir -p $OUT
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/_ls -- python3 tools/prof_loss_side.py 8 > /dev/null 2> $OUT/_ls.err
+FAILED=0
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/_ls -- python3 tools/prof_loss_side.py 8 > /dev/null 2> $OUT/_ls.err || { echo "rocprofv3 trace pass failed: $OUT/_ls.err" >&2; FAILED=1; }
 for pass in "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" "SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES"; do
   name=$(echo $pass | cut -d' ' -f1)
-  rocprofv3 --kernel-trace --pmc $pass --output-format csv -d $OUT/_lspmc_$name -- python3 tools/prof_loss_side.py 4 > /dev/null 2> $OUT/_lspmc_$name.err
+  rocprofv3 --kernel-trace --pmc $pass --output-format csv -d $OUT/_lspmc_$name -- python3 tools/prof_loss_side.py 4 > /dev/null 2> $OUT/_lspmc_$name.err || { echo "rocprofv3 --pmc $pass failed: $OUT/_lspmc_$name.err" >&2; FAILED=1; }
 done
 python3 - "$OUT" "$TAG" <<'PY'
 import csv, glob, sys, collections
@@ -20,7 +21,6 @@ for p in glob.glob(out + "/_ls/**/*kernel_trace.csv", recursive=True):
         n = r["Kernel_Name"]
         for w in want:
             if w in n:
-                key = w + ("<bwd>" if (w == "warp_fewc_kernel" and ", true>" in n.replace("(bool)1", "true")) else "")
                 dur[(w, n)].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
 cnt = collections.defaultdict(lambda: collections.defaultdict(list))
 for p in glob.glob(out + "/_lspmc_*/**/*counter_collection.csv", recursive=True):
@@ -49,4 +49,6 @@ for (w, n), d in sorted(dur.items()):
 f.close()
 print(open("%s/%s_loss_side_kernels.csv" % (out, tag)).read())
 PY
-rm -rf $OUT/_ls $OUT/_lspmc_* $OUT/*.err
+# a failed pass keeps its log (and the exit code says so); only this script's own scratch is removed
+if [ $FAILED -ne 0 ]; then exit 1; fi
+rm -rf $OUT/_ls $OUT/_lspmc_* $OUT/_ls.err $OUT/_lspmc_*.err
