@@ -18,7 +18,7 @@ LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(CSRC, "_obj")
 LIB = os.path.join(LIBDIR, "libcerberus_hip.so")
 ARCH = "gfx950"
-SOURCES = ["api.hip", "corr_generic.hip", "corr_d4.hip", "corr_d4_bwd.hip", "corr_strip.hip", "corr_coarse.hip", "corr_fwd_pipe.hip", "corr_mfma.hip", "corr_grad_prep.hip", "warp.hip", "upsample.hip"]
+SOURCES = ["api.hip", "corr_generic.hip", "corr_d4.hip", "corr_d4_bwd.hip", "corr_strip.hip", "corr_coarse.hip", "corr_fwd_pipe.hip", "corr_mfma.hip", "corr_grad_prep.hip", "warp.hip", "warp16.hip", "upsample.hip"]
 CXXFLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-Wall",
             "-Wno-unused-function", "-fno-fast-math",
             "-fhip-fp32-correctly-rounded-divide-sqrt"]
@@ -37,8 +37,8 @@ def _deps():
     return max(os.path.getmtime(h) for h in hdrs)
 
 
-def _compile(src, force, verbose, extra):
-    obj = os.path.join(OBJDIR, os.path.splitext(src)[0] + ".o")
+def _compile(src, force, verbose, extra, objdir=OBJDIR):
+    obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
     path = os.path.join(CSRC, src)
     newest = max(os.path.getmtime(path), _deps())
     if not force and os.path.exists(obj) and os.path.getmtime(obj) >= newest:
@@ -50,19 +50,35 @@ def _compile(src, force, verbose, extra):
     return obj, True
 
 
-def build(force: bool = False, verbose: bool = False, extra_flags=()):
-    """Compile every HIP source for gfx950 and link the shared library."""
-    os.makedirs(OBJDIR, exist_ok=True)
+def _build_lib(lib, objdir, sources, extra, force, verbose):
+    os.makedirs(objdir, exist_ok=True)
     os.makedirs(LIBDIR, exist_ok=True)
-    extra = list(extra_flags) + os.environ.get("CERB_EXTRA_HIPCC_FLAGS", "").split()
     with concurrent.futures.ThreadPoolExecutor(max_workers=4) as pool:
-        results = list(pool.map(lambda s: _compile(s, force, verbose, extra), SOURCES))
+        results = list(pool.map(lambda s: _compile(s, force, verbose, extra, objdir), sources))
     objs = [o for o, _ in results]
-    if force or any(changed for _, changed in results) or not os.path.exists(LIB):
-        cmd = [_hipcc(), "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", LIB] + objs
+    changed = force or any(c for _, c in results) or not os.path.exists(lib)
+    if changed:
+        cmd = [_hipcc(), "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", lib] + objs
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
+    return changed
+
+
+def build_variant(tag: str, flags, force: bool = False, verbose: bool = False, sources=None):
+    """A diagnostic build of the same library beside the product: ``lib/libcerberus_hip_<tag>.so`` from objects of
+    its own (``csrc/_obj_<tag>``), e.g. ``build_variant("stamp", ["-DCERB_STAMP"])``.  Loaded through
+    ``CERBERUS_HIP_LIB``; never the default."""
+    lib = os.path.join(LIBDIR, "libcerberus_hip_%s.so" % tag)
+    _build_lib(lib, os.path.join(CSRC, "_obj_" + tag), sources or SOURCES, list(flags), force, verbose)
+    return lib
+
+
+def build(force: bool = False, verbose: bool = False, extra_flags=()):
+    """Compile every HIP source for gfx950 and link the shared library."""
+    extra = list(extra_flags) + os.environ.get("CERB_EXTRA_HIPCC_FLAGS", "").split()
+    changed = _build_lib(LIB, OBJDIR, SOURCES, extra, force, verbose)
+    results = [(None, changed)]
     try:    # the inference host is an optional extra: its failure must not fail the build of the product library
         build_runtime(force or any(changed for _, changed in results), verbose)
     except (subprocess.CalledProcessError, OSError) as exc:
@@ -91,4 +107,9 @@ def build_runtime(force: bool = False, verbose: bool = False):
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose="--verbose" in sys.argv))
+    if "--variant" in sys.argv:     # python -m cerberusnet_amd.build --variant stamp -DCERB_STAMP
+        i = sys.argv.index("--variant")
+        print(build_variant(sys.argv[i + 1], [a for a in sys.argv[i + 2:] if a.startswith("-D")],
+                            force="--force" in sys.argv, verbose="--verbose" in sys.argv))
+    else:
+        print(build(force="--force" in sys.argv, verbose="--verbose" in sys.argv))

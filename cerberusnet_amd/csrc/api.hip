@@ -22,6 +22,7 @@ const char *const g_option_names[OPT_COUNT] = {
     "warp_staged",          // 0: auto (warp gathers through an LDS window), 2: never, >= 4: that many channels per forward workgroup
     "warp_stagger",         // warp backward phase shift: 0 auto, -1 off, else delays (x 1024 cycles) of the 2nd / 3rd / 4th 256 workgroups, a byte each
     "warp_fewc",            // 0: auto (<= 4 channels without context / grad_image take the lane-per-pixel kernels), -1: off
+    "warp_pair16",          // 0: auto (16-bit images take the two-elements-per-lane kernels of warp16.hip), -1: off
 #ifdef CERB_ABLATE
     "corr_debug_ablate",    // timing ablation mask (WRONG results when != 0); ablation builds only
 #endif

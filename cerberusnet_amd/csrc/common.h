@@ -26,8 +26,11 @@ template <> __device__ __forceinline__ float ld<hip_bfloat16>(const hip_bfloat16
 }
 template <typename T, typename A> __device__ __forceinline__ void st(T *p, A v) { *p = static_cast<T>(v); }
 template <> __device__ __forceinline__ void st<__half, float>(__half *p, float v) { *p = __float2half(v); }
+// gfx950's v_cvt_pk_bf16_f32 (one instruction) instead of the ~8 of hip_bfloat16(float)'s software rounding: identical
+// bits for every non-NaN input, NaN stays NaN with a different payload (tools/ubench/cvt_check.hip: all 2^32 inputs)
 template <> __device__ __forceinline__ void st<hip_bfloat16, float>(hip_bfloat16 *p, float v) {
-    *p = hip_bfloat16(v);
+    const __bf16 b = static_cast<__bf16>(v);
+    __builtin_memcpy(p, &b, 2);
 }
 
 // ---- correlation geometry (correlation_cuda.cpp:6-14) -----------------------
@@ -78,6 +81,7 @@ enum OptId {
     OPT_WARP_STAGED,
     OPT_WARP_STAGGER,
     OPT_WARP_FEWC,
+    OPT_WARP_PAIR16,
 #ifdef CERB_ABLATE
     OPT_DEBUG_ABLATE,   // timing-ablation mask: exists in -DCERB_ABLATE builds only
 #endif
@@ -185,6 +189,10 @@ int warp_backward(const void *image, const void *flow, const void *gout, void *g
                   void *gflow, const void *ctx, int64_t ctx_size, void *workspace,
                   int64_t workspace_bytes, int B, int C, int H, int W, int pad_mode, int interp,
                   int dtype, int flow_dtype, hipStream_t s);
+
+// warp16.hip: 16-bit storage, two pixels per lane and two channels per LDS dword; CERB_EUNSUPPORTED when it does not apply
+int warp16_forward(const void *image, const void *flow, void *out, void *ctx, int B, int C, int H, int W, int pad_mode,
+                   int dtype, int flow_dtype, int crange_opt, hipStream_t s);
 
 // upsample.hip: flow * factor -> bilinear x factor, align_corners = true (forward) / its adjoint
 int flow_upsample(bool forward, const void *src, void *dst, int64_t planes, int H, int W, int factor,

@@ -61,7 +61,7 @@ template <> struct Gmem<hip_bfloat16> {
     static __device__ __forceinline__ void stream2(hip_bfloat16 *p, float a, float b) { store2(p, a, b); }
     static __device__ __forceinline__ float widen(unsigned short b) { return __uint_as_float(static_cast<unsigned int>(b) << 16); }
     static __device__ __forceinline__ unsigned short narrow(float v) {
-        const hip_bfloat16 h(v);  // round to nearest even, NaN stays NaN
+        const __bf16 h = static_cast<__bf16>(v);  // v_cvt_pk_bf16_f32: round to nearest even, NaN stays NaN
         unsigned short b;
         __builtin_memcpy(&b, &h, 2);
         return b;

@@ -13,11 +13,14 @@ from bench import Workload
 ops = torch.ops.cerberus
 lvl = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 kind = sys.argv[2] if len(sys.argv) > 2 else "smooth"
-C, H, W = pyramid_shapes()[lvl]
+dt = {"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16}[sys.argv[4] if len(sys.argv) > 4 else "f32"]
+wh = (2048, 1024) if (len(sys.argv) > 5 and sys.argv[5] == "5") else (1024, 512)      # config 5 / config 3 frames
+C, H, W = pyramid_shapes(wh[0], wh[1], 32)[lvl]
 B = 4
-img = torch.from_numpy(hash_uniform((B, C, H, W), 1)).cuda()
-go = torch.from_numpy(hash_uniform((B, C, H, W), 2)).cuda()
-fl = Workload._flow(B, H, W, 3, kind, "cuda")
+img = torch.from_numpy(hash_uniform((B, C, H, W), 1)).cuda().to(dt)
+go = torch.from_numpy(hash_uniform((B, C, H, W), 2)).cuda().to(dt)
+fl = Workload._flow(B, H, W, 3, kind, "cuda").to(dt)
+print("stamps: level %d (%d, %d, %d) %s %s" % (lvl, C, H, W, kind, dt))
 _, ctx = ops.flow_warp_ctx(img, fl, 1, 0)
 want_flow = (sys.argv[3] if len(sys.argv) > 3 else "flow") == "flow"     # "tiles": grad_image alone
 for _ in range(5):
