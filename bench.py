@@ -15,7 +15,10 @@ Every rank owns `--pairs` image pairs (weak scaling).  Default step by N:
                         `extra.model_step` of the N = 1 line (the same step on one GPU)
 `--step ops` at N > 1 reports the op-only rate of the N ranks (the ops have no parameters: no collective
 belongs to them) with the model-sized exchange timed beside it as `gradient_exchange`; `--step head` is the
-flow head alone under DDP.
+flow head alone under DDP.  Every N > 1 line carries `single_gpu_step` and `scaling_efficiency` = value /
+(N x single_gpu_step) at its top level: the like-for-like ratio of the step `config.step` names.
+`--device cpu` (gloo) is the dry run of the N > 1 route on a box without GPUs: the same launcher, rendezvous, DDP
+wrap, timed region, no_sync pass and rank gather, on a small host model with the stock-PyTorch fallback ops.
 
 One "step" = the hot path of one training iteration over a batch of `--pairs`
 image pairs (default 4 per GPU, BASELINE config 4's per-GPU batch; the tensors
@@ -624,16 +627,36 @@ def cpu_baseline(levels, budget_s=20.0):
             row[what + "_ms_median"] = round(1e3 * float(np.median(ts)), 3)
             row[what + "_iters"] = len(ts)
         table[name] = row
-    # for the record: the config-1 forward with torch's default of one thread per host core
+    # BASELINE.md section 4 as written: torch.set_num_threads(all host cores), forward + backward on the four levels.
+    # On a many-core host this is far slower than the probed thread count above (thread fan-out on small maps), so the
+    # pass is capped: one warm-up and up to `all_iters` timed iterations per level within its own time budget.
     torch.set_num_threads(ncpu)
     fwd(shapes[0][0])
     t0 = time.perf_counter()
     fwd(shapes[0][0])
     all_cores_ms = round(1e3 * (time.perf_counter() - t0), 3)
+    all_budget, all_iters = max(4.0, 0.5 * budget_s), 3
+    t_all = time.perf_counter()
+    all_table = {}
+    for name, _ in shapes[1:]:
+        fwdbwd(name)
+        ts = []
+        while len(ts) < all_iters and (not ts or time.perf_counter() - t_all < all_budget):
+            t0 = time.perf_counter()
+            fwdbwd(name)
+            ts.append(time.perf_counter() - t0)
+        all_table[name] = {"fwd_bwd_ms_median": round(1e3 * float(np.median(ts)), 3), "iters": len(ts)}
+    all_pair_s = 2 * sum(all_table["L%d" % l]["fwd_bwd_ms_median"] for l in range(len(levels))) * 1e-3
     torch.set_num_threads(default_threads)
     pair_s = 2 * sum(table["L%d" % l]["fwd_bwd_ms_median"] for l in range(len(levels))) * 1e-3
     return {"value": round(1.0 / pair_s, 4), "unit": "image-pairs/s", "cores": threads, "kind": "port",
             "host_cores": ncpu, "per_shape_ms": table,
+            "value_all_cores": round(1.0 / all_pair_s, 4), "cores_all": ncpu,
+            "all_cores": {"per_shape_ms": all_table,
+                          "what": "BASELINE.md section 4 as specified: torch.set_num_threads(%d) = every host core, fwd + "
+                                  "autograd bwd on the four level shapes, 1 warm-up + up to %d timed iterations per level "
+                                  "(%.1f s budget, %.1f s used); `value` / `cores` beside it is the best thread count of a probe"
+                                  % (ncpu, all_iters, all_budget, time.perf_counter() - t_all)},
             "config1_fwd_ms_with_all_%d_cores" % ncpu: all_cores_ms,
             "sample": "CorrelationTorch semantics on torch CPU, B=1: config-1 tensor + the 4 level shapes, "
                       "3 warm-ups + up to 10 timed iterations each of fwd and fwd+autograd bwd (min / median "
@@ -651,7 +674,7 @@ def spawn_ranks(n):
     that has a GPU context."""
     import socket
     import subprocess
-    have = torch.cuda.device_count()
+    have = n if "cpu" in [a for i, a in enumerate(sys.argv) if i and sys.argv[i - 1] == "--device"] else torch.cuda.device_count()
     if have < n:
         print(json.dumps({"metric": METRIC, "skipped": "--gpus %d but this box has %d GPU(s)" % (n, have),
                           "n_gpus": n}), flush=True)
@@ -901,11 +924,31 @@ def head_step_mode(args, device, rank, world, dist):
     print(json.dumps(result), flush=True)
 
 
-def short_ops_rate(pairs, width, height, dtype, device, steps=60, warmup=10):
+def hot_kernel_times(wl, labels, reps=20):
+    """Seconds per launch (hot: the same launch replayed on the same tensors, HIP events) of the named launches of
+    direction 0."""
+    ops = torch.ops.cerberus
+    lv = wl.dirs[0]
+    wl._direction(lv, [])
+    torch.cuda.synchronize()
+    out = {}
+    for label in labels:
+        kind, l = label.rsplit("_L", 1)
+        t = lv[int(l)]
+        fn = {"corr_fwd": (lambda t=t: ops.correlation(t["f1"], t["warped"], *CORR_P)),
+              "corr_bwd": (lambda t=t: ops.correlation_backward(t["f1"], t["warped"], t["gout"], *CORR_P)),
+              "warp_fwd": (lambda t=t: ops.flow_warp_ctx(t["f2"], t["flow"], 1, 0)),
+              "warp_bwd": (lambda t=t: ops.flow_warp_backward_ctx(t["f2"], t["flow"], t["ctx"], t["f1"], 1, 0, True, True))}[kind]
+        out[label] = _time_graph([fn], reps)
+    return out
+
+
+def short_ops_rate(pairs, width, height, dtype, device, steps=60, warmup=10, flow_kind="smooth", probe=()):
     """A short timed pass of the op-only step on another configuration (value only: no per-kernel pass):
     same graph + two-stream launch as the headline.  Used for `extra.config5_f16` of the default line so
-    that a driver-timed figure of BASELINE config 5 exists (VERDICT r3 #7)."""
-    wl = Workload(pairs, width, height, device, "smooth", False, 1, dtype)
+    that a driver-timed figure of BASELINE config 5 exists.  `probe`: launches to time on
+    their own as well (hot, HIP events)."""
+    wl = Workload(pairs, width, height, device, flow_kind, False, 1, dtype)
     streams = [torch.cuda.Stream()]
     for _ in range(3):
         wl.step(streams)
@@ -933,8 +976,14 @@ def short_ops_rate(pairs, width, height, dtype, device, steps=60, warmup=10):
            "dtype": {torch.float16: "f16", torch.bfloat16: "bf16", torch.float32: "f32"}[dtype],
            "algorithmic_bytes_per_step": 2 * sum(kern.values()),
            "step_algorithmic_GBps": round(2 * sum(kern.values()) * steps / dt / 1e9, 1),
-           "corr_only_frac_of_hbm_peak_whole_step": round(corr_b * steps / dt / 1e9 / HBM_PEAK_GBPS, 4)}
-    del graph, held, wl
+           "corr_only_frac_of_hbm_peak_whole_step": round(corr_b * steps / dt / 1e9 / HBM_PEAK_GBPS, 4),
+           "flow_field": flow_kind}
+    del graph, held
+    if probe:
+        hot = hot_kernel_times(wl, probe)
+        out["per_kernel_hot"] = {k: {"us": round(v * 1e6, 2), "frac": round(kern[k] / v / 1e9 / HBM_PEAK_GBPS, 4)}
+                                 for k, v in hot.items()}
+    del wl
     torch.cuda.empty_cache()
     return out
 
@@ -953,16 +1002,26 @@ def model_step_mode(args, device, rank, world, dist, quiet=False):
     from cerberusnet_amd.distributed import wrap_ddp
     from cerberusnet_amd.loss_functions import unFlowLoss
     from cerberusnet_amd.nnet_models import CerberusBase, cerberus_flow_config
+    from cerberusnet_amd.nnet_models.hrnetv2 import W18, W32, W48
     from cerberusnet_amd.synth import fill_parameters, hash_uniform
     B, H, W = args.pairs, args.height, args.width
+    on_gpu = device.type == "cuda"
+    sync = torch.cuda.synchronize if on_gpu else (lambda: None)
     backend = getattr(args, "model_backend", "hip")          # "torch": the reference's own fallback ops (CorrelationTorch + grid_sample) on the GPU
+    if not on_gpu:
+        # --device cpu: the dry run of the N > 1 route (launcher, rendezvous, DDP, timed region, no_sync pass, gather) on a box
+        # without GPUs.  The product has no CPU path: the hot-path ops are the reference's own stock-PyTorch fallback here.
+        backend = "torch"
+        args.channels_last = False
+    arch = getattr(args, "arch", "w32")
+    widths = {"w18": W18, "w32": W32, "w48": W48}[arch]
     if getattr(args, "miopen_find", False):
         # MIOpen's find mode (what torch.backends.cudnn.benchmark means on ROCm): every convolution shape is timed
         # once with a workspace it may use; without it PyTorch's immediate mode takes the solver of the find-db whose
         # workspace it then cannot provide and falls back to GEMM (round 4's stderr: "IsEnoughWorkspace ...
         # GemmBwdRest / GemmWrwUniversal" on every step)
         torch.backends.cudnn.benchmark = True
-    model = CerberusBase(**cerberus_flow_config(correlation_backend=backend)).to(device).train()
+    model = CerberusBase(**cerberus_flow_config(widths=widths, correlation_backend=backend)).to(device).train()
     if getattr(args, "channels_last", True):
         model = model.to(memory_format=torch.channels_last)
     fill_parameters(model.backbone, 400)                  # the same weights on every rank
@@ -977,13 +1036,21 @@ def model_step_mode(args, device, rank, world, dist, quiet=False):
         l_img, l_seq = l_img.contiguous(memory_format=torch.channels_last), l_seq.contiguous(memory_format=torch.channels_last)
     params = [p for p in model.parameters() if p.requires_grad]
     opt = torch.optim.Adam(params, lr=1e-4, betas=(0.9, 0.99), weight_decay=1e-6)
-    amp = args.dtype in ("f16", "bf16")
+    amp = args.dtype in ("f16", "bf16") and on_gpu
     adt = {"f16": torch.float16, "bf16": torch.bfloat16}.get(args.dtype)
-    scaler = torch.amp.GradScaler("cuda", enabled=(args.dtype == "f16"))
+    scaler = torch.amp.GradScaler(device.type, enabled=(args.dtype == "f16" and on_gpu))
+    # test hook (tests/test_bench_cpu.py): "rank:step" -- that rank raises inside that timed step.  A failing rank must
+    # take the whole job down with a non-zero exit code, never leave its peers waiting in a collective
+    fail_rank, fail_step = (int(v) for v in os.environ.get("CERB_BENCH_FAIL_AT", "-1:-1").split(":"))
+    nstep = [0]
 
-    def step():
+    def step(timed=False):
+        if timed:
+            if rank == fail_rank and nstep[0] == fail_step:
+                raise RuntimeError("CERB_BENCH_FAIL_AT: injected failure on rank %d in timed step %d" % (rank, fail_step))
+            nstep[0] += 1
         opt.zero_grad(set_to_none=True)
-        with torch.autocast("cuda", dtype=adt, enabled=amp):
+        with torch.autocast(device.type, dtype=adt, enabled=amp):
             out = net(l_img=l_img, l_seq=l_seq, consistency=True)
             loss = loss_fn({k: [f.float() for f in v] for k, v in out.items()}, {"l_img": l_img, "l_seq": l_seq})
         scaler.scale(loss).backward()
@@ -992,18 +1059,18 @@ def model_step_mode(args, device, rank, world, dist, quiet=False):
         return loss
 
     def fence():
-        torch.cuda.synchronize()
+        sync()
         if dist is not None:
             dist.barrier()
-            torch.cuda.synchronize()
+            sync()
 
-    warm = max(3, args.warmup)
+    warm = max(3, args.warmup) if on_gpu else max(1, args.warmup)
     for _ in range(warm):
         loss = step()
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss = step()
+        loss = step(timed=True)
     fence()
     dt = time.perf_counter() - t0
     if dist is not None:
@@ -1019,13 +1086,13 @@ def model_step_mode(args, device, rank, world, dist, quiet=False):
         err, ds = None, 0.0
         try:
             with net.no_sync():
-                for _ in range(2):
+                for _ in range(2 if on_gpu else 1):
                     step()
-                torch.cuda.synchronize()
+                sync()
                 t0 = time.perf_counter()
                 for _ in range(args.steps):
                     step()
-                torch.cuda.synchronize()
+                sync()
                 ds = time.perf_counter() - t0
         except Exception as exc:  # a side report: never fail the line on it
             err = exc
@@ -1056,11 +1123,11 @@ def model_step_mode(args, device, rank, world, dist, quiet=False):
                 scaler = torch.amp.GradScaler("cuda", enabled=False)
                 for _ in range(2):
                     step()
-                torch.cuda.synchronize()
+                sync()
                 t0 = time.perf_counter()
                 for _ in range(5):
                     step()
-                torch.cuda.synchronize()
+                sync()
                 ms = (time.perf_counter() - t0) / 5 * 1e3
                 table[tag] = {"ms_per_step": round(ms, 2), "pairs_per_s": round(B / ms * 1e3, 2)}
             except Exception as exc:
@@ -1076,17 +1143,23 @@ def model_step_mode(args, device, rank, world, dist, quiet=False):
         "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {
             "step": "model",
-            "workload": "one training step of the host model (HRNetV2-W32 backbone + PWCNetHead / FlowEstimatorLite, "
+            "value_times": "`value` = image pairs per second of the whole DDP training step (all ranks); `single_gpu_step` = the "
+                           "same step per GPU without the gradient exchange; `scaling_efficiency` = value / (n_gpus x single_gpu_step)",
+            "workload": "one training step of the host model (HRNetV2-%s backbone + PWCNetHead / FlowEstimatorLite, "
                         "%d parameters, hash-filled; BASELINE configs 3 / 4 without the segmentation and depth heads) on "
-                        "%d synthetic %dx%d frame pairs per GPU: backbone on both frames, flow head in both directions, "
-                        "unFlowLoss, backward, Adam%s" % (nparam, B, W, H, "; autocast " + args.dtype if amp else ""),
+                        "%d synthetic %dx%d frame pairs per %s: backbone on both frames, flow head in both directions, "
+                        "unFlowLoss, backward, Adam%s" % (arch.upper(), nparam, B, W, H, "GPU" if on_gpu else "rank (CPU dry run)",
+                                                          "; autocast " + args.dtype if amp else ""),
             "pairs_per_gpu": B, "frame": [H, W], "parameters": nparam, "gradient_bytes_per_step": 4 * nparam,
             "launch": "eager", "backend": backend, "miopen_find": bool(getattr(args, "miopen_find", False)),
             "channels_last": bool(getattr(args, "channels_last", True)),
-            "sharding": ("image pairs sharded over ranks; DistributedDataParallel over RCCL (64 MB buckets, static graph): "
-                         "%.1f MB of gradients all-reduced inside every step, overlapped with backward" % (4e-6 * nparam)
+            "device": device.type, "collective_backend": (dist.get_backend() if dist is not None else None),
+            "sharding": ("image pairs sharded over ranks; DistributedDataParallel over %s (64 MB buckets, static graph): "
+                         "%.1f MB of gradients all-reduced inside every step, overlapped with backward"
+                         % ("RCCL" if on_gpu else "gloo (CPU dry run of the route)", 4e-6 * nparam)
                          if ddp else "one rank"),
-            "hot_path_ops": "cerberus:: HIP kernels (correlation_leaky_into, flow_warp, flow_upsample, area_resize)",
+            "hot_path_ops": ("cerberus:: HIP kernels (correlation_leaky_into, flow_warp, flow_upsample, area_resize)" if backend == "hip"
+                             else "the reference's stock-PyTorch fallback (CorrelationTorch + grid_sample + F.interpolate)"),
             "loss_last_step": float(loss.item()),
         },
         "roofline": None, "cpu_baseline": None,
@@ -1095,7 +1168,11 @@ def model_step_mode(args, device, rank, world, dist, quiet=False):
                 "the N = 1 line): the N = 1 default line times a different step (the ops alone)",
     }
     if single is not None:
+        # top level: the like-for-like figures of THIS step, so that no reader divides by the
+        # N = 1 default line (which times the ops alone)
         result["single_gpu_step"] = single
+        if "pairs_per_s_per_gpu" in single:
+            result["scaling_efficiency"] = round(result["value"] / (world * single["pairs_per_s_per_gpu"]), 4)
     if table is not None:
         result["backend_table"] = dict(table, what="5 steps each after 2 warm-up steps, same process and model: the hot-path ops as "
                                        "this package's HIP kernels (hip) or as the reference's stock-PyTorch fallback on the same GPU "
@@ -1133,7 +1210,8 @@ def main():
                          "one HIP stream each")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true",
-                    help="skip the short side passes of the default line (extra.config5_f16, extra.bf16_1024x512, extra.model_step)")
+                    help="skip the short side passes of the default line (extra.config5_f16, extra.bf16_1024x512, extra.flow_noise, "
+                         "extra.ragged, extra.loss_side, extra.model_step)")
     ap.add_argument("--probe-steps", type=int, default=20)
     ap.add_argument("--flow", choices=["smooth", "noise"], default="smooth",
                     help="synthetic flow fields fed to the warp (see Workload._flow)")
@@ -1183,6 +1261,10 @@ def main():
     ap.add_argument("--bwd-cslice", type=int, default=0, help="experiments: option corr_bwd_cslice")
     ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
                     help="experiments: set a library tuning option (include/cerberus_hip.h), repeatable")
+    ap.add_argument("--device", choices=["cuda", "cpu"], default="cuda",
+                    help="cpu: dry run of the N > 1 route without GPUs (gloo; --step model only, the host model on the "
+                         "reference's stock-PyTorch fallback ops: the product itself has no CPU path)")
+    ap.add_argument("--arch", choices=["w18", "w32", "w48"], default="w32", help="--step model: HRNetV2 width")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -1192,6 +1274,26 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if args.device == "cpu":
+        # the N > 1 route on a box without GPUs: same launcher / rendezvous / DDP / timed region / gather, gloo instead of RCCL
+        if (args.step or "model") != "model":
+            raise SystemExit("--device cpu runs --step model only (the hot-path ops have no CPU implementation)")
+        args.step = "model"
+        device = torch.device("cpu")
+        dist = None
+        if world > 1 or os.environ.get("CERB_FORCE_DIST") == "1":
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29511")
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        if args.steps == 200 and args.warmup == 20:
+            args.steps, args.warmup = 3, 1
+        torch.set_num_threads(max(1, (os.cpu_count() or 1) // max(1, world)))
+        model_step_mode(args, device, rank, world, dist)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU path exists for the product)")
     torch.cuda.set_device(local_rank)
@@ -1305,6 +1407,11 @@ def main():
                   "what": "HIP events around 60 back-to-back replays of the step graph after 20 untimed ones, on this rank; "
                           "run right before the W warm-up and K timed steps (the chip's post-idle transient, "
                           "profiles/r04_replay_gaps.txt, is over by then)"}
+    steady_slowest = None
+    if steady is not None and dist is not None and world > 1:
+        t = torch.tensor([steady["pairs_per_s_per_gpu"]], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        steady_slowest = float(t.item())
     if graph is not None:
         for _ in range(args.warmup):
             graph.replay()
@@ -1400,9 +1507,15 @@ def main():
                 "step": "ops",
                 "workload": "%s (HRNetV2-W32 pyramid of %dx%d, corr d=4 + flow-warp, %s), %d image "
                             "pairs per GPU per step (config 4's per-GPU batch), both flow "
-                            "directions, fwd+bwd" % (cfg, args.width, args.height, args.dtype, args.pairs),
+                            "directions, fwd+bwd; flow fields fed to the warp: %s" % (cfg, args.width, args.height, args.dtype, args.pairs,
+                            "smooth (an upsampled coarse field, as the flow head produces; the per-pixel uniform field of "
+                            "SURVEY 8(d) is extra.flow_noise)" if args.flow == "smooth" else "per-pixel uniform [-6, 6) px (SURVEY 8(d))"),
+                "value_times": "`value` = image pairs per second of the op-only step (all ranks)",
                 "pairs_per_gpu": args.pairs, "levels_CHW": [list(s) for s in wl.levels],
                 "flow_field": args.flow,
+                "flow_field_note": "`smooth` (the headline) = what PWCNetHead feeds the warp: a coarse random field in [-6, 6) px "
+                                   "upsampled x8 bilinearly (pwcnet_sfd.py:176) + 0.25 px of residual; SURVEY 8(d)'s per-pixel "
+                                   "uniform [-6, 6) field (`noise`, what the parity tests use) is timed as extra.flow_noise",
                 "stack_coarse": args.stack_coarse if hybrid else 0,
                 "launch": ("hipGraph replay" if graph is not None else "eager") +
                           (", directions fused into one batched call" if args.fuse_directions else
@@ -1426,6 +1539,12 @@ def main():
         result.update(extra)
         if steady is not None:
             result["steady_state"] = steady
+        if world > 1 and steady is not None:
+            # the like-for-like ratio at the top level of every N > 1 line: the ops have no collective, so the single-GPU
+            # figure is the slowest rank's own steady-state rate of the same step graph, measured in this run
+            result["single_gpu_step"] = {"pairs_per_s_per_gpu": steady_slowest, "what": "slowest rank's steady-state rate of the "
+                                         "same op-only step graph (HIP events over 60 replays, no other rank's work involved)"}
+            result["scaling_efficiency"] = round(result["value"] / (world * steady_slowest), 4)
         # what preceded the timed region besides the W warm-up steps `warmup` reports
         result["pre_timed"] = {
             "probe_order": "after" if args.probe_after else "before",
@@ -1549,6 +1668,38 @@ def main():
                              "fwd+bwd; same launch as the headline")
             except Exception as exc:
                 extra_lines["bf16_1024x512"] = {"error": repr(exc)[:200]}
+            try:    # the headline's schedule since round 5 stacks level 0 of both directions; the schedule of rounds 1-4 beside it
+                sc = short_ops_rate(4, 1024, 512, torch.float32, device, steps=100, warmup=20)
+                extra_lines["stack_coarse_0"] = dict(
+                    value=sc["value"], unit=sc["unit"], ms_per_step=sc["ms_per_step"], steps=sc["steps"], warmup=sc["warmup"],
+                    what="the headline's tensors with EVERY level on two streams (--stack-coarse 0: the schedule of rounds 1-4; "
+                         "the headline runs level 0 of both directions as one stacked call since round 5)")
+            except Exception as exc:
+                extra_lines["stack_coarse_0"] = {"error": repr(exc)[:200]}
+            try:    # SURVEY 8(d)'s flow field: independent uniform [-6, 6) px per pixel (the headline uses the smooth field)
+                fn = short_ops_rate(4, 1024, 512, torch.float32, device, flow_kind="noise",
+                                    probe=("warp_fwd_L3", "warp_bwd_L3", "warp_bwd_L2", "warp_bwd_L1"))
+                extra_lines["flow_noise"] = dict(
+                    value=fn["value"], unit=fn["unit"], ms_per_step=fn["ms_per_step"], steps=fn["steps"], warmup=fn["warmup"],
+                    warp_bwd_L3_us=fn["per_kernel_hot"]["warp_bwd_L3"]["us"], per_kernel_hot=fn["per_kernel_hot"],
+                    workload="the headline's tensors with the flow fields of SURVEY 8(d): per-pixel uniform in [-6, 6) px "
+                             "(a warp backward tile then gathers from a region 2.2 x its size)")
+            except Exception as exc:
+                extra_lines["flow_noise"] = {"error": repr(exc)[:200]}
+            try:    # frames off the tuned widths (the reference trains on random-scale crops and KITTI: datasets/__init__.py:33-112)
+                rag = {}
+                for (rw, rh) in ((896, 448), (1216, 352)):
+                    r = short_ops_rate(4, rw, rh, torch.float32, device, steps=40, warmup=8,
+                                       probe=[k % l for l in (1, 2, 3) for k in ("corr_fwd_L%d", "corr_bwd_L%d", "warp_fwd_L%d", "warp_bwd_L%d")]
+                                       + ["corr_fwd_L0", "corr_bwd_L0"])
+                    rag["%dx%d" % (rw, rh)] = {k: r[k] for k in ("value", "unit", "ms_per_step", "levels_CHW", "per_kernel_hot",
+                                                                  "step_algorithmic_GBps")}
+                rag["what"] = ("the W32 pyramids of 896x448 and 1216x352 frames (level widths 28..224 / 38..304: none of the widths "
+                               "16 / 32 / 64 / 128 / 256 the tuned kernels were built on), 4 image pairs, same launch as the headline; "
+                               "per_kernel_hot: one launch replayed on the same tensors (HIP events), frac = algorithmic bytes / time / 8 TB/s")
+                extra_lines["ragged"] = rag
+            except Exception as exc:
+                extra_lines["ragged"] = {"error": repr(exc)[:200]}
             try:    # the loss side of the training step: pyramid, RGB warps, gradOutput from the concat buffer's gradient
                 extra_lines["loss_side"] = loss_side_times(args.pairs, args.width, args.height, device)
             except Exception as exc:

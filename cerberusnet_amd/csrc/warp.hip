@@ -23,7 +23,7 @@
 #include <algorithm>
 #include <type_traits>
 
-#include "warp_common.h"
+#include "warp16_common.h"
 
 namespace cerb {
 namespace {
@@ -614,25 +614,13 @@ __device__ __forceinline__ bool flow_role_staged(
 #endif
 }
 
-// The same tile by direct gathers (the window of a diverged flow does not fit LDS): one wave
-// per strip walks all of its channels, eight channels in flight.
+// One pixel's grad_flow by direct gathers (the window of a diverged flow does not fit LDS): the lane walks all
+// channels, eight in flight; channel c adds into partial c & 3, the partials are summed 0..3 (the order of every role).
 template <typename T, typename F>
-__device__ __forceinline__ void flow_role_tile_direct(
+__device__ __forceinline__ void flow_pixel_direct(
     const T *__restrict__ image, const T *__restrict__ gout, const void *__restrict__ ctx,
-    F *__restrict__ gflow, int flow_block, int nflow_blocks, int B, int C, int H, int W, int pad_mode) {
+    F *__restrict__ gflow, int b, int p, int B, int C, int H, int W, int pad_mode) {
     const int plane = H * W;
-    const int lane = threadIdx.x & (kPix - 1), wave = threadIdx.x / kPix;
-    constexpr int SR = kStageRows;
-    const Strips strips(H, W);
-    const int tyn = (strips.ny + SR - 1) / SR;
-    int id = xcd_chunk(flow_block, nflow_blocks);
-    const int tx = id % strips.nx; id /= strips.nx;
-    const int ty = id % tyn;
-    const int b = id / tyn;
-    const int jy = ty * SR + wave;
-    int x = 0, y = 0;
-    if (!(jy < strips.ny && strips.pixel(jy * strips.nx + tx, lane, H, W, x, y))) return;
-    const int p = y * W + x;
     const float *pos = ctx_pos(ctx, B, H, W) + static_cast<int64_t>(b) * 2 * plane;
     const float ixp = pos[p], iyp = pos[plane + p];
     const float x0f = floorf(ixp), y0f = floorf(iyp);
@@ -671,6 +659,42 @@ __device__ __forceinline__ void flow_role_tile_direct(
     F *gf = gflow + static_cast<int64_t>(b) * 2 * plane + p;
     st(gf, mx * sx / static_cast<float>(W - 1) * 2.0f);
     st(gf + plane, my * sy / static_cast<float>(H - 1) * 2.0f);
+}
+
+// The 8 x 32 tile of flow_role_staged by direct gathers: one wave per strip
+template <typename T, typename F>
+__device__ __forceinline__ void flow_role_tile_direct(
+    const T *__restrict__ image, const T *__restrict__ gout, const void *__restrict__ ctx,
+    F *__restrict__ gflow, int flow_block, int nflow_blocks, int B, int C, int H, int W, int pad_mode) {
+    const int lane = threadIdx.x & (kPix - 1), wave = threadIdx.x / kPix;
+    constexpr int SR = kStageRows;
+    const Strips strips(H, W);
+    const int tyn = (strips.ny + SR - 1) / SR;
+    int id = xcd_chunk(flow_block, nflow_blocks);
+    const int tx = id % strips.nx; id /= strips.nx;
+    const int ty = id % tyn;
+    const int b = id / tyn;
+    const int jy = ty * SR + wave;
+    int x = 0, y = 0;
+    if (!(jy < strips.ny && strips.pixel(jy * strips.nx + tx, lane, H, W, x, y))) return;
+    flow_pixel_direct<T, F>(image, gout, ctx, gflow, b, y * W + x, B, C, H, W, pad_mode);
+}
+
+// The 8 x 64 tile of flow_role16 (16-bit storage) by direct gathers: a lane's two pixels one after the other
+template <typename T, typename F>
+__device__ __forceinline__ void flow_role16_direct(
+    const T *__restrict__ image, const T *__restrict__ gout, const void *__restrict__ ctx,
+    F *__restrict__ gflow, int flow_block, int nflow_blocks, int B, int C, int H, int W, int pad_mode) {
+    const int lane = threadIdx.x & (kPix - 1), wave = threadIdx.x / kPix;
+    const int ntx = (W + kTile16W - 1) / kTile16W, nty = (H + kTile16H - 1) / kTile16H;
+    int id = xcd_chunk(flow_block, nflow_blocks);
+    const int tx = id % ntx; id /= ntx;
+    const int ty = id % nty;
+    const int b = id / nty;
+    const int y = ty * kTile16H + wave * 2 + (lane >> 5), xa = tx * kTile16W + 2 * (lane & 31);
+    if (!(y < H && xa < W)) return;
+    flow_pixel_direct<T, F>(image, gout, ctx, gflow, b, y * W + xa, B, C, H, W, pad_mode);
+    if (xa + 1 < W) flow_pixel_direct<T, F>(image, gout, ctx, gflow, b, y * W + xa + 1, B, C, H, W, pad_mode);
 }
 
 #ifdef CERB_STAMP
@@ -716,6 +740,16 @@ __global__ __launch_bounds__(256, TH == 16 ? CERB_TILE16_WPS : 4) void warp_bwd_
     }
     if (static_cast<int>(blockIdx.x) >= ntile_blocks) {
         // ------------------------------ FLOW workgroup ------------------------------
+        if constexpr (sizeof(T) == 2) {
+            if (flow_staged == 2) {
+                // 16-bit storage: an 8 x 64 tile, two pixels per lane, the raw 16-bit window by LDS-DMA (warp16_common.h)
+                const int fb = blockIdx.x - ntile_blocks, nfb = gridDim.x - ntile_blocks;
+                if (!flow_role16<T, F>(reinterpret_cast<char *>(acc), NP * PS * 8, reinterpret_cast<int4 *>(&red[0][0]), image,
+                                       gout, ctx, gflow, fb, nfb, B, C, H, W, pad_mode))
+                    flow_role16_direct<T, F>(image, gout, ctx, gflow, fb, nfb, B, C, H, W, pad_mode);
+                return;
+            }
+        }
         if (flow_staged) {
             // an 8 x 32 tile x all channels through an LDS window (the accumulators' LDS)
             const int fb = blockIdx.x - ntile_blocks, nfb = gridDim.x - ntile_blocks;
@@ -831,21 +865,28 @@ __global__ __launch_bounds__(256, TH == 16 ? CERB_TILE16_WPS : 4) void warp_bwd_
         // strip j = tid + 256 k as (jy, jx), advanced without divisions in the loop
         int jy = tid / strips.nx, jx = tid % strips.nx;
         const int qy = 256 / strips.nx, qx = 256 % strips.nx;
-        for (int j = tid; j < spp; j += 256) {
-            const int slot = b * spp + j;
-            const int4 e = ext[slot];
-            const int sy0 = jy * kStripH, sy1 = min(sy0 + kStripH, H) - 1;
-            const int sx0 = jx * kStripW, sx1 = min(sx0 + kStripW, W) - 1;
-            const bool hit = e.x <= e.y && sx0 + e.x <= tx1 && sx1 + e.y >= tx0 &&
-                             sy0 + e.z <= ty1 && sy1 + e.w >= ty0;
-            if (hit) {
-                rx0 = min(rx0, sx0); rx1 = max(rx1, sx1);
-                ry0 = min(ry0, sy0); ry1 = max(ry1, sy1);
-                dxl = min(dxl, e.x); dxh = max(dxh, e.y);
-                dyl = min(dyl, e.z); dyh = max(dyh, e.w);
+        // four strips per trip, their ranges requested together (round 5: one load per trip -- at 256 x 512 pixels the
+        // eight dependent round trips to L2 were 11 % of a tile workgroup's time, profiles/r06_warp_bwd_tile_stamps_baseline.txt)
+        constexpr int SU = 4;
+        for (int j = tid; j < spp; j += 256 * SU) {
+            int4 e[SU];
+#pragma unroll
+            for (int u = 0; u < SU; ++u) e[u] = ext[b * spp + min(j + 256 * u, spp - 1)];
+#pragma unroll
+            for (int u = 0; u < SU; ++u) {
+                const int sy0 = jy * kStripH, sy1 = min(sy0 + kStripH, H) - 1;
+                const int sx0 = jx * kStripW, sx1 = min(sx0 + kStripW, W) - 1;
+                const bool hit = j + 256 * u < spp && e[u].x <= e[u].y && sx0 + e[u].x <= tx1 && sx1 + e[u].y >= tx0 &&
+                                 sy0 + e[u].z <= ty1 && sy1 + e[u].w >= ty0;
+                if (hit) {
+                    rx0 = min(rx0, sx0); rx1 = max(rx1, sx1);
+                    ry0 = min(ry0, sy0); ry1 = max(ry1, sy1);
+                    dxl = min(dxl, e[u].x); dxh = max(dxh, e[u].y);
+                    dyl = min(dyl, e[u].z); dyh = max(dyh, e[u].w);
+                }
+                jx += qx; jy += qy;
+                if (jx >= strips.nx) { jx -= strips.nx; ++jy; }
             }
-            jx += qx; jy += qy;
-            if (jx >= strips.nx) { jx -= strips.nx; ++jy; }
         }
     }
     // wave-wide folds on the DPP path (6 VALU each, result uniform); round 3 folded these eight values with
@@ -1433,7 +1474,11 @@ static int launch_tiles(const void *image, const void *gout, const void *ctx, vo
                              static_cast<int64_t>(C) * H * W * 4 < 0x7fffffff && staged_opt != 2 && flow_sub == 1 &&
                              (flow_tiles >= 512 || staged_opt >= 4);
     const int64_t nstrips = static_cast<int64_t>(B) * strips.per_image();
-    const int64_t flow_blocks = !gflow ? 0 : flow_staged ? flow_tiles : nstrips * flow_sub;
+    // 16-bit storage: the staged role as 8 x 64 tiles with two pixels per lane and an LDS-DMA window (same bits)
+    const bool flow16 = flow_staged && sizeof(T) == 2 && W % 8 == 0 && option(OPT_WARP_PAIR16) >= 0 &&
+                        (reinterpret_cast<uintptr_t>(gflow) & 7) == 0 && (reinterpret_cast<uintptr_t>(gout) & 3) == 0;
+    const int64_t flow16_tiles = static_cast<int64_t>(B) * ((H + kTile16H - 1) / kTile16H) * ((W + kTile16W - 1) / kTile16W);
+    const int64_t flow_blocks = !gflow ? 0 : flow16 ? flow16_tiles : flow_staged ? flow_tiles : nstrips * flow_sub;
     if (tile_blocks + flow_blocks > 0x7fffffff) return CERB_ETOOLARGE;
     // PHASE SHIFT (round 4).  When the whole launch is resident at once (<= 4 workgroups per CU) every workgroup runs the
     // same phase at the same time and each phase is bound by a throughput the chip shares -- the gradOutput gather by the
@@ -1456,7 +1501,7 @@ static int launch_tiles(const void *image, const void *gout, const void *ctx, vo
                        static_cast<const T *>(image), static_cast<const T *>(gout), ctx,
                        static_cast<T *>(gimage), static_cast<F *>(gflow), B,
                        C, H, W, tiles_x, tiles_y, nrange, crange, static_cast<int>(tile_blocks),
-                       pad_mode, flow_staged ? 1 : 0, flow_sub, stagger);
+                       pad_mode, flow16 ? 2 : flow_staged ? 1 : 0, flow_sub, stagger);
     return launch_status();
 }
 

@@ -15,15 +15,10 @@
 //     uncontracted), the two results leave as one v_cvt_pk_f16_f32 / v_cvt_pk_bf16_f32;
 //   * a workgroup owns an 8 x 64 pixel tile (a wave: 2 rows x 64 columns = the two 2 x 32 strips of the context side
 //     by side) for a range of channels.
-#include "warp_common.h"
+#include "warp16_common.h"
 
 namespace cerb {
 namespace {
-
-typedef unsigned u2v __attribute__((ext_vector_type(2)));
-typedef unsigned u4v __attribute__((ext_vector_type(4)));
-
-constexpr int kTile16W = 64, kTile16H = 8;
 
 #ifdef CERB_STAMP
 // diagnostic build only (-DCERB_STAMP): cycle counter of thread 0 at the phase boundaries of the first 64 workgroups
@@ -36,111 +31,6 @@ __device__ unsigned long long g_stamps16[64][16];
 #else
 #define CERB_STAMP16(k) do {} while (0)
 #endif
-
-// min / max over each 16-lane DPP row; lane 15 of every row holds its row's result
-template <bool MAX> __device__ __forceinline__ int row_minmax(int v) {
-#define CERB_DPP_STEP(ctrl)                                                           \
-    {                                                                                 \
-        const int o = __builtin_amdgcn_update_dpp(v, v, ctrl, 0xf, 0xf, false);       \
-        v = MAX ? max(v, o) : min(v, o);                                              \
-    }
-    CERB_DPP_STEP(0x111)   // row_shr:1
-    CERB_DPP_STEP(0x112)   // row_shr:2
-    CERB_DPP_STEP(0x114)   // row_shr:4
-    CERB_DPP_STEP(0x118)   // row_shr:8
-#undef CERB_DPP_STEP
-    return v;
-}
-
-template <typename T> __device__ __forceinline__ unsigned short bits16(float v) {
-    T t;
-    st(&t, v);
-    unsigned short b;
-    __builtin_memcpy(&b, &t, 2);
-    return b;
-}
-template <typename T> __device__ __forceinline__ float lo16(unsigned q) { return widen16<T>(static_cast<unsigned short>(q & 0xFFFFu)); }
-template <typename T> __device__ __forceinline__ float hi16(unsigned q) { return widen16<T>(static_cast<unsigned short>(q >> 16)); }
-
-// Two fp32 values side by side: products and sums of a channel PAIR are one v_pk_mul_f32 / v_pk_add_f32 each (the same
-// IEEE operations as the scalar forms, uncontracted: identical bits, half the instructions)
-typedef float f2v __attribute__((ext_vector_type(2)));
-template <typename T> __device__ __forceinline__ f2v widen2(unsigned q) { return f2v{lo16<T>(q), hi16<T>(q)}; }
-// two fp32 -> one dword of two 16-bit values: v_cvt_pk_f16_f32 / v_cvt_pk_bf16_f32, round to nearest even -- bit for bit
-// __float2half / st<hip_bfloat16> (tools/ubench/cvt_check.hip, all 2^32 inputs)
-template <typename T> __device__ __forceinline__ unsigned narrow2(float a, float b) {
-    if constexpr (std::is_same<T, __half>::value) {
-        typedef _Float16 h2v __attribute__((ext_vector_type(2)));
-        return __builtin_bit_cast(unsigned, __builtin_convertvector(f2v{a, b}, h2v));
-    } else {
-        typedef __bf16 b2v __attribute__((ext_vector_type(2)));
-        return __builtin_bit_cast(unsigned, __builtin_convertvector(f2v{a, b}, b2v));
-    }
-}
-
-// ---- the LDS window, filled by LDS-DMA -------------------------------------------------------------------------------
-// One channel's window is rows x pitch 16-bit pixels, RAW (a dword = two horizontally adjacent pixels), copied from the
-// image by `buffer_load_dwordx4 ... lds`: no VGPR destination, no ds_write, nothing for the VALU to do, and asynchronous
-// -- the next channel group's copy is in flight while this one's taps are blended.  The hardware writes the 64 lanes of
-// such an instruction to 64 consecutive 16-byte LDS slots, so lane l of DMA instruction q owns CELL 64 q + l of the
-// window (8 pixels, row-major), for every channel: its source offset is computed once, the channel is the scalar offset.
-// A cell outside the image gets an out-of-range offset and arrives as zeros (the apron of the `zeros` padding mode and
-// of border taps).  Columns start at a multiple of 8 pixels (16-byte aligned sources: W % 8 == 0).
-[[maybe_unused]] constexpr int kDmaBuf = 14336;        // bytes per window buffer; two buffers
-[[maybe_unused]] constexpr int kDmaMaxCells = 256;     // cells of ONE channel's window (4 DMA instructions); larger: direct gathers
-[[maybe_unused]] constexpr int kDmaMaxCh = 8;          // channels per pass
-
-// ceil(65536 / d): cell / d == (cell * m) >> 16 exactly for cell < 256, d <= 256
-struct RowMul {
-    unsigned v[257];
-    constexpr RowMul() : v{} {
-        for (int d = 1; d <= 256; ++d) v[d] = (65536u + d - 1) / d;
-    }
-};
-__device__ const RowMul g_rowmul{};
-
-template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-// at most n (wave-uniform, 0 .. 24) vector-memory operations still outstanding
-__device__ __forceinline__ void wait_vmcnt_upto(int n) {
-    switch (n) {
-#define W(k) case k: wait_vmcnt<k>(); break;
-        W(0) W(1) W(2) W(3) W(4) W(5) W(6) W(7) W(8) W(9) W(10) W(11) W(12) W(13) W(14) W(15) W(16)
-        W(17) W(18) W(19) W(20) W(21) W(22) W(23)
-#undef W
-        default: wait_vmcnt<24>(); break;
-    }
-}
-typedef __attribute__((address_space(3))) void *lds_void_ptr;
-
-struct DmaWindow {
-    int wx0, wy0, pitch, rows, cells;   // uniform; pitch in pixels, a multiple of 8
-    bool empty;                         // no tap of the workgroup is inside the image
-    // per-lane bounds of the north-west taps (lo > hi: none) -> the workgroup's window.  One barrier.
-    __device__ __forceinline__ void reduce(int xl, int xh, int yl, int yh, int4 *boxes, int wave, int lane) {
-        xl = wave_minmax<false>(xl); xh = wave_minmax<true>(xh);
-        yl = wave_minmax<false>(yl); yh = wave_minmax<true>(yh);
-        if (lane == 0) boxes[wave] = make_int4(xl, xh, yl, yh);
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int4 e = boxes[k];
-            xl = min(xl, e.x); xh = max(xh, e.y); yl = min(yl, e.z); yh = max(yh, e.w);
-        }
-        xl = __builtin_amdgcn_readfirstlane(xl); xh = __builtin_amdgcn_readfirstlane(xh);
-        yl = __builtin_amdgcn_readfirstlane(yl); yh = __builtin_amdgcn_readfirstlane(yh);
-        empty = xl > xh;
-        wx0 = empty ? 0 : xl & ~7;
-        wy0 = empty ? 0 : yl;
-        const int64_t pw = empty ? 8 : (static_cast<int64_t>(xh) - wx0 + 8) & ~7ll;
-        const int64_t rw = empty ? 1 : static_cast<int64_t>(yh) - yl + 1;
-        const int64_t c = (pw >> 3) * rw;
-        const bool ok = c <= kDmaMaxCells;
-        pitch = ok ? static_cast<int>(pw) : 8;
-        rows = ok ? static_cast<int>(rw) : 1;
-        cells = ok ? static_cast<int>(c) : kDmaMaxCells + 1;   // "does not fit"
-    }
-    __device__ __forceinline__ bool fits() const { return cells <= kDmaMaxCells; }
-};
 
 // One pixel's sampling state (the forward's arithmetic of warp_fwd_kernel, verbatim)
 struct Px {
@@ -310,44 +200,18 @@ __global__ __launch_bounds__(256) void warp_fwd_staged16_kernel(
     }
 
     // ---- the lane's cells: source offsets of DMA instruction q (cell 64 q + lane), once for all channels ----
-    const int p8 = w.pitch >> 3;
-    const int ninst = (w.cells + 63) >> 6;                                // DMA instructions per channel (<= 4)
-    const unsigned rowmul = g_rowmul.v[p8];
-    int voff[4];
-    bool mine[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int cell = 64 * q + lane;
-        const int row = static_cast<int>((static_cast<unsigned>(cell) * rowmul) >> 16), col = cell - row * p8;
-        const int gx = w.wx0 + 8 * col, gy = w.wy0 + row;
-        mine[q] = cell < w.cells;
-        voff[q] = (gx >= 0 && gx < W && gy >= 0 && gy < H) ? (gy * W + gx) * 2 : kDeadOffset;
-    }
-    const int chan_bytes = w.cells * 16;
+    DmaPlan plan;
+    plan.init(w, lane, H, W);
+    const int chan_bytes = plan.chan_bytes;
     const int nch = min(kDmaMaxCh, kDmaBuf / chan_bytes);                 // channels per pass (>= 3)
     const int ntot = c_end - c_begin;
     const int npass = (ntot + nch - 1) / nch;
-    // channel i of a pass is copied by wave i % 4; every copy is `ninst` instructions
     auto issue = [&](int k) {
         if (ablate & 2) return;
-        const int n = min(nch, ntot - k * nch);
-        char *buf = reinterpret_cast<char *>(win) + (k & 1) * kDmaBuf;
-        for (int i = wave; i < n; i += 4) {
-            const int soff = __builtin_amdgcn_readfirstlane((c_begin + k * nch + i) * plane * 2);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                if (q < ninst && mine[q])
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_img, (lds_void_ptr)(buf + i * chan_bytes + q * 1024), 16,
-                                                             voff[q], soff, 0, 0);
-            }
-        }
+        plan.issue(rsrc_img, reinterpret_cast<char *>(win) + (k & 1) * kDmaBuf, c_begin + k * nch, min(nch, ntot - k * nch), wave, plane);
     };
     // this wave's copy instructions of pass k
-    auto dma_count = [&](int k) {
-        if (k >= npass || (ablate & 2)) return 0;
-        const int n = min(nch, ntot - k * nch);
-        return ((n - wave + 3) >> 2) * ninst;
-    };
+    auto dma_count = [&](int k) { return (k >= npass || (ablate & 2)) ? 0 : plan.count(min(nch, ntot - k * nch), wave); };
 
     // taps: dword index of the pixel pair that holds the north-west tap, and its parity
     const int P2 = w.pitch >> 1;
@@ -360,7 +224,7 @@ __global__ __launch_bounds__(256) void warp_fwd_staged16_kernel(
     // blend: rare, so the two selects per channel sit behind a wave-uniform branch
     const bool any_dead = __ballot(live && (dead0 || dead1)) != 0ull;
     CERB_STAMP16(4);
-    if (ablate & 512) { if (j0 + voff[0] + voff[3] + nch == j1) win[1] = 1; return; }
+    if (ablate & 512) { if (j0 + plan.voff[0] + plan.voff[3] + nch == j1) win[1] = 1; return; }
 
     issue(0);
     if (npass > 1) issue(1);

@@ -69,3 +69,59 @@ def test_live_traffic_refuses_to_nest_profilers_too():
         assert res is None and "profiler" in why
     finally:
         del os.environ["ROCP_TOOL_LIBRARIES"]
+
+
+def _run_bench(extra_env, *flags, timeout=420):
+    import subprocess
+    import sys
+    env = dict(os.environ, **extra_env)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    return subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--device", "cpu", "--arch", "w18", "--pairs", "1",
+                           "--width", "128", "--height", "64", "--steps", "2", "--warmup", "1"] + list(flags),
+                          env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def test_the_n_gt_1_route_of_bench_runs_end_to_end_under_gloo_world_2():
+    """`bench.py --gpus N` at N > 1 had never executed anywhere.  On this CPU box the REAL route runs with
+    gloo in place of RCCL: spawn_ranks -> torch.distributed.run (two children) -> rendezvous on 127.0.0.1 -> wrap_ddp
+    around the host model (W18, stock-PyTorch fallback ops: the product has no CPU path) -> warm-up + timed DDP steps
+    (barrier on both sides, max over ranks) -> the no_sync single-GPU pass -> rank 0 prints ONE JSON line whose top
+    level carries single_gpu_step and scaling_efficiency."""
+    import json
+    r = _run_bench({}, "--gpus", "2")
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "single_gpu_step", "scaling_efficiency"):
+        assert key in d, key
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["config"]["step"] == "model" and d["config"]["collective_backend"] == "gloo" and d["config"]["device"] == "cpu"
+    assert "DistributedDataParallel" in d["config"]["sharding"] and "value_times" in d["config"]
+    one = d["single_gpu_step"]["pairs_per_s_per_gpu"]
+    assert one > 0 and np.isclose(d["scaling_efficiency"], d["value"] / (2 * one), rtol=2e-3)
+    assert np.isclose(d["value"], 2 * 1 * 2 / (d["ms_per_step"] * 2e-3), rtol=2e-2)      # pairs x ranks x steps / time
+
+
+def test_a_rank_that_raises_takes_the_job_down_instead_of_hanging_its_peers():
+    """rank 1 raises inside the second timed step while rank 0 is in DDP's gradient all-reduce; the launcher
+    must come back with a non-zero exit code (well inside the timeout), with no JSON line."""
+    r = _run_bench({"CERB_BENCH_FAIL_AT": "1:1"}, "--gpus", "2", timeout=240)
+    assert r.returncode != 0
+    assert "injected failure on rank 1" in r.stderr
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+def test_cpu_dry_run_refuses_the_op_only_step():
+    r = _run_bench({}, "--gpus", "1", "--step", "ops", timeout=120)
+    assert r.returncode != 0 and "no CPU implementation" in (r.stderr + r.stdout)
+
+
+def test_cpu_baseline_also_reports_the_all_cores_figure_as_specified():
+    r = bench.cpu_baseline([(8, 8, 16), (4, 16, 32)], budget_s=5.0)
+    assert r["value_all_cores"] > 0 and r["cores_all"] == os.cpu_count()
+    assert set(r["all_cores"]["per_shape_ms"]) == {"L0", "L1"}
+    pair_s = 2e-3 * sum(r["all_cores"]["per_shape_ms"]["L%d" % l]["fwd_bwd_ms_median"] for l in range(2))
+    assert np.isclose(r["value_all_cores"], 1.0 / pair_s, rtol=1e-3)
