@@ -18,7 +18,14 @@ LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(CSRC, "_obj")
 LIB = os.path.join(LIBDIR, "libcerberus_hip.so")
 ARCH = "gfx950"
-SOURCES = ["api.hip", "corr_generic.hip", "corr_d4.hip", "corr_d4_bwd.hip", "corr_strip.hip", "corr_coarse.hip", "corr_fwd_pipe.hip", "corr_mfma.hip", "corr_grad_prep.hip", "warp.hip", "warp16.hip", "upsample.hip"]
+# the product: dispatched code only
+SOURCES = ["api.hip", "corr_generic.hip", "corr_d4.hip", "corr_d4_bwd.hip", "corr_strip.hip", "corr_coarse.hip", "corr_mfma.hip",
+           "corr_grad_prep.hip", "warp.hip", "warp16.hip", "upsample.hip"]
+# lib/libcerberus_hip_experiments.so (-DCERB_EXPERIMENTS): the product's sources + the measured-and-rejected kernels that no
+# dispatch rule selects (forward variants 1, 2, 8, 17; backward 2, 6, 7, 9, 10; the two-item strip backward) -- kept for the
+# record and tested through CERBERUS_HIP_LIB (tests/test_experiments_gpu.py), never loaded by default
+EXPERIMENT_SOURCES = SOURCES + ["corr_fwd_pipe.hip"]
+EXPERIMENTS_LIB = os.path.join(LIBDIR, "libcerberus_hip_experiments.so")
 CXXFLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-Wall",
             "-Wno-unused-function", "-fno-fast-math",
             "-fhip-fp32-correctly-rounded-divide-sqrt"]
@@ -74,6 +81,10 @@ def build_variant(tag: str, flags, force: bool = False, verbose: bool = False, s
     return lib
 
 
+def build_experiments(force: bool = False, verbose: bool = False):
+    return build_variant("experiments", ["-DCERB_EXPERIMENTS"], force, verbose, sources=EXPERIMENT_SOURCES)
+
+
 def build(force: bool = False, verbose: bool = False, extra_flags=()):
     """Compile every HIP source for gfx950 and link the shared library."""
     extra = list(extra_flags) + os.environ.get("CERB_EXTRA_HIPCC_FLAGS", "").split()
@@ -107,7 +118,9 @@ def build_runtime(force: bool = False, verbose: bool = False):
 
 
 if __name__ == "__main__":
-    if "--variant" in sys.argv:     # python -m cerberusnet_amd.build --variant stamp -DCERB_STAMP
+    if "--experiments" in sys.argv:
+        print(build_experiments(force="--force" in sys.argv, verbose="--verbose" in sys.argv))
+    elif "--variant" in sys.argv:     # python -m cerberusnet_amd.build --variant stamp -DCERB_STAMP
         i = sys.argv.index("--variant")
         print(build_variant(sys.argv[i + 1], [a for a in sys.argv[i + 2:] if a.startswith("-D")],
                             force="--force" in sys.argv, verbose="--verbose" in sys.argv))

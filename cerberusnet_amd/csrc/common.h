@@ -176,7 +176,8 @@ int corr_coarse_backward(const void *in1, const void *in2, const void *gout, voi
 int corr_mfma_forward(const void *in1, const void *in2, void *out, const CorrGeom &g, float slope,
                       int64_t obs, int dtype, hipStream_t s);
 
-// fp32 forward as a persistent, cross-item pipelined grid (corr_fwd_pipe.hip); CERB_EUNSUPPORTED unless C % 8 == 0
+// fp32 forward as a persistent, cross-item pipelined grid (corr_fwd_pipe.hip; -DCERB_EXPERIMENTS builds only: measured
+// slower than the tile kernels); CERB_EUNSUPPORTED unless C % 8 == 0
 int corr_fwd_pipe(const void *in1, const void *in2, void *out, const CorrGeom &g, float slope, int64_t obs,
                   hipStream_t s);
 

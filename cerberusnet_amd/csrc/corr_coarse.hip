@@ -1,4 +1,5 @@
-// corr_coarse.hip -- correlation forward for the COARSE pyramid levels (fp32, d = 4, W = 16 / 32 / 64).
+// corr_coarse.hip -- correlation forward / backward for the COARSE pyramid levels (d = 4, W <= 64; round 6: the forward on
+// any W % 4 == 0 up to 64, the widths between 16 / 32 / 64 on the lanes of the next one).
 //
 //   out[dy*9+dx][y][x] = leaky(1/C sum_c x1[c][y][x] * x2[c][y+dy-4][x+dx-4])
 //   (reference: correlation_cuda_kernel.cu:29-95; same sums, other order)
@@ -108,8 +109,12 @@ __device__ __forceinline__ void static_for(F &&f) {
 // SPR  4-pixel strips per image row (W = 4 * SPR, SPR | 16)
 // NW   waves per workgroup (channel slices)
 // CB   channels per load batch and lane; two batches in flight
-template <int SPR_, int NW_, int CB_>
+// RAG  1: the image row is narrower than the lanes' 4 * SPR columns (any W % 4 == 0 up to that): the true width is a
+//      run-time value, the strips past the row's end load nothing -- their zeros are the zero padding their left
+//      neighbour's shift picks up -- and store nothing (round 6)
+template <int SPR_, int NW_, int CB_, int RAG_ = 0>
 struct CoarseFwdCfg {
+    static constexpr bool RAG = RAG_ != 0;
     static constexpr int SPR = SPR_, W = 4 * SPR_, NW = NW_, CB = CB_;
     static constexpr int KI = 16 / SPR_;          // channel groups interleaved inside a 16-lane DPP row
     static constexpr int G = 64 / SPR_;           // channel groups per wave
@@ -166,11 +171,12 @@ __device__ __forceinline__ float quad_add(float v) {   // v + v of the lane the 
 
 template <typename K, typename T>
 __global__ __launch_bounds__(K::THREADS, K::NW >= 8 ? 5 : 3) void corr_fwd_d4_coarse_kernel(
-    const T *__restrict__ x1, const T *__restrict__ x2, T *__restrict__ out, int C, int H,
+    const T *__restrict__ x1, const T *__restrict__ x2, T *__restrict__ out, int C, int H, int Wimg,
     int cpl, float slope, int64_t out_bstride, unsigned per_xcd, unsigned nitems, FastDiv by_h) {
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) f4 part[];
-    constexpr int SPR = K::SPR, W = K::W, CB = K::CB;
+    constexpr int SPR = K::SPR, CB = K::CB;
+    const int W = K::RAG ? Wimg : K::W;        // the image's width (K::W: the lanes' capacity and the pitch of the LDS rows)
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
@@ -200,8 +206,9 @@ __global__ __launch_bounds__(K::THREADS, K::NW >= 8 ? 5 : 3) void corr_fwd_d4_co
     const __amdgpu_buffer_rsrc_t r1 = uniform_rsrc(x1 + static_cast<int64_t>(b) * C * plane, item_bytes);
     const __amdgpu_buffer_rsrc_t r2 = uniform_rsrc(x2 + static_cast<int64_t>(b) * C * plane, item_bytes);
     const int c0 = (wave * K::G + g) * cpl;
-    const int v1 = ((c0 * H + y) * W + 4 * sx) * E;
-    const int v2 = ((c0 * H + y2) * W + 4 * sx) * E;
+    const bool strip_live = !K::RAG || 4 * sx < W;
+    const int v1 = strip_live ? ((c0 * H + y) * W + 4 * sx) * E : kDead;
+    const int v2 = strip_live ? ((c0 * H + y2) * W + 4 * sx) * E : kDead;
     const int nb = cpl / CB;
 
     float acc[kND][4];
@@ -214,8 +221,8 @@ __global__ __launch_bounds__(K::THREADS, K::NW >= 8 ? 5 : 3) void corr_fwd_d4_co
         const bool live = k < nb;
 #pragma unroll
         for (int i = 0; i < CB; ++i) {
-            xa[set][i] = load_px4<T>(r1, live ? v1 + i * plane * E : kDead, soff);
-            xw[set][i] = load_px4<T>(r2, (live && inside) ? v2 + i * plane * E : kDead, soff);
+            xa[set][i] = load_px4<T>(r1, (live && strip_live) ? v1 + i * plane * E : kDead, soff);
+            xw[set][i] = load_px4<T>(r2, (live && inside && strip_live) ? v2 + i * plane * E : kDead, soff);
         }
     };
     float zacc[4] = {0.f, 0.f, 0.f, 0.f};
@@ -299,11 +306,11 @@ __global__ __launch_bounds__(K::THREADS, K::NW >= 8 ? 5 : 3) void corr_fwd_d4_co
             }
     }
     {
-        float *dst = reinterpret_cast<float *>(part) + wave * (kND * W) + 4 * sx + (lane >> 4);
+        float *dst = reinterpret_cast<float *>(part) + wave * (kND * K::W) + 4 * sx + (lane >> 4);
 #pragma unroll
         for (int d = 0; d < kND; ++d) {
             const float red = halves_sum(rows_pair_sum(acc[d][0], acc[d][1]), rows_pair_sum(acc[d][2], acc[d][3]));
-            if (i16 % K::KI == 0) dst[d * W] = red;
+            if (i16 % K::KI == 0) dst[d * K::W] = red;
         }
     }
     __syncthreads();
@@ -316,7 +323,7 @@ __global__ __launch_bounds__(K::THREADS, K::NW >= 8 ? 5 : 3) void corr_fwd_d4_co
         f4 q = s0 * inv;
 #pragma unroll
         for (int p = 0; p < 4; ++p) q[p] = q[p] > 0.f ? q[p] : q[p] * slope;
-        store_px4<T>(orow + (t / SPR) * plane + (t % SPR) * 4, q);
+        if (!K::RAG || (t % SPR) * 4 < W) store_px4<T>(orow + (t / SPR) * plane + (t % SPR) * 4, q);
     }
     COARSE_STAMP(6);
 #ifdef CERB_STAMP
@@ -335,7 +342,7 @@ int launch_coarse_fwd(const char *name, const void *in1, const void *in2, void *
     note_kernel(0, name);
     hipLaunchKernelGGL((corr_fwd_d4_coarse_kernel<K, T>), dim3(8 * per_xcd), dim3(K::THREADS),
                        K::LDS_BYTES, s, static_cast<const T *>(in1), static_cast<const T *>(in2),
-                       static_cast<T *>(outp), g.C, g.H, g.C / (K::NW * K::G), slope, obs, per_xcd,
+                       static_cast<T *>(outp), g.C, g.H, g.W, g.C / (K::NW * K::G), slope, obs, per_xcd,
                        static_cast<unsigned>(nitems), FastDiv(static_cast<uint32_t>(g.H)));
     return launch_status();
 }
@@ -587,6 +594,15 @@ static int coarse_forward_t(const void *in1, const void *in2, void *out, const C
     if (g.W == 64 && g.C % K64::CMULT == 0) return launch_coarse_fwd<K64, T>("corr_fwd_d4_coarse_64", in1, in2, out, g, slope, obs, s);
     if (g.W == 32 && g.C % K32::CMULT == 0) return launch_coarse_fwd<K32, T>("corr_fwd_d4_coarse_32", in1, in2, out, g, slope, obs, s);
     if (g.W == 16 && g.C % K16::CMULT == 0) return launch_coarse_fwd<K16, T>("corr_fwd_d4_coarse_16", in1, in2, out, g, slope, obs, s);
+    // round 6: widths between those run on the lanes of the next one (RAG)
+    using R16 = CoarseFwdCfg<4, 4, 2, 1>;
+    using R32 = CoarseFwdCfg<8, 4, 4, 1>;
+    using R64 = CoarseFwdCfg<16, 4, 4, 1>;
+    if (g.W % 4 == 0) {
+        if (g.W > 32 && g.W < 64 && g.C % R64::CMULT == 0) return launch_coarse_fwd<R64, T>("corr_fwd_d4_coarse_rag64", in1, in2, out, g, slope, obs, s);
+        if (g.W > 16 && g.W < 32 && g.C % R32::CMULT == 0) return launch_coarse_fwd<R32, T>("corr_fwd_d4_coarse_rag32", in1, in2, out, g, slope, obs, s);
+        if (g.W < 16 && g.C % R16::CMULT == 0) return launch_coarse_fwd<R16, T>("corr_fwd_d4_coarse_rag16", in1, in2, out, g, slope, obs, s);
+    }
     return CERB_EUNSUPPORTED;
 }
 

@@ -632,7 +632,8 @@ int fwd_dispatch(const void *x1, const void *x2, void *o, const CorrGeom &g, flo
                     return launch_fwd_dma<FwdDma4>("corr_fwd_d4_dma_4x64", x1, x2, o, g, slope, obs, s);
             }
             break;
-        case 17:   // the persistent, cross-item pipelined forward (corr_fwd_pipe.hip)
+#ifdef CERB_EXPERIMENTS
+        case 17:   // the persistent, cross-item pipelined forward (corr_fwd_pipe.hip): built, measured slower (profiles/r05_fwd_pipe_experiment.txt), test builds only
             if constexpr (sizeof(T) == 4) {
                 if (vec && dma_ok(g)) {
                     const int rc = corr_fwd_pipe(x1, x2, o, g, slope, obs, s);
@@ -640,6 +641,7 @@ int fwd_dispatch(const void *x1, const void *x2, void *o, const CorrGeom &g, flo
                 }
             }
             break;
+#endif
         case 10: case 11: case 12: case 13:
             if constexpr (sizeof(T) == 4) {
                 if (vec && dma_ok(g)) {
@@ -664,6 +666,38 @@ int fwd_dispatch(const void *x1, const void *x2, void *o, const CorrGeom &g, flo
     // tiles, lane mapping and summation order as the register-staged ones -> identical bits.
     // Level 3: 19-21 vs 22 us; levels 0 / 1 / 2: 11.6 / 11.0 / 12.0 vs 12.7 / 13.2 / 13.3 us.
     const bool dma = sizeof(T) == 4 && vec && dma_ok(g);
+    if constexpr (sizeof(T) == 4) {
+        if (dma) {
+            // Round 6: the LDS-DMA variants by a cost estimate instead of "the largest tile with >= 256 workgroups".  That
+            // rule assumed widths that are multiples of the tile: at 64 x 44 x 152 it picked 2 x 64 tiles (264 workgroups of
+            // which the last eight run alone: 20.2 us) over 4 x 64 (132 workgroups, 15.6 us), at 128 x 28 x 56 the 1 x 16
+            // tiles (17.9 us) over 1 x 32 (10.5).  A workgroup takes ~7 us of latency + 0.52 us per 1024 pixel-channels of
+            // its tile, the workgroups of a CU run one after the other: est = ceil(workgroups / 256) x (7 + 0.52 x tile
+            // pixels x C / 1024) ranks all 45 (shape, variant) timings of profiles/r06_ragged_forward_variants.txt in their
+            // measured order and leaves the benched pyramid's choices as they were.
+            auto est = [&](int64_t wgs, int tile_px) {
+                return static_cast<double>((wgs + 255) / 256) * (7.0 + 0.52 * tile_px * g.C / 1024.0);
+            };
+            int best = 0;
+            double cost = est(fwd_tiles<FwdDma4>(g), 256);
+            auto consider = [&](int id, bool ok, int64_t wgs, int px) {
+                if (!ok) return;
+                const double c = est(wgs, px);
+                if (c < cost) { cost = c; best = id; }
+            };
+            consider(1, g.C % 2 == 0, fwd_tiles<FwdDmaB>(g), 128);
+            consider(2, g.C % 4 == 0, fwd_tiles<FwdDmaC>(g), 64);
+            consider(3, g.C % 8 == 0, fwd_tiles<FwdDmaD>(g), 32);
+            consider(4, g.C % 16 == 0, fwd_tiles<FwdDmaE>(g), 16);
+            switch (best) {
+                case 1: return launch_fwd_dma<FwdDmaB>("corr_fwd_d4_dma_2x64_s2", x1, x2, o, g, slope, obs, s);
+                case 2: return launch_fwd_dma<FwdDmaC>("corr_fwd_d4_dma_1x64_s4", x1, x2, o, g, slope, obs, s);
+                case 3: return launch_fwd_dma<FwdDmaD>("corr_fwd_d4_dma_1x32_s8", x1, x2, o, g, slope, obs, s);
+                case 4: return launch_fwd_dma<FwdDmaE>("corr_fwd_d4_dma_1x16_s16", x1, x2, o, g, slope, obs, s);
+                default: return launch_fwd_dma<FwdDma4>("corr_fwd_d4_dma_4x64", x1, x2, o, g, slope, obs, s);
+            }
+        }
+    }
     if (fwd_tiles<FwdA1b>(g) >= want || g.C % 2 != 0) {
         if constexpr (sizeof(T) == 4) {
             if (dma) return launch_fwd_dma<FwdDma4>("corr_fwd_d4_dma_4x64", x1, x2, o, g, slope, obs, s);

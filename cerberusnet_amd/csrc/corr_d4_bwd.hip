@@ -1188,6 +1188,13 @@ int bwd_dispatch(const void *x1, const void *x2, const void *go, void *g1, void 
             if (rc != CERB_EUNSUPPORTED) return rc;
         }
     }
+    if constexpr (sizeof(T) == 4) {
+        // variant 12 forces the strip kernel on every shape it supports (any W % 4 == 0 up to 256), the narrow maps included
+        if (g.W <= 32 && vec && dma_ok(g) && option(OPT_CORR_BWD_VARIANT) == 12) {
+            const int rc = corr_strip_backward(x1, x2, go, g1, g2, g, s);
+            if (rc != CERB_EUNSUPPORTED) return rc;
+        }
+    }
     if (g.W <= 32) {
         if constexpr (sizeof(T) == 4) {
             if (vec && dma_ok(g) && option(OPT_CORR_BWD_VARIANT) != 1)
@@ -1204,11 +1211,15 @@ int bwd_dispatch(const void *x1, const void *x2, const void *go, void *g1, void 
         // (21.0 vs 21.3, 18.5 vs 16.4 us) but 2.9 % more pairs/s in the whole step (0.3765 vs
         // 0.3875 ms, three alternating runs: it leaves LDS and L2 to the other stream's kernel).
         // Variant 12 forces it on every shape it supports, 13 keeps it off the 64-wide maps.
+        // Round 6: widths between the powers of two run on the lanes of the next one (StripCfg RAG: lanes past the row's
+        // end idle, any H, any C).  4 pairs, us, the tile kernels -> this: 32 x 112 x 224 44.8 -> 32.0, 64 x 44 x 152
+        // 30.7 -> 28.1, 128 x 22 x 76 28.6 -> 20.1, 64 x 56 x 112 20.9 -> 20.7; at 64 lanes and below (128 x 28 x 56:
+        // 17.1 -> 19.4) the displacement-group kernel stays ahead, so only the exact 64-wide maps take it there.
         const int v = option(OPT_CORR_BWD_VARIANT);
-        const int rows_per_wg = g.W == 256 ? 2 : g.W == 128 ? 4 : 8;
-        const int64_t strip_wgs = static_cast<int64_t>(g.B) * (g.H / rows_per_wg) * (g.C / 32) * 2;
-        const bool strip_auto = (g.W == 256 && strip_wgs >= 192) || (g.W == 128 && strip_wgs >= 192) ||
-                                (g.W == 64 && strip_wgs >= 128 && v != 13);
+        const int rows_per_wg = g.W > 128 ? 2 : g.W > 64 ? 4 : 8;
+        const int64_t strip_wgs = static_cast<int64_t>(g.B) * ((g.H + rows_per_wg - 1) / rows_per_wg) * ((g.C + 31) / 32) * 2;
+        const bool strip_auto = (g.W > 64 && g.W <= 256 && strip_wgs >= 192) ||
+                                (g.W == 64 && g.H % 8 == 0 && g.C % 16 == 0 && strip_wgs >= 128 && v != 13);
         if (vec && dma_ok(g) && (v == 12 || ((v == 0 || v == 13) && strip_auto))) {
             const int rc = corr_strip_backward(x1, x2, go, g1, g2, g, s);
             if (rc != CERB_EUNSUPPORTED) return rc;

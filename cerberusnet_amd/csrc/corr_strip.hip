@@ -71,9 +71,13 @@ __device__ __forceinline__ void static_for(F &&f) {
 
 // SPR  4-pixel strips per image row (W = 4 * SPR); a wave holds RW = 64 / SPR lane-rows
 // NWV  waves per workgroup = channel groups of CW = 4 that share the gradOutput stream
-template <int SPR_, int NWV_, int FLAGS_ = 0, int CW_ = 4, int NIT_ = 1>
+// RAG  1: ragged shapes -- the image is narrower than the lanes' 4 * SPR columns (any W % 4 == 0 up to that), H need not
+//      be a multiple of the workgroup's rows, C not of its channels: the true width is a run-time value, lanes past a
+//      row's end load nothing (their zeros ARE the zero padding their left neighbour's DPP shift picks up), stores are masked
+template <int SPR_, int NWV_, int FLAGS_ = 0, int CW_ = 4, int NIT_ = 1, int RAG_ = 0>
 struct StripCfg {
-    static constexpr int NIT = NIT_;   // work items a workgroup walks one after the other (round 5 experiment: 2 -> half the grid)
+    static constexpr int NIT = NIT_;
+    static constexpr bool RAG = RAG_ != 0;   // work items a workgroup walks one after the other (round 5 experiment: 2 -> half the grid)
     // timing-experiment flags (-DCERB_ABLATE builds): 1 gradOutput DMA non-temporal, 2 x loads non-temporal, 4 no FMAs,
     // 8 no loads / DMAs, 16 no LDS reads, 32 natural step order, 64 no step barrier, 256 no stores (all but 1, 2, 32, 512: wrong results),
     // 512 experiment: a step's memory instructions inside its FMA stream instead of behind it (slower: see step())
@@ -139,6 +143,9 @@ struct StripBwd {
     __amdgpu_buffer_rsrc_t rsrc_x, rsrc_g;
     float *smem;
     int H, plane, wave, lane, y0;
+    int Wr;                        // the image's width (RAG: <= K::W, the lanes' capacity; otherwise K::W itself)
+    bool lane_live;                // the lane's strip lies inside the image row
+    __device__ __forceinline__ int width() const { if constexpr (K::RAG) return Wr; else return K::W; }
     unsigned lds_base, lds_lane;   // byte address of the ring / of the lane's cell inside an entry
     int row0, voff0;               // image row of the lane's x row at step 0, its byte offset in a plane
     f4 xs[2][K::CW];
@@ -147,8 +154,8 @@ struct StripBwd {
     // x rows of step S (image row row0 + S), CW channels; `live` false: nothing is fetched (zeros)
     __device__ __forceinline__ void load_x(int S, bool live, f4 (&dst)[K::CW]) {
         const int row = row0 + S;
-        int vo = voff0 + S * (K::W * 4);
-        vo = (live && static_cast<unsigned>(row) < static_cast<unsigned>(H)) ? vo : kDead;
+        int vo = voff0 + S * (width() * 4);
+        vo = (live && (!K::RAG || lane_live) && static_cast<unsigned>(row) < static_cast<unsigned>(H)) ? vo : kDead;
 #pragma unroll
         for (int c = 0; c < K::CW; ++c)
             if constexpr (!(K::FLAGS & 8))
@@ -158,8 +165,8 @@ struct StripBwd {
     // one channel of load_x (the interleaved schedule of step() issues them one at a time)
     __device__ __forceinline__ void load_x1(int S, bool live, f4 (&dst)[K::CW], int c) {
         const int row = row0 + S;
-        int vo = voff0 + S * (K::W * 4);
-        vo = (live && static_cast<unsigned>(row) < static_cast<unsigned>(H)) ? vo : kDead;
+        int vo = voff0 + S * (width() * 4);
+        vo = (live && (!K::RAG || lane_live) && static_cast<unsigned>(row) < static_cast<unsigned>(H)) ? vo : kDead;
         if constexpr (!(K::FLAGS & 8))
             dst[c] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, vo, c * plane * 4, (K::FLAGS & 2) ? 2 : 0));
     }
@@ -184,14 +191,14 @@ struct StripBwd {
             // one instruction = the 64 cells of an entry: lane-row lr reads its image row (side 0:
             // the lane's own output row j; side 1: the x row of the step)
             const int row = SIDE == 0 ? y0 + lr * K::NR + j : y0 + lr * K::NR + S - kD;
-            const bool ok = act && static_cast<unsigned>(row) < static_cast<unsigned>(H);
+            const bool ok = act && (!K::RAG || lane_live) && static_cast<unsigned>(row) < static_cast<unsigned>(H);
             // side 1 reads the row shifted by ex = dx - 4 (a dword-aligned 16-byte read per lane).
             // The request never leaves the batch item's 81 planes (ex < 0 only occurs on planes
             // >= 5, ex > 0 only on planes <= 75), so the cells at a row's ends pick up a few values
             // of the neighbouring row: patch_g() zeroes them once the data has landed.  (The row
             // offset rides in the VGPR offset: the range check looks at that one alone, and the
             // shift by ex < 0 of a row's first lane must not make it negative.)
-            const int vo = (pl * H + row) * (K::W * 4) + sx * 16 + (SIDE ? (dx - kD) * 4 : 0);
+            const int vo = (pl * H + row) * (width() * 4) + sx * 16 + (SIDE ? (dx - kD) * 4 : 0);
             const int doff = act ? slot * K::SLOT + k * K::ENTRY : K::NSLOT * K::SLOT;   // idle: scratch entry behind the ring
             if constexpr (!(K::FLAGS & 8))
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_g, (lds_void_ptr)(smem + doff / 4), 16,
@@ -213,7 +220,7 @@ struct StripBwd {
 #pragma unroll
                 for (int lr = 0; lr < K::RW; ++lr) {
                     const unsigned row = lds_base + slot * K::SLOT + k * K::ENTRY + lr * K::PITCH;
-                    const unsigned a = ex < 0 ? row + lane * 4 : row + K::PITCH - 4 - lane * 4;
+                    const unsigned a = ex < 0 ? row + lane * 4 : row + width() * 4 - 4 - lane * 4;   // the image row's true end
                     if (lane < n) asm volatile("ds_write_b32 %0, %1" ::"v"(a), "v"(0.f) : "memory");
                 }
             }
@@ -332,7 +339,7 @@ template <typename K>
 __global__ __launch_bounds__(K::THREADS, K::WPS)
 void corr_bwd_d4_strip_kernel(const float *__restrict__ x1, const float *__restrict__ x2,
                               const float *__restrict__ gout, float *__restrict__ gin1,
-                              float *__restrict__ gin2, int C, int H, int nyb, int ncb) {
+                              float *__restrict__ gin2, int C, int H, int Wimg, int nyb, int ncb) {
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x;
@@ -348,7 +355,8 @@ void corr_bwd_d4_strip_kernel(const float *__restrict__ x1, const float *__restr
     const int cb = __builtin_amdgcn_readfirstlane(bid % ncb); bid /= ncb;
     const int yb = __builtin_amdgcn_readfirstlane(bid % nyb);
     const int b = __builtin_amdgcn_readfirstlane(bid / nyb);
-    const int plane = H * K::W;
+    const int Wr = K::RAG ? Wimg : K::W;
+    const int plane = H * Wr;
     const int c0 = cb * K::CWG + wave * K::CW;
     const int y0 = yb * K::ROWS;
 
@@ -362,14 +370,17 @@ void corr_bwd_d4_strip_kernel(const float *__restrict__ x1, const float *__restr
         constexpr int SIDE = decltype(sidec)::value;
         constexpr int LATE = decltype(latec)::value;
         StripBwd<K, SIDE> st;
-        st.rsrc_x = uniform_rsrc(src, K::CW * plane * 4);
+        // (RAG: a wave whose channels lie past C gets an empty range -- every load returns zeros -- and stores nothing)
+        st.rsrc_x = uniform_rsrc(src, (K::RAG ? max(0, min(K::CW, C - c0)) : K::CW) * plane * 4);
+        st.Wr = Wr;
+        st.lane_live = sx * 4 < Wr;
         st.rsrc_g = uniform_rsrc(gob, kND * kND * plane * 4);
         st.smem = smem;
         st.H = H; st.plane = plane; st.wave = wave; st.lane = lane; st.y0 = y0;
         st.lds_base = static_cast<unsigned>(reinterpret_cast<size_t>((__attribute__((address_space(3))) float *)smem));
         st.lds_lane = st.lds_base + lr * K::PITCH + sx * 16;
         st.row0 = y0 + lr * K::NR - kD;
-        st.voff0 = (st.row0 * K::W + sx * 4) * 4;
+        st.voff0 = (st.row0 * Wr + sx * 4) * 4;
 #pragma unroll
         for (int j = 0; j < K::NR; ++j)
 #pragma unroll
@@ -423,10 +434,12 @@ void corr_bwd_d4_strip_kernel(const float *__restrict__ x1, const float *__restr
         for (int j = 0; j < K::NR; ++j)
 #pragma unroll
             for (int c = 0; c < K::CW; ++c) {
-                float *p = dst + static_cast<int64_t>(c) * plane + (y0 + lr * K::NR + j) * K::W + sx * 4;
+                float *p = dst + static_cast<int64_t>(c) * plane + (y0 + lr * K::NR + j) * Wr + sx * 4;
                 const f4 r = f4{st.acc[j][c][0] * inv, st.acc[j][c][1] * inv, st.acc[j][c][2] * inv, st.acc[j][c][3] * inv};
                 if constexpr (K::FLAGS & 256) { if (r[0] == 1.2345e-30f) *reinterpret_cast<f4 *>(p) = r; }   // experiment: no stores
-                else __builtin_nontemporal_store(r, reinterpret_cast<f4 *>(p));
+                else if constexpr (K::RAG) {
+                    if (st.lane_live && y0 + lr * K::NR + j < H && c0 + c < C) __builtin_nontemporal_store(r, reinterpret_cast<f4 *>(p));
+                } else __builtin_nontemporal_store(r, reinterpret_cast<f4 *>(p));
             }
 #ifdef CERB_STAMP
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -450,7 +463,7 @@ void corr_bwd_d4_strip_kernel(const float *__restrict__ x1, const float *__restr
 template <typename K>
 int launch_strip(const char *name, const void *in1, const void *in2, const void *goutp, void *g1p,
                  void *g2p, const CorrGeom &g, hipStream_t s) {
-    const int nyb = g.H / K::ROWS, ncb = g.C / K::CWG;
+    const int nyb = (g.H + K::ROWS - 1) / K::ROWS, ncb = (g.C + K::CWG - 1) / K::CWG;
     int64_t blocks = static_cast<int64_t>(g.B) * nyb * ncb * 2;
     if (blocks > 0x7fffffff) return CERB_ETOOLARGE;
     if (blocks % K::NIT) return CERB_EUNSUPPORTED;
@@ -462,7 +475,7 @@ int launch_strip(const char *name, const void *in1, const void *in2, const void 
     hipLaunchKernelGGL((corr_bwd_d4_strip_kernel<K>), dim3(static_cast<unsigned>(blocks)),
                        dim3(K::THREADS), K::LDS_BYTES, s, static_cast<const float *>(in1),
                        static_cast<const float *>(in2), static_cast<const float *>(goutp),
-                       static_cast<float *>(g1p), static_cast<float *>(g2p), g.C, g.H, nyb, ncb);
+                       static_cast<float *>(g1p), static_cast<float *>(g2p), g.C, g.H, g.W, nyb, ncb);
     return launch_status();
 }
 
@@ -484,9 +497,9 @@ extern "C" int cerberus_debug_strip_stamps(void *dst, int bytes) {
 }
 #endif
 
-// fp32, pad = d = 4 (checked by the caller); returns CERB_EUNSUPPORTED for shapes it does not cover:
-// W in {256, 128, 64} (whole rows per wavefront), H a multiple of the rows a workgroup owns, C a
-// multiple of the workgroup's channels.  `experiment` = StripCfg::FLAGS of a timing experiment.
+// fp32, pad = d = 4 (checked by the caller); returns CERB_EUNSUPPORTED for shapes it does not cover (W > 256 or
+// W % 4 != 0).  W in {256, 128, 64} with H a multiple of the rows a workgroup owns and C a multiple of its channels
+// take the exact configurations; every other W % 4 == 0 up to 256 the ragged ones (StripCfg RAG).
 int corr_strip_backward(const void *in1, const void *in2, const void *gout, void *gin1, void *gin2,
                         const CorrGeom &g, hipStream_t s) {
     if (static_cast<int64_t>(kND * kND) * g.H * g.W >= (1ll << 29) ||
@@ -536,6 +549,15 @@ int corr_strip_backward(const void *in1, const void *in2, const void *gout, void
         CERB_STRIP(16, 4, 0, "corr_bwd_d4_strip_w64_c16");
     }
 #undef CERB_STRIP
+    // ragged shapes (round 6): any W % 4 == 0 up to 256 on the lanes of the next power-of-two width, any H, any C
+    // (whole groups of 4 channels per wave; a workgroup's unused channel groups idle)
+    if (g.W % 4 == 0 && g.W <= 256) {
+        if (g.W > 128) return launch_strip<StripCfg<64, 8, 0, 4, 1, 1>>("corr_bwd_d4_strip_rag256", in1, in2, gout, gin1, gin2, g, s);
+        if (g.W > 64) return launch_strip<StripCfg<32, 8, 0, 4, 1, 1>>("corr_bwd_d4_strip_rag128", in1, in2, gout, gin1, gin2, g, s);
+        if (g.C % 32 != 0 && g.C % 32 <= 16)
+            return launch_strip<StripCfg<16, 4, 0, 4, 1, 1>>("corr_bwd_d4_strip_rag64_c16", in1, in2, gout, gin1, gin2, g, s);
+        return launch_strip<StripCfg<16, 8, 0, 4, 1, 1>>("corr_bwd_d4_strip_rag64", in1, in2, gout, gin1, gin2, g, s);
+    }
     return CERB_EUNSUPPORTED;
 }
 

@@ -710,8 +710,11 @@ __device__ unsigned long long g_stamps[64][16];
 #endif
 
 constexpr int kTileW = 64;
+#ifndef CERB_TILE_PAD
+#define CERB_TILE_PAD 2     // >= 2 (the one-pixel ring); more = row padding against LDS bank conflicts (tools/lds_conflicts_warp.py)
+#endif
 template <int TH> struct TileGeom {
-    static constexpr int PW = kTileW + 2;          // padded row, in accumulators
+    static constexpr int PW = kTileW + CERB_TILE_PAD;          // padded row, in accumulators
     static constexpr int PS = (TH + 2) * PW;       // accumulators per channel plane
 };
 

@@ -28,6 +28,17 @@ def experiments_build():
 
 
 FWD_EXPERIMENTS, BWD_EXPERIMENTS = {1, 2, 8}, {2, 6, 7, 9, 10}
+try:        # decided at collection time (no GPU needed: the library is only loaded, nothing is launched)
+    EXPERIMENTS = experiments_build()
+except Exception:   # library not built: the GPU tests fail loudly on their own
+    EXPERIMENTS = False
+
+
+def variants(all_of_them, experimental):
+    """The kernel variants this build holds: the measured-and-rejected ones exist in the -DCERB_EXPERIMENTS library only
+    (lib/libcerberus_hip_experiments.so); tests/test_experiments_gpu.py runs this file against it in a child process, so
+    the product run collects no test it would have to skip."""
+    return [v for v in all_of_them if EXPERIMENTS or v not in experimental]
 
 
 def dev(a, dtype=None):
@@ -321,14 +332,12 @@ def test_native_library_is_loaded():
     assert "libcerberus_hip.so" in maps
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13])
+@pytest.mark.parametrize("variant", variants([1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13], FWD_EXPERIMENTS))
 @pytest.mark.parametrize("shape", [(2, 32, 13, 72), (1, 16, 9, 64), (1, 48, 20, 33),
                                    (2, 64, 5, 16), (1, 16, 3, 130), (2, 7, 11, 132)])
 def test_every_tuned_forward_variant(variant, shape):
     """Force each tile / channel-split variant of the tuned forward (vector and
     scalar staging paths, ragged tiles) against the C oracle."""
-    if variant in FWD_EXPERIMENTS and not experiments_build():
-        pytest.skip("variant exists in -DCERB_EXPERIMENTS builds only")
     B, C, H, W = shape
     x1, x2 = hash_uniform(shape, 41), hash_uniform(shape, 42)
     ref = oracle.corr_forward_ref(x1, x2, 4, 1, 4, 1, 1)
@@ -343,7 +352,7 @@ def test_every_tuned_forward_variant(variant, shape):
 
 
 @pytest.mark.parametrize("shape", [(2, 32, 13, 72), (1, 16, 9, 64), (3, 64, 21, 132), (2, 8, 4, 32), (1, 40, 37, 256),
-                                   (4, 32, 128, 256)])
+                                   (4, 32, 128, 256)] if EXPERIMENTS else [])
 def test_pipelined_persistent_forward_against_the_oracle(shape):
     """Round 5: the persistent, cross-item pipelined forward (corr_fwd_pipe.hip, variant 17: 4 x 32 tiles, two channel
     halves per wavefront met by v_permlane32_swap, every workgroup walking several tiles behind one run-ahead loader):
@@ -368,13 +377,11 @@ def test_pipelined_persistent_forward_against_the_oracle(shape):
         assert rel_err(out, ref) < TOL, grid
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("variant", variants([0, 1, 2, 3, 4], BWD_EXPERIMENTS))
 @pytest.mark.parametrize("cslice", [0, 2, 4, 8, 1000])
 @pytest.mark.parametrize("shape", [(2, 12, 13, 72), (1, 10, 20, 32), (1, 7, 18, 33),
                                    (1, 16, 40, 28), (2, 5, 9, 130), (2, 9, 21, 136)])
 def test_tuned_backward_tiles_and_channel_slices(variant, cslice, shape):
-    if variant in BWD_EXPERIMENTS and not experiments_build():
-        pytest.skip("variant exists in -DCERB_EXPERIMENTS builds only")
     B, C, H, W = shape
     x1, x2 = hash_uniform(shape, 43), hash_uniform(shape, 44)
     go = hash_uniform((B, 81, H, W), 45)
@@ -573,7 +580,7 @@ def test_seeded_random_shape_sweep_tuned_vs_generic():
     assert any("dma" in k for k in kernels) and any("generic" not in k for k in kernels), kernels
 
 
-@pytest.mark.parametrize("variant", [6, 7, 8, 9, 10])
+@pytest.mark.parametrize("variant", variants([6, 7, 8, 9, 10], BWD_EXPERIMENTS))
 @pytest.mark.parametrize("shape", [(2, 32, 13, 72), (1, 10, 20, 64), (1, 7, 18, 36), (2, 40, 9, 132),
                                    (1, 64, 4, 64), (3, 33, 37, 196), (1, 1, 1, 68), (2, 12, 8, 256)])
 def test_row_streaming_backward_against_the_oracle(shape, variant):
@@ -581,8 +588,6 @@ def test_row_streaming_backward_against_the_oracle(shape, variant):
     an LDS ring by LDS-DMA, all channels of a workgroup at once): ragged tiles in both
     directions, channel ranges that do not fill a workgroup (C not a multiple of 32) and more
     than one range, the shifted gradOutput slots of the second gradient at every border."""
-    if variant in BWD_EXPERIMENTS and not experiments_build():
-        pytest.skip("variant exists in -DCERB_EXPERIMENTS builds only")
     B, C, H, W = shape
     x1, x2 = hash_uniform(shape, 143), hash_uniform(shape, 144)
     go = hash_uniform((B, 81, H, W), 145)
@@ -874,6 +879,41 @@ def test_strip_backward_against_the_oracle(shape):
     assert np.array_equal(g1, g1b) and np.array_equal(g2, g2b)
 
 
+RAGGED_STRIP_SHAPES = [(2, 32, 14, 224), (1, 64, 7, 152), (2, 32, 11, 112), (1, 40, 9, 76), (2, 24, 13, 56), (1, 16, 5, 28),
+                       (1, 33, 6, 252), (3, 7, 3, 4), (1, 36, 17, 132), (2, 48, 10, 68), (1, 20, 8, 64), (1, 30, 6, 256),
+                       (1, 32, 7, 128)]
+
+
+@pytest.mark.parametrize("shape", RAGGED_STRIP_SHAPES)
+def test_strip_backward_on_ragged_shapes_against_the_oracle(shape):
+    """Round 6: the strip backward on any width that is a multiple of 4 up to 256 (the lanes past a row's
+    end load nothing: their zeros are the zero padding the last strip's DPP neighbour shift picks up; the second
+    gradient's shifted gradOutput rows are zeroed at the TRUE row end), heights that are not a multiple of the
+    workgroup's rows and channel counts that are not a multiple of its channels (waves without channels idle, stores
+    masked) -- the level shapes of 896 x 448 and 1216 x 352 frames among them -- against the C oracle, incl. a NaN at a
+    row's last pixel that the next row must not see."""
+    B, C, H, W = shape
+    x1, x2 = hash_uniform(shape, 421), hash_uniform(shape, 422)
+    go = hash_uniform((B, 81, H, W), 423)
+    x1[0, 0, H // 2, W - 1] = np.inf
+    go[0, 44, H - 1, W - 1] = np.nan
+    r1, r2 = oracle.corr_backward_ref(x1, x2, go, 4, 1, 4, 1, 1)
+    _lib.set_option("corr_bwd_variant", 12)
+    try:
+        g1, g2 = run_bwd(x1, x2, go, (4, 1, 4, 1, 1))
+        name = _lib.last_kernel(1)
+        g1b, g2b = run_bwd(x1, x2, go, (4, 1, 4, 1, 1))
+    finally:
+        _lib.set_option("corr_bwd_variant", 0)
+    assert name.startswith("corr_bwd_d4_strip_rag"), name
+    assert np.array_equal(np.isnan(g1), np.isnan(r1)) and np.array_equal(np.isinf(g1), np.isinf(r1))
+    assert np.array_equal(np.isnan(g2), np.isnan(r2)) and np.array_equal(np.isinf(g2), np.isinf(r2))
+    ok1, ok2 = np.isfinite(r1), np.isfinite(r2)
+    assert rel_err(np.where(ok1, g1, 0), np.where(ok1, r1, 0)) < TOL
+    assert rel_err(np.where(ok2, g2, 0), np.where(ok2, r2, 0)) < TOL
+    assert np.array_equal(g1, g1b, equal_nan=True) and np.array_equal(g2, g2b, equal_nan=True)
+
+
 def test_strip_backward_is_the_default_where_the_wide_level_fills_the_chip():
     shape = (4, 32, 128, 256)
     x1, x2 = dev(hash_uniform(shape, 1)), dev(hash_uniform(shape, 2))
@@ -1000,6 +1040,35 @@ def test_coarse_level_forward_with_16bit_storage_against_the_oracle(dtype, tol, 
     finally:
         _lib.set_option("corr_fwd_variant", 0)
     assert rel_err(out.double().cpu().numpy(), old.double().cpu().numpy()) < tol
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, TOL), (torch.float16, 2e-3), (torch.bfloat16, 1.6e-2)])
+@pytest.mark.parametrize("shape", [(2, 128, 7, 28), (1, 256, 5, 12), (1, 128, 9, 56), (2, 64, 6, 44), (1, 128, 3, 20),
+                                   (1, 256, 4, 60), (4, 256, 14, 28), (1, 128, 2, 4), (2, 128, 5, 36)])
+def test_coarse_forward_on_ragged_widths_against_the_oracle(shape, dtype, tol):
+    """Round 6: the coarse-level forward on any width that is a multiple of 4 up to 64 -- the strips past
+    the row's end load nothing (their zeros are the padding the last strip's neighbour shift reads) and store nothing --,
+    fp32 and 16-bit storage, incl. an Inf at a row's last pixel and the LeakyReLU epilogue."""
+    B, C, H, W = shape
+    x1, x2 = hash_uniform(shape, 431), hash_uniform(shape, 432)
+    if dtype == torch.float32:
+        x2[0, 0, H // 2, W - 1] = np.inf
+    a, b = dev(x1).to(dtype), dev(x2).to(dtype)
+    ref = oracle.corr_forward_ref(a.float().cpu().numpy(), b.float().cpu().numpy(), 4, 1, 4, 1, 1)
+    _lib.set_option("corr_fwd_variant", 15)
+    try:
+        out = torch.ops.cerberus.correlation(a, b, 4, 1, 4, 1, 1, 1)
+        name = _lib.last_kernel(0)
+        lk = torch.ops.cerberus.correlation_leaky(a, b, 4, 1, 4, 1, 1, 1, 0.1)
+    finally:
+        _lib.set_option("corr_fwd_variant", 0)
+    assert name.startswith("corr_fwd_d4_coarse_rag"), name
+    o = out.float().cpu().numpy()
+    assert np.array_equal(np.isfinite(o), np.isfinite(ref))
+    ok = np.isfinite(ref)
+    assert rel_err(np.where(ok, o, 0), np.where(ok, ref, 0)) < tol
+    lref = np.where(ref > 0, ref, ref * np.float32(0.1))
+    assert rel_err(np.where(ok, lk.float().cpu().numpy(), 0), np.where(ok, lref, 0)) < tol
 
 
 def test_coarse_level_kernels_are_the_default_on_the_coarse_levels_of_the_benched_pyramid():
