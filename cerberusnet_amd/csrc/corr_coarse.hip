@@ -368,8 +368,9 @@ int launch_coarse_fwd(const char *name, const void *in1, const void *in2, void *
 //   * nine ds_read_b128 bring the rows' values for the lane's strip, then 36 FMAs + 8 DPP moves
 //     per channel.
 // No barrier before the final one, no division by a run-time value.
-template <int SPR_, int CPL_>
+template <int SPR_, int CPL_, int RAG_ = 0>
 struct CoarseBwdCfg {
+    static constexpr bool RAG = RAG_ != 0;     // as in CoarseFwdCfg: the image row is narrower than the lanes' 4 * SPR columns
     static constexpr int SPR = SPR_, W = 4 * SPR_, CPL = CPL_;
     static constexpr int KI = 16 / SPR_, G = 64 / SPR_, CSET = G * CPL_;
     static constexpr int NWV = 3, NDYW = 3, THREADS = 64 * NWV;
@@ -393,11 +394,12 @@ __device__ __forceinline__ void lds_read16(f4 &dst, unsigned addr) {
 template <typename K>
 __global__ __launch_bounds__(K::THREADS, 4) void corr_bwd_d4_coarse_kernel(
     const float *__restrict__ x1, const float *__restrict__ x2, const float *__restrict__ gout,
-    float *__restrict__ g1, float *__restrict__ g2, int C, int H, unsigned per_xcd, unsigned nitems, FastDiv by_ncs,
+    float *__restrict__ g1, float *__restrict__ g2, int C, int H, int Wimg, unsigned per_xcd, unsigned nitems, FastDiv by_ncs,
     FastDiv by_h) {
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int SPR = K::SPR, W = K::W, CPL = K::CPL;
+    constexpr int SPR = K::SPR, CPL = K::CPL;
+    const int W = K::RAG ? Wimg : K::W;        // the image's width (K::W: the lanes' capacity and the pitch of the staged rows)
     const int tid = threadIdx.x;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
@@ -434,7 +436,7 @@ __global__ __launch_bounds__(K::THREADS, 4) void corr_bwd_d4_coarse_kernel(
             int dx, p, right;
             if (q < 10) { right = 0; dx = q < 4 ? 0 : q < 7 ? 1 : q < 9 ? 2 : 3; p = q - (q < 4 ? 0 : q < 7 ? 4 : q < 9 ? 7 : 9); }
             else { const int r = q - 10; right = 1; dx = r < 1 ? 5 : r < 3 ? 6 : r < 6 ? 7 : 8; p = r < 1 ? 3 : r < 3 ? r + 1 : r < 6 ? r - 2 : r - 6; }
-            patch_off = dx * (SPR * 16) + (right ? (SPR - 1) * 16 : 0) + p * 4;
+            patch_off = dx * (SPR * 16) + (right ? (W / 4 - 1) * 16 : 0) + p * 4;      // the image row's true end
         }
 
         float acc[CPL][4];
@@ -459,12 +461,12 @@ __global__ __launch_bounds__(K::THREADS, 4) void corr_bwd_d4_coarse_kernel(
                 const int vo = (pl * H + row) * (W * 4) + st * 16 + (SIDE ? (dx - kD) * 4 : 0);
                 // (side 0 reads gradOutput of its own row even when the x row lies outside the image: see compute)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rg, (lds_void_ptr)(smem + (wv * K::WAVE_LDS + set * K::SET + q * 1024) / 4), 16,
-                                                         ((SIDE == 0 || ok[k]) && dx < kND) ? vo : kDead, 0, 0, 0);
+                                                         ((SIDE == 0 || ok[k]) && dx < kND && (!K::RAG || st * 4 < W)) ? vo : kDead, 0, 0, 0);
             }
             const int vx = ((c0 * H + xr) * W + 4 * sx) * 4;
 #pragma unroll
             for (int i = 0; i < CPL; ++i)
-                xs[set][i] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rx, ok[k] ? vx + i * plane * 4 : kDead, 0, 0));
+                xs[set][i] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rx, (ok[k] && (!K::RAG || sx * 4 < W)) ? vx + i * plane * 4 : kDead, 0, 0));
         };
         auto compute = [&](int k, int set, auto pending_c) {
             constexpr int PENDING = decltype(pending_c)::value;
@@ -547,7 +549,7 @@ __global__ __launch_bounds__(K::THREADS, 4) void corr_bwd_d4_coarse_kernel(
             const int lsx = (l & 15) / K::KI, lg = (l >> 4) * K::KI + (l & 15) % K::KI;
             const int c = cs * K::CSET + lg * CPL + i;
             float *o = gdst + ((static_cast<int64_t>(b) * C + c) * H + y) * W + 4 * lsx;
-            __builtin_nontemporal_store(sum * inv, reinterpret_cast<f4 *>(o));
+            if (!K::RAG || 4 * lsx < W) __builtin_nontemporal_store(sum * inv, reinterpret_cast<f4 *>(o));
         }
     };
     if (side == 0) run(std::integral_constant<int, 0>{});
@@ -565,7 +567,7 @@ int launch_coarse_bwd(const char *name, const void *in1, const void *in2, const 
     note_kernel(1, name);
     hipLaunchKernelGGL((corr_bwd_d4_coarse_kernel<K>), dim3(8 * per_xcd), dim3(K::THREADS), K::LDS_BYTES, s,
                        static_cast<const float *>(in1), static_cast<const float *>(in2), static_cast<const float *>(goutp),
-                       static_cast<float *>(g1p), static_cast<float *>(g2p), g.C, g.H, per_xcd, static_cast<unsigned>(nitems),
+                       static_cast<float *>(g1p), static_cast<float *>(g2p), g.C, g.H, g.W, per_xcd, static_cast<unsigned>(nitems),
                        FastDiv(static_cast<uint32_t>(ncs)), FastDiv(static_cast<uint32_t>(g.H)));
     return launch_status();
 }
@@ -627,6 +629,15 @@ int corr_coarse_backward(const void *in1, const void *in2, const void *gout, voi
     if (g.W == 64 && g.C % K64::CSET == 0) return launch_coarse_bwd<K64>("corr_bwd_d4_coarse_64", in1, in2, gout, gin1, gin2, g, s);
     if (g.W == 32 && g.C % K32::CSET == 0) return launch_coarse_bwd<K32>("corr_bwd_d4_coarse_32", in1, in2, gout, gin1, gin2, g, s);
     if (g.W == 16 && g.C % K16::CSET == 0) return launch_coarse_bwd<K16>("corr_bwd_d4_coarse_16", in1, in2, gout, gin1, gin2, g, s);
+    // round 6: widths between those run on the lanes of the next one (RAG)
+    using R16 = CoarseBwdCfg<4, 2, 1>;
+    using R32 = CoarseBwdCfg<8, 4, 1>;
+    using R64 = CoarseBwdCfg<16, 4, 1>;
+    if (g.W % 4 == 0) {
+        if (g.W > 32 && g.W < 64 && g.C % R64::CSET == 0) return launch_coarse_bwd<R64>("corr_bwd_d4_coarse_rag64", in1, in2, gout, gin1, gin2, g, s);
+        if (g.W > 16 && g.W < 32 && g.C % R32::CSET == 0) return launch_coarse_bwd<R32>("corr_bwd_d4_coarse_rag32", in1, in2, gout, gin1, gin2, g, s);
+        if (g.W < 16 && g.C % R16::CSET == 0) return launch_coarse_bwd<R16>("corr_bwd_d4_coarse_rag16", in1, in2, gout, gin1, gin2, g, s);
+    }
     return CERB_EUNSUPPORTED;
 }
 

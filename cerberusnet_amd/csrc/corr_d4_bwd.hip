@@ -1182,7 +1182,7 @@ int bwd_dispatch(const void *x1, const void *x2, const void *go, void *g1, void 
         // the latter (4096 workgroups, since the items are chunked over the XCDs by image): 18.9 vs 20.0 us.  14 forces it, 15 is the
         // dispatch without it.
         const int v = option(OPT_CORR_BWD_VARIANT);
-        const int64_t coarse_wgs = static_cast<int64_t>(g.B) * 2 * g.H * (g.C / (g.W == 64 ? 16 : 32));
+        const int64_t coarse_wgs = static_cast<int64_t>(g.B) * 2 * g.H * (g.C / (g.W > 32 ? 16 : 32));
         if (vec && dma_ok(g) && (v == 14 || ((v == 0 || v == 13) && g.W <= 64 && coarse_wgs <= 4096))) {   // 13 = auto, minus the strip kernel on 64-wide maps
             const int rc = corr_coarse_backward(x1, x2, go, g1, g2, g, s);
             if (rc != CERB_EUNSUPPORTED) return rc;

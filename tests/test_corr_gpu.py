@@ -1071,6 +1071,32 @@ def test_coarse_forward_on_ragged_widths_against_the_oracle(shape, dtype, tol):
     assert rel_err(np.where(ok, lk.float().cpu().numpy(), 0), np.where(ok, lref, 0)) < tol
 
 
+@pytest.mark.parametrize("shape", [(2, 128, 7, 28), (1, 256, 5, 12), (1, 128, 9, 56), (2, 64, 6, 44), (1, 128, 3, 20),
+                                   (1, 256, 4, 60), (4, 256, 14, 28), (1, 128, 2, 4), (2, 128, 5, 36), (4, 128, 28, 56)])
+def test_coarse_backward_on_ragged_widths_against_the_oracle(shape):
+    """The coarse-level backward on the same widths: dead strips neither load nor store, the second gradient's shifted
+    gradOutput rows are zeroed at the TRUE row end; NaN / Inf stay where the reference's sums put them."""
+    B, C, H, W = shape
+    x1, x2 = hash_uniform(shape, 441), hash_uniform(shape, 442)
+    go = hash_uniform((B, 81, H, W), 443)
+    x1[0, 1, H // 2, W - 1] = np.inf
+    go[0, 44, H - 1, W - 1] = np.nan
+    go[0, 8, 0, 0] = -np.inf
+    r1, r2 = oracle.corr_backward_ref(x1, x2, go, 4, 1, 4, 1, 1)
+    _lib.set_option("corr_bwd_variant", 14)
+    try:
+        g1, g2 = run_bwd(x1, x2, go, (4, 1, 4, 1, 1))
+        name = _lib.last_kernel(1)
+    finally:
+        _lib.set_option("corr_bwd_variant", 0)
+    assert name.startswith("corr_bwd_d4_coarse_rag"), name
+    assert np.array_equal(np.isnan(g1), np.isnan(r1)) and np.array_equal(np.isinf(g1), np.isinf(r1))
+    assert np.array_equal(np.isnan(g2), np.isnan(r2)) and np.array_equal(np.isinf(g2), np.isinf(r2))
+    ok1, ok2 = np.isfinite(r1), np.isfinite(r2)
+    assert rel_err(np.where(ok1, g1, 0), np.where(ok1, r1, 0)) < TOL
+    assert rel_err(np.where(ok2, g2, 0), np.where(ok2, r2, 0)) < TOL
+
+
 def test_coarse_level_kernels_are_the_default_on_the_coarse_levels_of_the_benched_pyramid():
     for (B, C, H, W), fw, bw in (((4, 256, 16, 32), "corr_fwd_d4_coarse_32", "corr_bwd_d4_coarse_32"),
                                  ((4, 128, 32, 64), "corr_fwd_d4_coarse_64", "corr_bwd_d4_coarse_64"),
