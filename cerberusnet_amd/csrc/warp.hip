@@ -1410,7 +1410,8 @@ int warp_forward(const void *image, const void *flow, void *out, void *ctx, int6
     const bool staged = interp == CERB_INTERP_BILINEAR && dtype != CERB_F64 && W % 4 == 0 &&
                         (reinterpret_cast<uintptr_t>(image) & 15) == 0 && staged_opt != 2 &&
                         static_cast<int64_t>(C) * H * W * 4 < 0x7fffffff;
-    if (staged && (dtype == CERB_F16 || dtype == CERB_BF16) && option(OPT_WARP_PAIR16) >= 0) {
+    if (staged && (((dtype == CERB_F16 || dtype == CERB_BF16) && option(OPT_WARP_PAIR16) >= 0) ||
+                   (dtype == CERB_F32 && option(OPT_WARP_PAIR16) == 1))) {      // fp32: opt-in (A/B: profiles/r06_warp_fp32_dma_ab.txt)
         // 16-bit storage: two pixels per lane, two channels per LDS dword (warp16.hip); same bits
         const int rc = warp16_forward(image, flow, out, ctx, B, C, H, W, pad_mode, dtype, flow_dtype, staged_opt, s);
         if (rc != CERB_EUNSUPPORTED) return rc;

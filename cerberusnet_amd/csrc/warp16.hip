@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void warp_fwd_staged16_kernel(
     const T *__restrict__ image, const F *__restrict__ flow, T *__restrict__ out,
     void *__restrict__ ctx, int B, int C, int H, int W, int pad_mode, int crange, int nrange, int ablate) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    static_assert(sizeof(T) == 2, "16-bit storage only");
+    constexpr int esz = sizeof(T), cpx = 16 / esz;   // 16-bit storage, or fp32 (round 6: the same kernel, 4-pixel cells, no widening)
 #ifndef CERB_ABLATE
     ablate = 0;     // timing ablations (WRONG results) exist in -DCERB_ABLATE builds only: 1 no stores, 2 no staging loads, 4 no taps
 #endif
@@ -153,19 +153,24 @@ __global__ __launch_bounds__(256) void warp_fwd_staged16_kernel(
         int xl = kExtEmptyLo, xh = kExtEmptyHi, yl = kExtEmptyLo, yh = kExtEmptyHi;
         if (!dead0) { xl = px[0].x0; xh = px[0].x0 + 1; yl = px[0].y0; yh = px[0].y0 + 1; }
         if (!dead1) { xl = min(xl, px[1].x0); xh = max(xh, px[1].x0 + 1); yl = min(yl, px[1].y0); yh = max(yh, px[1].y0 + 1); }
-        w.reduce(xl, xh, yl, yh, boxes, wave, lane);
+        w.reduce(xl, xh, yl, yh, boxes, wave, lane, cpx);
     }
     CERB_STAMP16(3);
     if (ablate & 256) { if (w.cells == 12345) win[0] = 1; return; }
 
     const int c_begin = r * crange, c_end = min(C, c_begin + crange);
     const T *img = image + static_cast<int64_t>(b) * C * plane;
-    const __amdgpu_buffer_rsrc_t rsrc_img = uniform_rsrc(img, C * plane * 2);
-    const __amdgpu_buffer_rsrc_t rsrc_out = uniform_rsrc(out + static_cast<int64_t>(b) * C * plane, C * plane * 2);
-    const int out_voff = live ? p * 2 : kDeadOffset;
+    const __amdgpu_buffer_rsrc_t rsrc_img = uniform_rsrc(img, C * plane * esz);
+    const __amdgpu_buffer_rsrc_t rsrc_out = uniform_rsrc(out + static_cast<int64_t>(b) * C * plane, C * plane * esz);
+    const int out_voff = live ? p * esz : kDeadOffset;
     auto store2 = [&](int c, float a, float bv) {
         if (ablate & 1) { if (a == 1.2345f) win[0] = 1; return; }
-        __builtin_amdgcn_raw_buffer_store_b32(narrow2<T>(a, bv), rsrc_out, out_voff, c * plane * 2, 0);
+        if constexpr (esz == 2) {
+            __builtin_amdgcn_raw_buffer_store_b32(narrow2<T>(a, bv), rsrc_out, out_voff, c * plane * 2, 0);
+        } else {
+            typedef unsigned u2s __attribute__((ext_vector_type(2)));
+            __builtin_amdgcn_raw_buffer_store_b64(u2s{__float_as_uint(a), __float_as_uint(bv)}, rsrc_out, out_voff, c * plane * 4, 0);
+        }
     };
     if (w.empty) {   // no tap of the tile is inside the image
         for (int c = c_begin; c < c_end; ++c) store2(c, zs0, zs1);
@@ -201,7 +206,7 @@ __global__ __launch_bounds__(256) void warp_fwd_staged16_kernel(
 
     // ---- the lane's cells: source offsets of DMA instruction q (cell 64 q + lane), once for all channels ----
     DmaPlan plan;
-    plan.init(w, lane, H, W);
+    plan.init(w, lane, H, W, esz);
     const int chan_bytes = plan.chan_bytes;
     const int nch = min(kDmaMaxCh, kDmaBuf / chan_bytes);                 // channels per pass (>= 3)
     const int ntot = c_end - c_begin;
@@ -214,10 +219,12 @@ __global__ __launch_bounds__(256) void warp_fwd_staged16_kernel(
     auto dma_count = [&](int k) { return (k >= npass || (ablate & 2)) ? 0 : plan.count(min(nch, ntot - k * nch), wave); };
 
     // taps: dword index of the pixel pair that holds the north-west tap, and its parity
-    const int P2 = w.pitch >> 1;
+    // (fp32: a dword IS a pixel -- P2 is the row pitch in dwords either way)
+    const int P2 = esz == 2 ? w.pitch >> 1 : w.pitch;
     const int xr0 = dead0 ? 0 : px[0].x0 - w.wx0, xr1 = dead1 ? 0 : px[1].x0 - w.wx0;
-    const int j0 = (dead0 ? 0 : (px[0].y0 - w.wy0) * P2) + (xr0 >> 1), j1 = (dead1 ? 0 : (px[1].y0 - w.wy0) * P2) + (xr1 >> 1);
-    const unsigned sh0 = (xr0 & 1) * 16u, sh1 = (xr1 & 1) * 16u;
+    const int j0 = (dead0 ? 0 : (px[0].y0 - w.wy0) * P2) + (esz == 2 ? xr0 >> 1 : xr0);
+    const int j1 = (dead1 ? 0 : (px[1].y0 - w.wy0) * P2) + (esz == 2 ? xr1 >> 1 : xr1);
+    [[maybe_unused]] const unsigned sh0 = (xr0 & 1) * 16u, sh1 = (xr1 & 1) * 16u;
     const f2v wnw = {px[0].wnw, px[1].wnw}, wne = {px[0].wne, px[1].wne};
     const f2v wsw = {px[0].wsw, px[1].wsw}, wse = {px[0].wse, px[1].wse};
     // a lane without any in-image tap (zeros padding far outside, a non-finite flow) stores its zsum instead of the
@@ -244,13 +251,21 @@ __global__ __launch_bounds__(256) void warp_fwd_staged16_kernel(
             for (int i = 0; i < n; ++i, q0 += cdw, q0s += cdw, q1 += cdw, q1s += cdw) {
                 const int c = c_begin + k * nch + i;
                 if (ablate & 4) { store2(c, zs0, zs1); continue; }
-                // (north-west, north-east) and (south-west, south-east) of both pixels as packed 16-bit pairs
-                const unsigned an = __builtin_amdgcn_alignbit(q0[1], q0[0], sh0), as = __builtin_amdgcn_alignbit(q0s[1], q0s[0], sh0);
-                const unsigned bn = __builtin_amdgcn_alignbit(q1[1], q1[0], sh1), bs = __builtin_amdgcn_alignbit(q1s[1], q1s[0], sh1);
-                f2v acc = f2v{lo16<T>(an), lo16<T>(bn)} * wnw;   // pixel 0 | pixel 1; absent taps contribute exact zeros
-                acc += f2v{hi16<T>(an), hi16<T>(bn)} * wne;
-                acc += f2v{lo16<T>(as), lo16<T>(bs)} * wsw;
-                acc += f2v{hi16<T>(as), hi16<T>(bs)} * wse;
+                f2v acc;
+                if constexpr (esz == 2) {
+                    // (north-west, north-east) and (south-west, south-east) of both pixels as packed 16-bit pairs
+                    const unsigned an = __builtin_amdgcn_alignbit(q0[1], q0[0], sh0), as = __builtin_amdgcn_alignbit(q0s[1], q0s[0], sh0);
+                    const unsigned bn = __builtin_amdgcn_alignbit(q1[1], q1[0], sh1), bs = __builtin_amdgcn_alignbit(q1s[1], q1s[0], sh1);
+                    acc = f2v{lo16<T>(an), lo16<T>(bn)} * wnw;   // pixel 0 | pixel 1; absent taps contribute exact zeros
+                    acc += f2v{hi16<T>(an), hi16<T>(bn)} * wne;
+                    acc += f2v{lo16<T>(as), lo16<T>(bs)} * wsw;
+                    acc += f2v{hi16<T>(as), hi16<T>(bs)} * wse;
+                } else {
+                    acc = f2v{__uint_as_float(q0[0]), __uint_as_float(q1[0])} * wnw;
+                    acc += f2v{__uint_as_float(q0[1]), __uint_as_float(q1[1])} * wne;
+                    acc += f2v{__uint_as_float(q0s[0]), __uint_as_float(q1s[0])} * wsw;
+                    acc += f2v{__uint_as_float(q0s[1]), __uint_as_float(q1s[1])} * wse;
+                }
                 if constexpr (decltype(with_dead)::value) {
                     if (dead0) acc.x = zs0;
                     if (dead1) acc.y = zs1;
@@ -283,9 +298,9 @@ extern "C" int cerberus_debug_stamps16(void *dst, int bytes) {
 // general kernels).  Preconditions checked by the caller: bilinear, image 16-byte aligned, C * H * W * 4 < 2^31.
 int warp16_forward(const void *image, const void *flow, void *out, void *ctx, int B, int C, int H, int W, int pad_mode,
                    int dtype, int flow_dtype, int crange_opt, hipStream_t s) {
-    if (dtype != CERB_F16 && dtype != CERB_BF16) return CERB_EUNSUPPORTED;
-    if (W % 8) return CERB_EUNSUPPORTED;     // 16-byte cells of 16-bit pixels
-    if ((reinterpret_cast<uintptr_t>(out) & 3) || (reinterpret_cast<uintptr_t>(flow) & 7)) return CERB_EUNSUPPORTED;
+    if (dtype != CERB_F16 && dtype != CERB_BF16 && dtype != CERB_F32) return CERB_EUNSUPPORTED;
+    if (W % (dtype == CERB_F32 ? 4 : 8)) return CERB_EUNSUPPORTED;     // 16-byte cells
+    if ((reinterpret_cast<uintptr_t>(out) & 7) || (reinterpret_cast<uintptr_t>(flow) & 7)) return CERB_EUNSUPPORTED;
     const int ntx = (W + kTile16W - 1) / kTile16W, nty = (H + kTile16H - 1) / kTile16H;
     const int64_t tiles = static_cast<int64_t>(B) * ntx * nty;
     // channels per workgroup: as few as keep the launch at <= 1024 workgroups, between 8 and 32 (the rule of the general
@@ -301,7 +316,9 @@ int warp16_forward(const void *image, const void *flow, void *out, void *ctx, in
     hipLaunchKernelGGL((warp_fwd_staged16_kernel<T, F>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s,     \
                        static_cast<const T *>(image), static_cast<const F *>(flow), static_cast<T *>(out), ctx, B, \
                        C, H, W, pad_mode, crange, nrange, debug_mask())
-    if (dtype == CERB_F16) {
+    if (dtype == CERB_F32) {
+        CERB_LAUNCH16(float, float);
+    } else if (dtype == CERB_F16) {
         if (flow_dtype == CERB_F32) CERB_LAUNCH16(__half, float); else CERB_LAUNCH16(__half, __half);
     } else {
         if (flow_dtype == CERB_F32) CERB_LAUNCH16(hip_bfloat16, float); else CERB_LAUNCH16(hip_bfloat16, hip_bfloat16);

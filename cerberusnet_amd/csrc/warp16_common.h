@@ -89,10 +89,11 @@ __device__ __forceinline__ void wait_vmcnt_upto(int n) {
 typedef __attribute__((address_space(3))) void *lds_void_ptr;
 
 struct DmaWindow {
-    int wx0, wy0, pitch, rows, cells;   // uniform; pitch in pixels, a multiple of 8
+    int wx0, wy0, pitch, rows, cells;   // uniform; pitch in pixels, a multiple of the cell's pixels
     bool empty;                         // no tap of the workgroup is inside the image
     // per-lane bounds of the north-west taps (lo > hi: none) -> the workgroup's window.  One barrier.
-    __device__ __forceinline__ void reduce(int xl, int xh, int yl, int yh, int4 *boxes, int wave, int lane) {
+    // cpx: pixels per 16-byte cell (8 of 16-bit storage, 4 of fp32)
+    __device__ __forceinline__ void reduce(int xl, int xh, int yl, int yh, int4 *boxes, int wave, int lane, int cpx = 8) {
         xl = wave_minmax<false>(xl); xh = wave_minmax<true>(xh);
         yl = wave_minmax<false>(yl); yh = wave_minmax<true>(yh);
         if (lane == 0) boxes[wave] = make_int4(xl, xh, yl, yh);
@@ -105,13 +106,13 @@ struct DmaWindow {
         xl = __builtin_amdgcn_readfirstlane(xl); xh = __builtin_amdgcn_readfirstlane(xh);
         yl = __builtin_amdgcn_readfirstlane(yl); yh = __builtin_amdgcn_readfirstlane(yh);
         empty = xl > xh;
-        wx0 = empty ? 0 : xl & ~7;
+        wx0 = empty ? 0 : xl & ~(cpx - 1);
         wy0 = empty ? 0 : yl;
-        const int64_t pw = empty ? 8 : (static_cast<int64_t>(xh) - wx0 + 8) & ~7ll;
+        const int64_t pw = empty ? cpx : (static_cast<int64_t>(xh) - wx0 + cpx) & ~static_cast<int64_t>(cpx - 1);
         const int64_t rw = empty ? 1 : static_cast<int64_t>(yh) - yl + 1;
-        const int64_t c = (pw >> 3) * rw;
+        const int64_t c = (pw / cpx) * rw;
         const bool ok = c <= kDmaMaxCells;
-        pitch = ok ? static_cast<int>(pw) : 8;
+        pitch = ok ? static_cast<int>(pw) : cpx;
         rows = ok ? static_cast<int>(rw) : 1;
         cells = ok ? static_cast<int>(c) : kDmaMaxCells + 1;   // "does not fit"
     }
@@ -126,8 +127,11 @@ struct DmaPlan {
     bool mine[4];       // the cell exists
     int ninst;          // copy instructions per channel (<= 4)
     int chan_bytes;     // LDS bytes of one channel's window
-    __device__ __forceinline__ void init(const DmaWindow &w, int lane, int H, int W) {
-        const int p8 = w.pitch >> 3;
+    int esz;            // bytes per pixel (2 / 4): a cell holds 16 / esz pixels
+    __device__ __forceinline__ void init(const DmaWindow &w, int lane, int H, int W, int esz_ = 2) {
+        esz = esz_;
+        const int cpx = 16 / esz;
+        const int p8 = w.pitch / cpx;
         ninst = (w.cells + 63) >> 6;
         chan_bytes = w.cells * 16;
         const unsigned rowmul = g_rowmul.v[p8];
@@ -135,16 +139,16 @@ struct DmaPlan {
         for (int q = 0; q < 4; ++q) {
             const int cell = 64 * q + lane;
             const int row = static_cast<int>((static_cast<unsigned>(cell) * rowmul) >> 16), col = cell - row * p8;
-            const int gx = w.wx0 + 8 * col, gy = w.wy0 + row;
+            const int gx = w.wx0 + cpx * col, gy = w.wy0 + row;
             mine[q] = cell < w.cells;
-            voff[q] = (gx >= 0 && gx < W && gy >= 0 && gy < H) ? (gy * W + gx) * 2 : kDeadOffset;
+            voff[q] = (gx >= 0 && gx < W && gy >= 0 && gy < H) ? (gy * W + gx) * esz : kDeadOffset;
         }
     }
     // channels c0 .. c0 + n - 1 of the image behind `rsrc` -> buf[n][cells][16 bytes]; channel i by wave i % 4
     __device__ __forceinline__ void issue(__amdgpu_buffer_rsrc_t rsrc, char *buf, int c0, int n, int wave, int plane) const {
 #if defined(__HIP_DEVICE_COMPILE__)
         for (int i = wave; i < n; i += 4) {
-            const int soff = __builtin_amdgcn_readfirstlane((c0 + i) * plane * 2);
+            const int soff = __builtin_amdgcn_readfirstlane((c0 + i) * plane * esz);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 if (q < ninst && mine[q])

@@ -599,3 +599,24 @@ def test_phase_shift_of_coresident_workgroups_changes_nothing_but_time(lvl):
             _lib.set_option("warp_stagger", 0)
     for tag in ("auto", "explicit"):
         assert torch.equal(res[tag][0], res["off"][0]) and torch.equal(res[tag][1], res["off"][1]), tag
+
+
+def test_fp32_forward_through_the_dma_window_kernel_is_bit_identical_too():
+    """warp16.hip's kernel instantiated for fp32 (4-pixel cells, no widening; option warp_pair16 = 1): measured SLOWER
+    than the staged kernel (profiles/r06_warp_fp32_dma_ab.txt: twice the LDS per channel, four channels per pass), so it
+    is opt-in only -- but it must stay correct: same bits as the default, outputs and context."""
+    from cerberusnet_amd import _lib
+    for k, (shape, amp) in enumerate([((2, 19, 37, 132), 0.7), ((1, 8, 64, 128), 6.0), ((2, 5, 24, 64), 30.0), ((1, 32, 40, 256), 3.0)]):
+        B, C, H, W = shape
+        img = dev(hash_uniform(shape, 900 + k))
+        flo = hash_uniform((B, 2, H, W), 910 + k, -amp, amp)
+        flo[0, 0, H // 2, W // 2] = np.nan
+        flo = dev(flo)
+        for pad in (0, 1):
+            out0, ctx0 = torch.ops.cerberus.flow_warp_ctx(img, flo, pad, 0)
+            _lib.set_option("warp_pair16", 1)
+            try:
+                out1, ctx1 = torch.ops.cerberus.flow_warp_ctx(img, flo, pad, 0)
+            finally:
+                _lib.set_option("warp_pair16", 0)
+            assert torch.equal(out0.view(torch.int32), out1.view(torch.int32)) and torch.equal(ctx0, ctx1), (shape, pad)
