@@ -721,7 +721,7 @@ template <int TH> struct TileGeom {
 #ifndef CERB_TILE16_WPS
 #define CERB_TILE16_WPS 4
 #endif
-template <typename T, typename F, int TH, int CW, int NS>
+template <typename T, typename F, int TH, int CW, int NS, int PR = 0>
 __global__ __launch_bounds__(256, TH == 16 ? CERB_TILE16_WPS : 4) void warp_bwd_tile_kernel(
     const T *__restrict__ image, const T *__restrict__ gout, const void *__restrict__ ctx,
     T *__restrict__ gimage, F *__restrict__ gflow, int B, int C, int H, int W,
@@ -913,12 +913,22 @@ __global__ __launch_bounds__(256, TH == 16 ? CERB_TILE16_WPS : 4) void warp_bwd_
     dxh = max(max(red[0][5], red[1][5]), max(red[2][5], red[3][5]));
     dyl = min(min(red[0][6], red[1][6]), min(red[2][6], red[3][6]));
     dyh = max(max(red[0][7], red[1][7]), max(red[2][7], red[3][7]));
-    int n = 0, xs = 0, ys = 0, rw = 1;
+    // 16-bit storage (round 6): sources are handled as horizontally adjacent PAIRS -- one dword of gradOutput per pair and
+    // channel instead of two halfword loads (a wave-level load costs the address path ~9 cycles whether its lanes fetch 2
+    // or 4 bytes: 23 % of a channel group's time at the 256 x 512 level was the ISSUE of these loads,
+    // profiles/r06_warp_bwd_tile_stamps_baseline.txt) -- so the region starts at an even column and has an even width
+    // (PR: a template parameter, chosen by the launcher -- with both forms in one kernel the 16-row variant spilled 76 VGPRs)
+    constexpr bool kPair16 = PR != 0 && sizeof(T) == 2 && NS % 2 == 0;
+    constexpr bool pairs = kPair16;
+    int n = 0, xs = 0, ys = 0, rw = 1, rh = 0;
     if (rx0 <= rx1) {   // at least one strip reaches the tile (ranges are small ints here)
         xs = max(rx0, tx0 - dxh);
         ys = max(ry0, ty0 - dyh);
-        rw = max(min(rx1, tx1 - dxl) + 1 - xs, 0);
-        n = rw * max(min(ry1, ty1 - dyl) + 1 - ys, 0);
+        int x_end = min(rx1, tx1 - dxl) + 1;       // one past the region's last column
+        if (pairs) { xs &= ~1; x_end = (x_end + 1) & ~1; }   // (W is even: the last pair ends inside the row)
+        rw = max(x_end - xs, 0);
+        rh = max(min(ry1, ty1 - dyl) + 1 - ys, 0);
+        n = rw * rh;
         rw = max(rw, 1);
     }
     __syncthreads();    // red[] is reused below
@@ -1144,10 +1154,12 @@ __global__ __launch_bounds__(256, TH == 16 ? CERB_TILE16_WPS : 4) void warp_bwd_
     // one set of gradOutput loads, one block reduction, the adds and the write-out.  The
     // list order depends on the waves' arrival order; the sums do not (integer adds commute).
     constexpr int kCap = (NP * PS * 8) / 16 < 256 * NS ? (NP * PS * 8) / 16 : 256 * NS;
+    constexpr int NSP = NS / 2;                                  // pairs per thread (16-bit storage)
+    constexpr int kCapP = (NP * PS * 8) / 32 < 256 * NSP ? (NP * PS * 8) / 32 : 256 * NSP;   // list capacity in pairs (two int4 each)
     int4 *list = reinterpret_cast<int4 *>(acc);
     if (tid == 0) red[1][1] = 0;
     __syncthreads();
-    {
+    if constexpr (!pairs) {
         // regions of up to 2560 pixels (a 16 x 64 tile under +-7 px of flow variation) are
         // classified in ONE batch: all position loads of the workgroup in flight together,
         // one counter update per wave
@@ -1178,45 +1190,123 @@ __global__ __launch_bounds__(256, TH == 16 ? CERB_TILE16_WPS : 4) void warp_bwd_
                     list[start + rank[j]] = make_int4(s[j].pv, s[j].o, __float_as_int(s[j].fx),
                                                       __float_as_int(s[j].fy));
         }
+    } else {
+        // the same walk over PAIRS of region pixels (the region is rw / 2 pairs wide): a pair is kept when either pixel
+        // touches the tile; its entry is two int4 (pixel index, the two tile offsets -- -1: does not touch --, four fractions)
+        constexpr int NBP = 5;
+        const int rwp = rw >> 1, npairs = rwp * rh;
+        Walk w(tid, max(rwp, 1));
+        for (int base = 0; base < npairs; base += 256 * NBP) {
+            Src s[NBP][2];
+            bool in[NBP];
+#pragma unroll
+            for (int j = 0; j < NBP; ++j) {
+                const bool on = base + j * 256 + tid < npairs;
+                const bool i0 = classify(on, w.ry, 2 * w.rx, s[j][0]);
+                const bool i1 = classify(on, w.ry, 2 * w.rx + 1, s[j][1]);
+                in[j] = i0 || i1;
+                w.next();
+            }
+            int rank[NBP], total = 0;
+#pragma unroll
+            for (int j = 0; j < NBP; ++j) {
+                const unsigned long long m = __ballot(in[j]);
+                rank[j] = total + __popcll(m & ((1ull << lane) - 1ull));
+                total += __popcll(m);
+            }
+            int start = 0;
+            if (lane == 0 && total) start = atomicAdd(&red[1][1], total);
+            start = __shfl(start, 0, 64);
+#pragma unroll
+            for (int j = 0; j < NBP; ++j)
+                if (in[j] && start + rank[j] < kCapP) {
+                    list[2 * (start + rank[j])] = make_int4(s[j][0].pv, s[j][0].o, __float_as_int(s[j][0].fx), __float_as_int(s[j][0].fy));
+                    list[2 * (start + rank[j]) + 1] = make_int4(s[j][1].o, __float_as_int(s[j][1].fx), __float_as_int(s[j][1].fy), 0);
+                }
+        }
     }
     __syncthreads();
-    const int count = red[1][1];
+    const int count = red[1][1];               // sources, or pairs of them
     __syncthreads();
     CERB_STAMP_AT(2);
 
-    if (count <= kCap) {
+    if (count <= (pairs ? kCapP : kCap)) {
         Src src[NS];
         float g[NS][CW];
-        const int ns = (count + 255) / 256;   // sources per thread actually present
+        const int ns = pairs ? 2 * ((count + 255) / 256) : (count + 255) / 256;   // sources per thread actually present
         const int first_pv = count > 0 ? list[0].x : 0;
+        if constexpr (!pairs) {
 #pragma unroll
-        for (int j = 0; j < NS; ++j) {
-            const int e = j * 256 + tid;
-            const int4 v = list[min(e, kCap - 1)];
-            const bool have = e < count;
-            // an idle slot (past the end of the list) points at the list's FIRST source: its gradOutput values then take
-            // part in the block maximum unmasked (a repeated value cannot change a maximum or add a non-finite one)
-            src[j].pv = have ? v.x : first_pv;
-            src[j].o = have ? v.y : -1;
-            src[j].fx = __int_as_float(v.z);
-            src[j].fy = __int_as_float(v.w);
+            for (int j = 0; j < NS; ++j) {
+                const int e = j * 256 + tid;
+                const int4 v = list[min(e, kCap - 1)];
+                const bool have = e < count;
+                // an idle slot (past the end of the list) points at the list's FIRST source: its gradOutput values then take
+                // part in the block maximum unmasked (a repeated value cannot change a maximum or add a non-finite one)
+                src[j].pv = have ? v.x : first_pv;
+                src[j].o = have ? v.y : -1;
+                src[j].fx = __int_as_float(v.z);
+                src[j].fy = __int_as_float(v.w);
+            }
+        } else {
+#pragma unroll
+            for (int jp = 0; jp < NSP; ++jp) {
+                const int e = jp * 256 + tid;
+                const int4 v0 = list[2 * min(e, kCapP - 1)], v1 = list[2 * min(e, kCapP - 1) + 1];
+                const bool have = e < count;
+                // (an idle pair points at the list's first pair, as above; a pixel of a live pair that does not touch the tile
+                // has o = -1: skipped by the adds and masked out of the block maximum)
+                src[2 * jp].pv = have ? v0.x : first_pv;
+                src[2 * jp].o = have ? v0.y : -1;
+                src[2 * jp].fx = __int_as_float(v0.z);
+                src[2 * jp].fy = __int_as_float(v0.w);
+                src[2 * jp + 1].pv = src[2 * jp].pv + 1;
+                src[2 * jp + 1].o = have ? v1.x : -1;
+                src[2 * jp + 1].fx = __int_as_float(v1.y);
+                src[2 * jp + 1].fy = __int_as_float(v1.z);
+            }
         }
+        // gradOutput of the channel group [c0, c0 + CW) at every source of the thread
+        auto load_all = [&](int c0) {
+            if constexpr (!pairs) {
+#pragma unroll
+                for (int j = 0; j < NS; ++j)
+                    if (j < ns) load_g(src[j], c0, g[j]);
+            } else {
+#if defined(__HIP_DEVICE_COMPILE__)
+                if constexpr (kPair16) {
+#pragma unroll
+                    for (int jp = 0; jp < NSP; ++jp)
+                        if (2 * jp < ns) {
+                            const int voff = src[2 * jp].pv * 2;      // an even pixel: a dword holds it and its right neighbour
+#pragma unroll
+                            for (int c = 0; c < CW; ++c) {
+                                const unsigned q = __builtin_amdgcn_raw_buffer_load_b32(
+                                    rsrc_go, voff, __builtin_amdgcn_readfirstlane(min(c0 + c, c_end - 1) * plane * 2), 0);
+                                g[2 * jp][c] = widen16<T>(static_cast<unsigned short>(q & 0xFFFFu));
+                                g[2 * jp + 1][c] = widen16<T>(static_cast<unsigned short>(q >> 16));
+                            }
+                        }
+                }
+#endif
+            }
+        };
         __syncthreads();                       // everyone has its sources: the LDS becomes accumulators
         static_assert((NP * PS) % 2 == 0, "accumulators are zeroed 16 bytes at a time");
         for (int i = tid; i < NP * PS / 2; i += 256) reinterpret_cast<int4 *>(acc)[i] = make_int4(0, 0, 0, 0);
-#pragma unroll
-        for (int j = 0; j < NS; ++j)
-            if (j < ns) load_g(src[j], c_begin, g[j]);
+        load_all(c_begin);
         __syncthreads();
         CERB_STAMP_AT(3);
 #pragma unroll
         for (int j = 0; j < NS; ++j)
             if (j < ns) add_density(src[j]);
+        // (pairs: a pixel of a live pair that does not touch the tile is masked out of the maximum -- the scale, and with
+        // it every bit of the result, is then the one the pixel-by-pixel form computes)
         int gb0 = 0;
 #pragma unroll
         for (int j = 0; j < NS; ++j)
-            if (j < ns) gb0 = absmax_bits(src[j], g[j], gb0);
-        const int sbits = density_bits(count, gb0);
+            if (j < ns) gb0 = pairs ? absmax_bits_masked(src[j], g[j], gb0) : absmax_bits(src[j], g[j], gb0);
+        const int sbits = density_bits(pairs ? 2 * count : count, gb0);
         CERB_STAMP_AT(4);
         for (int c0 = c_begin; c0 < c_end; c0 += CW) {
             const int cw = min(CW, c_end - c0);
@@ -1225,7 +1315,7 @@ __global__ __launch_bounds__(256, TH == 16 ? CERB_TILE16_WPS : 4) void warp_bwd_
                 gb = 0;
 #pragma unroll
                 for (int j = 0; j < NS; ++j)
-                    if (j < ns) gb = absmax_bits(src[j], g[j], gb);
+                    if (j < ns) gb = pairs ? absmax_bits_masked(src[j], g[j], gb) : absmax_bits(src[j], g[j], gb);
             }
             float scale, unscale;
             bool nonfinite;
@@ -1236,11 +1326,7 @@ __global__ __launch_bounds__(256, TH == 16 ? CERB_TILE16_WPS : 4) void warp_bwd_
                 if (j < ns) add_taps(src[j], g[j], cw, scale, nonfinite);
             if (c0 == c_begin) CERB_STAMP_AT(6);
             // the next group's gradOutput travels while this group's tile is written out
-            if (c0 + CW < c_end) {
-#pragma unroll
-                for (int j = 0; j < NS; ++j)
-                    if (j < ns) load_g(src[j], c0 + CW, g[j]);
-            }
+            if (c0 + CW < c_end) load_all(c0 + CW);
             __syncthreads();   // every tap of the group has been added
             if (c0 == c_begin) CERB_STAMP_AT(7);
             write_out(c0, cw, unscale, nonfinite);
@@ -1500,12 +1586,23 @@ static int launch_tiles(const void *image, const void *gout, const void *ctx, vo
         else if (tile_blocks == 256 && total > 512 && total <= 1024) stagger = 6 | (2 << 8);
     }
     if (stagger < 0) stagger = 0;
-    hipLaunchKernelGGL((warp_bwd_tile_kernel<T, F, TH, CW, NS>),
-                       dim3(static_cast<unsigned>(tile_blocks + flow_blocks)), dim3(256), 0, s,
-                       static_cast<const T *>(image), static_cast<const T *>(gout), ctx,
-                       static_cast<T *>(gimage), static_cast<F *>(gflow), B,
-                       C, H, W, tiles_x, tiles_y, nrange, crange, static_cast<int>(tile_blocks),
-                       pad_mode, flow16 ? 2 : flow_staged ? 1 : 0, flow_sub, stagger);
+    // 16-bit storage: the tile role takes its sources as horizontally adjacent pairs (one dword of gradOutput per pair)
+    constexpr bool can_pair = sizeof(T) == 2 && NS % 2 == 0;
+    const bool pair_sources = can_pair && W % 2 == 0 && (reinterpret_cast<uintptr_t>(gout) & 3) == 0 && option(OPT_WARP_PAIR16) >= 0;
+#define CERB_LAUNCH_TILES(PR)                                                                          \
+    hipLaunchKernelGGL((warp_bwd_tile_kernel<T, F, TH, CW, NS, PR>),                                   \
+                       dim3(static_cast<unsigned>(tile_blocks + flow_blocks)), dim3(256), 0, s,        \
+                       static_cast<const T *>(image), static_cast<const T *>(gout), ctx,               \
+                       static_cast<T *>(gimage), static_cast<F *>(gflow), B,                           \
+                       C, H, W, tiles_x, tiles_y, nrange, crange, static_cast<int>(tile_blocks),       \
+                       pad_mode, flow16 ? 2 : flow_staged ? 1 : 0, flow_sub, stagger)
+    if constexpr (can_pair) {
+        if (pair_sources) CERB_LAUNCH_TILES(1); else CERB_LAUNCH_TILES(0);
+    } else {
+        (void)pair_sources;
+        CERB_LAUNCH_TILES(0);
+    }
+#undef CERB_LAUNCH_TILES
     return launch_status();
 }
 
