@@ -1651,8 +1651,8 @@ def main():
             traffic_src = dict(live_info, measured_by_this_run=True,
                                ratio_to_algorithmic=round(traffic / kern[dominant], 3))
         cfg_key = (args.width, args.height, args.dtype)
-        tnames = {(1024, 512, "f32"): ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"),
-                  (2048, 1024, "f16"): ("r05_config5_f16_pmc_traffic.json", "r04_config5_f16_pmc_traffic.json",
+        tnames = {(1024, 512, "f32"): ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"),
+                  (2048, 1024, "f16"): ("r06_config5_f16_pmc_traffic.json", "r05_config5_f16_pmc_traffic.json", "r04_config5_f16_pmc_traffic.json",
                                         "r03_config5_f16_pmc_traffic.json", "r02_config5_f16_pmc_traffic.json")}.get(cfg_key, ())
         for tname in tnames:
             tpath = os.path.join(REPO, "profiles", tname)

@@ -1653,8 +1653,9 @@ int warp_backward(const void *image, const void *flow, const void *gout, void *g
         const int th_opt = option(OPT_WARP_TILE_H);
         const bool th8 = th_opt ? th_opt == 8 : static_cast<int64_t>(B) * H * W <= 64 * 128 * 4;
         if (th8) {
+            // (16-bit storage: six sources per thread instead of five, an even number: they are taken as pairs)
             CERB_DISPATCH2(dtype, flow_dtype, if constexpr (!std::is_same<T, double>::value)
-                return (launch_tiles<T, F, 8, 5>(image, gout, ctx, gimage, gflow, B, C, H, W, pad_mode, s)))
+                return (launch_tiles<T, F, 8, sizeof(T) == 2 ? 6 : 5>(image, gout, ctx, gimage, gflow, B, C, H, W, pad_mode, s)))
         } else {
             CERB_DISPATCH2(dtype, flow_dtype, if constexpr (!std::is_same<T, double>::value)
                 return (launch_tiles<T, F, 16, 6>(image, gout, ctx, gimage, gflow, B, C, H, W, pad_mode, s)))
