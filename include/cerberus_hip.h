@@ -224,16 +224,18 @@ int cerberus_area_pyramid(const void *src, void *const *dsts, const int *out_h, 
  *                          layout divides: corr_coarse.hip; auto uses it there up to 2560 (row, displacement
  *                          row) workgroups), 16 = auto without it, 17 = the persistent, cross-item pipelined forward
  *                          (fp32, C % 8 == 0: corr_fwd_pipe.hip; built and measured in round 5, slower than the tile
- *                          kernels: never picked by auto; with it, "corr_bwd_cslice" > 0 sets its number of workgroups)
+ *                          kernels: -DCERB_EXPERIMENTS builds only since round 6; with it, "corr_bwd_cslice" > 0 sets
+ *                          its number of workgroups)
  *   "corr_bwd_variant"   : 0 = auto, 1 = all 81 displacements per lane (register-staged),
  *                          3 = three displacement groups, 4 / 5 = LDS-DMA with the 8x64 /
  *                          16x32 tile (fp32, W % 4 == 0), 8 = displacement-row streaming,
  *                          11 = the matrix-core kernel in its row-per-wave form of rounds 2-4 (fp16 / bf16 storage; auto
  *                          uses the segment-per-wave form of round 5: same bits, 8-12 % faster),
- *                          12 = whole image rows per wavefront (fp32, W in {256, 128, 64}; auto uses
- *                          it where such a map has enough workgroups for the chip; 13 = auto, but not
- *                          on 64-wide maps), 14 = the coarse-level kernel (fp32, W = 16 / 32 / 64,
- *                          corr_coarse.hip; auto uses it there up to 4096 workgroups), 15 = auto without
+ *                          12 = whole image rows per wavefront (fp32; round 6: any W % 4 == 0 up to 256, any
+ *                          H and C -- widths between 64 / 128 / 256 run on the lanes of the next one; auto uses
+ *                          it on maps wider than 64 with enough workgroups for the chip and on exact 64-wide
+ *                          ones; 13 = auto, but not on 64-wide maps), 14 = the coarse-level kernel (fp32, round 6:
+ *                          any W % 4 == 0 up to 64, corr_coarse.hip; auto uses it there up to 4096 workgroups), 15 = auto without
  *                          it; 2, 6, 7, 9, 10 (and forward
  *                          1, 2, 8) are measured-and-rejected variants that exist only in
  *                          -DCERB_EXPERIMENTS test builds (otherwise: auto)
@@ -265,6 +267,11 @@ int cerberus_area_pyramid(const void *src, void *const *dsts, const int *out_h, 
  *                          256 workgroups in units of 1024 cycles, one byte each.  Speed only: same results.
  *   "warp_fewc"          : 0 = auto (a warp of <= 4 channels takes the lane-per-pixel kernels when no context /
  *                          no grad_image is asked for: the photometric loss's RGB warps), -1 = off.  Same bits.
+ *   "warp_pair16"        : (round 6) 0 = auto: fp16 / bf16 images with W % 8 == 0 take the kernels of warp16.hip --
+ *                          forward and the backward's grad_flow role with two pixels per lane and a raw 16-bit LDS
+ *                          window filled by LDS-DMA, the backward's tile role with its sources as pairs (W % 2 == 0);
+ *                          -1 = off (the general kernels); 1 = additionally the fp32 forward through the same
+ *                          window kernel (measured slower than the staged one: for A/B only).  Same bits in every case.
  * Returns CERB_EINVAL for an unknown key. */
 int cerberus_set_option(const char *key, int value);
 int cerberus_get_option(const char *key, int *value);
