@@ -74,28 +74,38 @@ __device__ __forceinline__ void static_for(F &&f) {
 // RAG  1: ragged shapes -- the image is narrower than the lanes' 4 * SPR columns (any W % 4 == 0 up to that), H need not
 //      be a multiple of the workgroup's rows, C not of its channels: the true width is a run-time value, lanes past a
 //      row's end load nothing (their zeros ARE the zero padding their left neighbour's DPP shift picks up), stores are masked
-template <int SPR_, int NWV_, int FLAGS_ = 0, int CW_ = 4, int NIT_ = 1, int RAG_ = 0>
+// NRP  row pairs per workgroup (round 6 experiment): NRP = 2 -> 16 waves = 2 row pairs x 8 channel groups.  The two
+//      pairs walk the cyclic schedule two steps apart, so they request the SAME x rows in the same time step (the second request
+//      is an L1 hit: 12 x rows from L2 for 4 output rows instead of 10 for 2); the gradOutput ring holds both pairs' planes
+//      (2 x 18 per step: 147 KB, one workgroup per CU at the same 4 waves per SIMD)
+template <int SPR_, int NWV_, int FLAGS_ = 0, int CW_ = 4, int NIT_ = 1, int RAG_ = 0, int NRP_ = 1>
 struct StripCfg {
     static constexpr int NIT = NIT_;
-    static constexpr bool RAG = RAG_ != 0;   // work items a workgroup walks one after the other (round 5 experiment: 2 -> half the grid)
+    static constexpr bool RAG = RAG_ != 0;
+    static constexpr int NRP = NRP_;   // work items a workgroup walks one after the other (round 5 experiment: 2 -> half the grid)
     // timing-experiment flags (-DCERB_ABLATE builds): 1 gradOutput DMA non-temporal, 2 x loads non-temporal, 4 no FMAs,
     // 8 no loads / DMAs, 16 no LDS reads, 32 natural step order, 64 no step barrier, 256 no stores (all but 1, 2, 32, 512: wrong results),
     // 512 experiment: a step's memory instructions inside its FMA stream instead of behind it (slower: see step())
     static constexpr int FLAGS = FLAGS_;
     static constexpr int SPR = SPR_, W = 4 * SPR_, RW = 64 / SPR_;
     static constexpr int NR = 2, CW = CW_, NWV = NWV_, CWG = CW * NWV_;
-    static constexpr int ROWS = NR * RW;                 // image rows per workgroup
-    static constexpr int THREADS = 64 * NWV_;
+    static constexpr int ROWS = NR * RW;                 // image rows per row pair (a wave's rows)
+    static constexpr int ROWS_WG = NRP_ * ROWS;          // image rows per workgroup
+    static constexpr int NWAVES = NWV_ * NRP_;
+    static constexpr int THREADS = 64 * NWAVES;
     static constexpr int NSLOT = 4;
     // waves per SIMD the register allocator leaves room for: two 8-wave workgroups per CU on the 256-wide level
     // (one round of 512 workgroups at 4 pairs); the narrower levels have fewer workgroups than that anyway
     static constexpr int WPS = NIT_ > 1 ? 2 : (SPR_ == 64 || CW_ < 4) ? 4 : 2;
     static constexpr int PITCH = W * 4;                  // bytes per staged gradOutput row
     static constexpr int ENTRY = RW * PITCH;             // one (j, dx) plane: RW rows
-    static constexpr int SLOT = NR * kND * ENTRY;        // one step
-    static constexpr int NDMA = (NR * kND + NWV_ - 1) / NWV_;   // DMA instructions per wave and step
+    static constexpr int PAIRB = NR * kND * ENTRY;       // one row pair's planes of one step
+    static constexpr int SLOT = NRP_ * PAIRB;            // one step
+    static constexpr int NPL = NRP_ * NR * kND;          // planes per step
+    static constexpr int NDMA = (NPL + NWAVES - 1) / NWAVES;   // DMA instructions per wave and step
     static constexpr size_t LDS_BYTES = static_cast<size_t>(NSLOT) * SLOT + ENTRY;   // + a scratch entry for idle DMA slots
     static_assert(64 % SPR_ == 0, "whole rows per wave");
+    static_assert(NRP_ == 1 || NIT_ == 1, "row pairs and multi-item walks are separate experiments");
     static_assert((NR * kND - 1) * ENTRY < 65536, "ds_read immediate offsets");
 };
 
@@ -143,6 +153,7 @@ struct StripBwd {
     __amdgpu_buffer_rsrc_t rsrc_x, rsrc_g;
     float *smem;
     int H, plane, wave, lane, y0;
+    int rp;                        // the wave's row pair (0 unless K::NRP > 1); y0 is THIS pair's first row
     int Wr;                        // the image's width (RAG: <= K::W, the lanes' capacity; otherwise K::W itself)
     bool lane_live;                // the lane's strip lies inside the image row
     __device__ __forceinline__ int width() const { if constexpr (K::RAG) return Wr; else return K::W; }
@@ -183,14 +194,20 @@ struct StripBwd {
     __device__ __forceinline__ void issue_g1(int S, bool live, int slot, int q) {
         const int lr = lane / K::SPR, sx = lane % K::SPR;
         {
-            const int k = wave + K::NWV * q;                    // wave-uniform
-            const int j = k >= kND ? 1 : 0, dx = k - j * kND;
-            const int dyi = S - j;                              // vertical displacement index of the block
-            const bool act = live && k < K::NR * kND && dyi >= 0 && dyi < kND;
+            const int k = wave + K::NWAVES * q;                 // wave-uniform: plane k of the step's NPL
+            // (NRP > 1: plane k belongs to row pair kp, whose rows start (kp - rp) * ROWS below this wave's and whose cyclic
+            // schedule is that many steps behind)
+            const int kp = K::NRP > 1 ? k / (K::NR * kND) : 0, kk = k - kp * (K::NR * kND);
+            const int y0k = y0 + (kp - rp) * K::ROWS;
+            int Sk = S;
+            if constexpr (K::NRP > 1) { Sk = (S - (kp - rp) * K::ROWS) % 10; Sk = Sk < 0 ? Sk + 10 : Sk; }
+            const int j = kk >= kND ? 1 : 0, dx = kk - j * kND;
+            const int dyi = Sk - j;                             // vertical displacement index of the block
+            const bool act = live && k < K::NPL && dyi >= 0 && dyi < kND;
             const int pl = SIDE == 0 ? dyi * kND + dx : (kND - 1 - dyi) * kND + (kND - 1 - dx);
             // one instruction = the 64 cells of an entry: lane-row lr reads its image row (side 0:
             // the lane's own output row j; side 1: the x row of the step)
-            const int row = SIDE == 0 ? y0 + lr * K::NR + j : y0 + lr * K::NR + S - kD;
+            const int row = SIDE == 0 ? y0k + lr * K::NR + j : y0k + lr * K::NR + Sk - kD;
             const bool ok = act && (!K::RAG || lane_live) && static_cast<unsigned>(row) < static_cast<unsigned>(H);
             // side 1 reads the row shifted by ex = dx - 4 (a dword-aligned 16-byte read per lane).
             // The request never leaves the batch item's 81 planes (ex < 0 only occurs on planes
@@ -212,10 +229,13 @@ struct StripBwd {
         if constexpr (SIDE == 1 && !(K::FLAGS & 8)) {
 #pragma unroll
             for (int q = 0; q < K::NDMA; ++q) {
-                const int k = wave + K::NWV * q;
-                const int j = k >= kND ? 1 : 0, dx = k - j * kND, ex = dx - kD;
-                const int dyi = S - j;
-                const bool act = k < K::NR * kND && dyi >= 0 && dyi < kND;
+                const int k = wave + K::NWAVES * q;
+                const int kp = K::NRP > 1 ? k / (K::NR * kND) : 0, kk = k - kp * (K::NR * kND);
+                int Sk = S;
+                if constexpr (K::NRP > 1) { Sk = (S - (kp - rp) * K::ROWS) % 10; Sk = Sk < 0 ? Sk + 10 : Sk; }
+                const int j = kk >= kND ? 1 : 0, dx = kk - j * kND, ex = dx - kD;
+                const int dyi = Sk - j;
+                const bool act = k < K::NPL && dyi >= 0 && dyi < kND;
                 const int n = act ? (ex < 0 ? -ex : ex) : 0;
 #pragma unroll
                 for (int lr = 0; lr < K::RW; ++lr) {
@@ -357,8 +377,9 @@ void corr_bwd_d4_strip_kernel(const float *__restrict__ x1, const float *__restr
     const int b = __builtin_amdgcn_readfirstlane(bid / nyb);
     const int Wr = K::RAG ? Wimg : K::W;
     const int plane = H * Wr;
-    const int c0 = cb * K::CWG + wave * K::CW;
-    const int y0 = yb * K::ROWS;
+    const int rp = K::NRP > 1 ? wave / K::NWV : 0;            // the wave's row pair and channel group
+    const int c0 = cb * K::CWG + (wave - rp * K::NWV) * K::CW;
+    const int y0 = yb * K::ROWS_WG + rp * K::ROWS;
 
     const float *src = (side == 0 ? x2 : x1) + (static_cast<int64_t>(b) * C + c0) * plane;
     float *dst = (side == 0 ? gin1 : gin2) + (static_cast<int64_t>(b) * C + c0) * plane;
@@ -376,9 +397,9 @@ void corr_bwd_d4_strip_kernel(const float *__restrict__ x1, const float *__restr
         st.lane_live = sx * 4 < Wr;
         st.rsrc_g = uniform_rsrc(gob, kND * kND * plane * 4);
         st.smem = smem;
-        st.H = H; st.plane = plane; st.wave = wave; st.lane = lane; st.y0 = y0;
+        st.H = H; st.plane = plane; st.wave = wave; st.lane = lane; st.y0 = y0; st.rp = rp;
         st.lds_base = static_cast<unsigned>(reinterpret_cast<size_t>((__attribute__((address_space(3))) float *)smem));
-        st.lds_lane = st.lds_base + lr * K::PITCH + sx * 16;
+        st.lds_lane = st.lds_base + rp * K::PAIRB + lr * K::PITCH + sx * 16;
         st.row0 = y0 + lr * K::NR - kD;
         st.voff0 = (st.row0 * Wr + sx * 4) * 4;
 #pragma unroll
@@ -463,7 +484,7 @@ void corr_bwd_d4_strip_kernel(const float *__restrict__ x1, const float *__restr
 template <typename K>
 int launch_strip(const char *name, const void *in1, const void *in2, const void *goutp, void *g1p,
                  void *g2p, const CorrGeom &g, hipStream_t s) {
-    const int nyb = (g.H + K::ROWS - 1) / K::ROWS, ncb = (g.C + K::CWG - 1) / K::CWG;
+    const int nyb = (g.H + K::ROWS_WG - 1) / K::ROWS_WG, ncb = (g.C + K::CWG - 1) / K::CWG;
     int64_t blocks = static_cast<int64_t>(g.B) * nyb * ncb * 2;
     if (blocks > 0x7fffffff) return CERB_ETOOLARGE;
     if (blocks % K::NIT) return CERB_EUNSUPPORTED;
@@ -534,6 +555,9 @@ int corr_strip_backward(const void *in1, const void *in2, const void *gout, void
         if (option(OPT_CORR_BWD_CSLICE) == 2 && g.H % 2 == 0 && g.C % 32 == 0)
             return launch_strip<StripCfg<64, 8, 0, 4, 2>>("corr_bwd_d4_strip_w256_2items", in1, in2, gout, gin1, gin2, g, s);
 #endif
+        // round 6, VERDICT r5 #4 (one bounded structural attempt): 16 waves = 2 row pairs x 8 channel groups, one workgroup per CU
+        if (option(OPT_CORR_BWD_CSLICE) == 16 && g.H % 4 == 0 && g.C % 32 == 0)
+            return launch_strip<StripCfg<64, 8, 0, 4, 1, 0, 2>>("corr_bwd_d4_strip_w256_2pairs", in1, in2, gout, gin1, gin2, g, s);
         CERB_STRIP(64, 8, 0, "corr_bwd_d4_strip_w256");
     } else if (g.W == 128) {
 #ifdef CERB_ABLATE

@@ -880,6 +880,31 @@ def test_strip_backward_against_the_oracle(shape):
     assert np.array_equal(g1, g1b) and np.array_equal(g2, g2b)
 
 
+@pytest.mark.parametrize("shape", [(2, 32, 16, 256), (1, 64, 8, 256), (3, 32, 12, 256), (4, 32, 128, 256)])
+def test_strip_backward_with_two_row_pairs_per_workgroup(shape):
+    """Round 6, VERDICT r5 #4: StripCfg NRP = 2 (option corr_bwd_cslice = 16): sixteen waves = two row pairs x eight channel
+    groups, the pairs two steps apart in the cyclic schedule, one gradOutput ring for both -- against the oracle (the
+    benched level against the default strip kernel, itself pinned there) and bit-identical to the one-pair form (the same
+    per-lane arithmetic in the same order)."""
+    B, C, H, W = shape
+    x1, x2 = hash_uniform(shape, 451), hash_uniform(shape, 452)
+    go = hash_uniform((B, 81, H, W), 453)
+    _lib.set_option("corr_bwd_variant", 12)
+    try:
+        g1d, g2d = run_bwd(x1, x2, go, (4, 1, 4, 1, 1))
+        _lib.set_option("corr_bwd_cslice", 16)
+        g1, g2 = run_bwd(x1, x2, go, (4, 1, 4, 1, 1))
+        name = _lib.last_kernel(1)
+    finally:
+        _lib.set_option("corr_bwd_variant", 0)
+        _lib.set_option("corr_bwd_cslice", 0)
+    assert name == "corr_bwd_d4_strip_w256_2pairs", name
+    if B * H * W <= 64 * 1024:
+        r1, r2 = oracle.corr_backward_ref(x1, x2, go, 4, 1, 4, 1, 1)
+        assert rel_err(g1, r1) < TOL and rel_err(g2, r2) < TOL
+    assert np.array_equal(g1, g1d) and np.array_equal(g2, g2d)
+
+
 RAGGED_STRIP_SHAPES = [(2, 32, 14, 224), (1, 64, 7, 152), (2, 32, 11, 112), (1, 40, 9, 76), (2, 24, 13, 56), (1, 16, 5, 28),
                        (1, 33, 6, 252), (3, 7, 3, 4), (1, 36, 17, 132), (2, 48, 10, 68), (1, 20, 8, 64), (1, 30, 6, 256),
                        (1, 32, 7, 128)]
