@@ -312,6 +312,8 @@ int warp16_forward(const void *image, const void *flow, void *out, void *ctx, in
     const int nrange = (C + crange - 1) / crange;
     const int64_t blocks = tiles * nrange;
     if (blocks > 0x7fffffff) return CERB_ETOOLARGE;
+    // (a phase shift of the workgroups that share a CU -- the k-th of a CU starting k x 1 .. 8 k cycles late, so that one's set-up
+    // runs beside another's channel phase -- was tried and loses at every step and level: 23.7 -> 23.9 .. 28.3 us at 32 x 256 x 512)
 #define CERB_LAUNCH16(T, F)                                                                                        \
     hipLaunchKernelGGL((warp_fwd_staged16_kernel<T, F>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s,     \
                        static_cast<const T *>(image), static_cast<const F *>(flow), static_cast<T *>(out), ctx, B, \

@@ -13,18 +13,22 @@ typedef unsigned u4v __attribute__((ext_vector_type(4)));
 constexpr int kTile16W = 64, kTile16H = 8;
 
 
-// min / max over each 16-lane DPP row; lane 15 of every row holds its row's result
+// min / max over each 16-lane DPP row; lane 15 of every row holds its row's result (fused DPP steps: see wave_minmax)
 template <bool MAX> __device__ __forceinline__ int row_minmax(int v) {
-#define CERB_DPP_STEP(ctrl)                                                           \
-    {                                                                                 \
-        const int o = __builtin_amdgcn_update_dpp(v, v, ctrl, 0xf, 0xf, false);       \
-        v = MAX ? max(v, o) : min(v, o);                                              \
-    }
-    CERB_DPP_STEP(0x111)   // row_shr:1
-    CERB_DPP_STEP(0x112)   // row_shr:2
-    CERB_DPP_STEP(0x114)   // row_shr:4
-    CERB_DPP_STEP(0x118)   // row_shr:8
-#undef CERB_DPP_STEP
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (MAX)
+        asm volatile("s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                     "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+                     "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+                     "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+                     "s_nop 1" : "+v"(v));
+    else
+        asm volatile("s_nop 1\n\tv_min_i32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                     "s_nop 1\n\tv_min_i32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+                     "s_nop 1\n\tv_min_i32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+                     "s_nop 1\n\tv_min_i32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+                     "s_nop 1" : "+v"(v));
+#endif
     return v;
 }
 

@@ -202,22 +202,34 @@ __device__ __forceinline__ void flow_grad_terms(A vnw, A vne, A vsw, A vse, A ax
 constexpr int kStageRows = 4;     // strips (waves) per workgroup, stacked vertically
 [[maybe_unused]] constexpr int kDeadOffset = static_cast<int>(0x80000000u);   // buffer offset that reads 0 / drops a store
 
-// Wave-wide min / max through DPP row shifts and row broadcasts: 6 VALU instructions and no
-// LDS crossbar traffic (__shfl_xor is a ds_bpermute_b32 each); the result is wave-uniform.
+// Wave-wide min / max through DPP row shifts and row broadcasts; the result is wave-uniform.  Round 6: the six steps are
+// v_min_i32_dpp / v_max_i32_dpp themselves (inline asm: the compiler makes v_mov + v_mov_dpp + v_min of every
+// __builtin_amdgcn_update_dpp step, 18 VALU instructions per reduction instead of 6; a forward wave runs eight of them, a
+// backward tile workgroup eight + two per channel group).  `s_nop 1`: a DPP operand written by the previous VALU instruction
+// needs two wait states, and the hazard recogniser does not look into inline asm.  A lane whose DPP source does not exist
+// (bound_ctrl off) keeps its value: the same folds as before, bit for bit.
 template <bool MAX> __device__ __forceinline__ int wave_minmax(int v) {
-#define CERB_DPP_STEP(ctrl, rows)                                                     \
-    {                                                                                 \
-        const int o = __builtin_amdgcn_update_dpp(v, v, ctrl, rows, 0xf, false);      \
-        v = MAX ? max(v, o) : min(v, o);                                              \
-    }
-    CERB_DPP_STEP(0x111, 0xf)   // row_shr:1
-    CERB_DPP_STEP(0x112, 0xf)   // row_shr:2
-    CERB_DPP_STEP(0x114, 0xf)   // row_shr:4
-    CERB_DPP_STEP(0x118, 0xf)   // row_shr:8  -> lane 15 of every row holds the row's result
-    CERB_DPP_STEP(0x142, 0xa)   // row_bcast:15 into rows 1 and 3
-    CERB_DPP_STEP(0x143, 0xc)   // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave's
-#undef CERB_DPP_STEP
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (MAX)
+        asm volatile("s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                     "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+                     "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+                     "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+                     "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                     "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+                     "s_nop 1" : "+v"(v));
+    else
+        asm volatile("s_nop 1\n\tv_min_i32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                     "s_nop 1\n\tv_min_i32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+                     "s_nop 1\n\tv_min_i32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+                     "s_nop 1\n\tv_min_i32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+                     "s_nop 1\n\tv_min_i32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                     "s_nop 1\n\tv_min_i32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+                     "s_nop 1" : "+v"(v));
     return __builtin_amdgcn_readlane(v, 63);
+#else
+    return v;
+#endif
 }
 
 // 4 consecutive pixels of storage type T through a buffer resource, widened to fp32
