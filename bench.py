@@ -640,7 +640,9 @@ def cpu_baseline(levels, budget_s=20.0):
     # many-core host that is far slower than the probed thread count (thread fan-out on small maps: 19.8 s for ONE config-1
     # forward on 256 cores), so it runs in a CHILD process with a hard deadline: the levels it finished are measured, the
     # rest are scaled from the probed-thread medians by the ratio seen on the finished ones (stated per level).
-    all_budget = max(6.0, budget_s) if ncpu <= 64 else 60.0      # 256 threads: ~50 s per fwd+bwd of the SMALLEST level (round-6 run)
+    # (256 threads: ~50 s per fwd + bwd of ANY level -- the cost is the fork / join of ~500 small parallel regions, not the
+    # tensor size -- so on such a host the deadline lets the smallest level finish once or twice and the rest is scaled)
+    all_budget = max(6.0, budget_s) if ncpu <= 64 else 100.0
     all_table, all_note = _cpu_all_cores_child(levels, all_budget)
     done = [k for k, v in all_table.items() if v.get("iters")]
     ratio = (sum(all_table[k]["fwd_bwd_ms_median"] for k in done) / sum(table[k]["fwd_bwd_ms_median"] for k in done)) if done else None

@@ -312,6 +312,9 @@ int warp16_forward(const void *image, const void *flow, void *out, void *ctx, in
     const int nrange = (C + crange - 1) / crange;
     const int64_t blocks = tiles * nrange;
     if (blocks > 0x7fffffff) return CERB_ETOOLARGE;
+    // a small map gives too few 8 x 64 tiles to fill the chip: the general kernel's 8 x 32 tiles do better there
+    // (128 x 32 x 64 at 4 pairs: 256 workgroups here, 6.5 us, against 512 and 6.2 us; 64 x 64 x 128: 512, 8.0 against 8.6)
+    if (blocks < 512 && crange_opt < 4) return CERB_EUNSUPPORTED;
     // (a phase shift of the workgroups that share a CU -- the k-th of a CU starting k x 1 .. 8 k cycles late, so that one's set-up
     // runs beside another's channel phase -- was tried and loses at every step and level: 23.7 -> 23.9 .. 28.3 us at 32 x 256 x 512)
 #define CERB_LAUNCH16(T, F)                                                                                        \

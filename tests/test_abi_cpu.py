@@ -158,3 +158,22 @@ def test_product_never_imports_oracle():
                 text = open(os.path.join(root, f)).read()
                 assert "import oracle" not in text and "from oracle" not in text, f
                 assert "corr_oracle" not in text, f
+
+
+def test_the_product_library_holds_dispatched_code_only():
+    """the measured-and-rejected kernels (the persistent pipelined forward, the column-walking / two-item
+    backward variants) are compiled into lib/libcerberus_hip_experiments.so only; both libraries export the same C ABI."""
+    exp_path = os.path.join(os.path.dirname(_lib.LIB_PATH), "libcerberus_hip_experiments.so")
+    assert os.path.exists(exp_path), "python -m cerberusnet_amd.build --experiments (or __graft_entry__.build())"
+    v = ctypes.c_int(-1)
+    assert _lib.get().cerberus_get_option(b"experiments_build", ctypes.byref(v)) == 0 and v.value == (
+        1 if "experiments" in os.path.basename(_lib.LIB_PATH) else 0)
+    exp = ctypes.CDLL(exp_path)
+    assert exp.cerberus_get_option(b"experiments_build", ctypes.byref(v)) == 0 and v.value == 1
+    for name in _declared_symbols():
+        assert hasattr(exp, name), name
+    prod_bytes, exp_bytes = open(os.path.join(os.path.dirname(exp_path), "libcerberus_hip.so"), "rb").read(), open(exp_path, "rb").read()
+    for marker in (b"corr_fwd_d4_pipe", b"corr_bwd_d4_col_4x64", b"corr_bwd_d4_strip_w256_2items"):
+        assert marker in exp_bytes and marker not in prod_bytes, marker
+    from cerberusnet_amd import build
+    assert "corr_fwd_pipe.hip" not in build.SOURCES and "corr_fwd_pipe.hip" in build.EXPERIMENT_SOURCES
