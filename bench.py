@@ -213,6 +213,42 @@ class Workload:
         self._levels_bwd(self.stacked, list(reversed(coarse)), keep)
         return keep
 
+    def step_stacked(self, streams, stacked_levels):
+        """Generalisation of step_hybrid (an experiment: --stack-levels 0,2): the levels in
+        `stacked_levels` run as ONE batched call per op for both directions on the main stream, the others on two
+        streams; the streams join in front of every stacked level and fork again behind it."""
+        if getattr(self, "stacked", None) is None:
+            self.stacked = []
+            for a, b in zip(*self.dirs):
+                self.stacked.append({k: (torch.cat([a[k], b[k]], 0) if a[k] is not None else None)
+                                     for k in ("f1", "f2", "gout", "flow")})
+        keep = []
+        main, side = torch.cuda.current_stream(), streams[0]
+        forked = [False]
+
+        def level(l, fwd):
+            if l in stacked_levels:
+                if forked[0]:
+                    main.wait_stream(side)
+                    forked[0] = False
+                (self._levels_fwd(self.stacked, [l]) if fwd else self._levels_bwd(self.stacked, [l], keep))
+            else:
+                if not forked[0]:
+                    side.wait_stream(main)
+                    forked[0] = True
+                with torch.cuda.stream(side):
+                    (self._levels_fwd(self.dirs[1], [l]) if fwd else self._levels_bwd(self.dirs[1], [l], keep))
+                (self._levels_fwd(self.dirs[0], [l]) if fwd else self._levels_bwd(self.dirs[0], [l], keep))
+
+        n = len(self.levels)
+        for l in range(n):
+            level(l, True)
+        for l in reversed(range(n)):
+            level(l, False)
+        if forked[0]:
+            main.wait_stream(side)
+        return keep
+
     def serial_step(self, skip=None):
         """Both directions on the current stream; `skip` leaves one launch of direction 0 out."""
         keep = []
@@ -1263,6 +1299,9 @@ def main():
                     help="the two flow directions as ONE batched call per op on the N coarsest levels (where a launch is priced by "
                          "its latency), two streams above (VERDICT r4 #8; default 1: level 0 stacked, -6.7 us per step; 2 loses; "
                          "0 = rounds 1-4: every level on two streams)")
+    ap.add_argument("--stack-levels", default=None, metavar="L,L",
+                    help="experiment: exactly these levels as one batched call for both directions (joins / forks around them); "
+                         "overrides --stack-coarse")
     ap.add_argument("--chains", type=int, default=1,
                     help="split each direction's batch into this many independent sub-batches, "
                          "one HIP stream each")
@@ -1409,6 +1448,9 @@ def main():
                                                    for _ in range(max(1, len(wl.dirs) - 1))]
     hybrid = bool(args.stack_coarse and streams and len(wl.dirs) == 2)
     step_fn = (lambda: wl.step_hybrid(streams, args.stack_coarse)) if hybrid else (lambda: wl.step(streams))
+    if args.stack_levels is not None and streams and len(wl.dirs) == 2:
+        stacked_set = {int(v) for v in args.stack_levels.split(",") if v != ""}
+        step_fn = lambda: wl.step_stacked(streams, stacked_set)
     for _ in range(max(1, args.warmup if args.no_graph else 3)):
         step_fn()
     torch.cuda.synchronize()
@@ -1575,6 +1617,7 @@ def main():
                                    "upsampled x8 bilinearly (pwcnet_sfd.py:176) + 0.25 px of residual; SURVEY 8(d)'s per-pixel "
                                    "uniform [-6, 6) field (`noise`, what the parity tests use) is timed as extra.flow_noise",
                 "stack_coarse": args.stack_coarse if hybrid else 0,
+                "stack_levels": args.stack_levels,
                 "launch": ("hipGraph replay" if graph is not None else "eager") +
                           (", directions fused into one batched call" if args.fuse_directions else
                            ", %d streams (one per flow direction%s%s)" % (
