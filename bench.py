@@ -1037,6 +1037,32 @@ def hot_kernel_times(wl, labels, reps=20):
     return out
 
 
+def f2_fused_times(pairs, width, height, device, reps=20):
+    """SURVEY.md 8(f)-2 built (round 6): flow_warp + correlation + LeakyReLU as ONE forward kernel that never writes the warped
+    features (cerberus::warp_correlation_leaky) against the two tuned launches, per level of the headline's pyramid; hot, HIP
+    events.  `saved_bytes` = the warped tensor's write + read the fusion removes."""
+    from cerberusnet_amd.synth import hash_uniform, pyramid_shapes
+    ops = torch.ops.cerberus
+    out = {}
+    for l, (C, H, W) in enumerate(pyramid_shapes(width, height, 32)):
+        if l == 0:
+            continue                                     # (the coarsest level is not warped)
+        f1 = torch.from_numpy(hash_uniform((pairs, C, H, W), 1)).to(device)
+        f2 = torch.from_numpy(hash_uniform((pairs, C, H, W), 2)).to(device)
+        fl = Workload._flow(pairs, H, W, 3, "smooth", device)
+        t_f = _time_graph([lambda: ops.warp_correlation_leaky(f1, f2, fl, 1, 0.1)], reps)
+        t_u = _time_graph([lambda: ops.correlation_leaky(f1, ops.flow_warp(f2, fl, 1, 0), *CORR_P, 0.1)], reps)
+        nbytes = (2 * C + 2 + 81) * pairs * H * W * 4        # f1 + f2 + flow in, the cost volume out
+        out["L%d" % l] = {"fused_us": round(t_f * 1e6, 2), "two_launches_us": round(t_u * 1e6, 2),
+                          "algorithmic_bytes": nbytes, "fused_frac": round(nbytes / t_f / 1e9 / HBM_PEAK_GBPS, 4),
+                          "saved_bytes": 2 * C * pairs * H * W * 4}
+    out["what"] = ("cerberus::warp_correlation_leaky (warp_corr.hip: an 8 x 32 tile samples its 16 x 40 window -- 2.5 x the pixels "
+                   "of the stand-alone warp -- into LDS and correlates from there) against flow_warp + correlation_leaky, "
+                   "%d pairs, fp32, hot: the fusion loses, as DESIGN.md 3.5 priced it; opt-in (PWCNetHead(fuse_warp=True)) for "
+                   "the memory it saves in training: no warped tensor, no warp context" % pairs)
+    return out
+
+
 def short_ops_rate(pairs, width, height, dtype, device, steps=60, warmup=10, flow_kind="smooth", probe=()):
     """A short timed pass of the op-only step on another configuration (value only: no per-kernel pass):
     same graph + two-stream launch as the headline.  Used for `extra.config5_f16` of the default line so
@@ -1801,6 +1827,10 @@ def main():
                 extra_lines["ragged"] = rag
             except Exception as exc:
                 extra_lines["ragged"] = {"error": repr(exc)[:200]}
+            try:    # f2: the fused warp + correlation forward against the two tuned launches
+                extra_lines["f2_fused"] = f2_fused_times(args.pairs, args.width, args.height, device)
+            except Exception as exc:
+                extra_lines["f2_fused"] = {"error": repr(exc)[:200]}
             try:    # the loss side of the training step: pyramid, RGB warps, gradOutput from the concat buffer's gradient
                 extra_lines["loss_side"] = loss_side_times(args.pairs, args.width, args.height, device)
             except Exception as exc:

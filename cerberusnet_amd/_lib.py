@@ -11,7 +11,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # CERBERUS_HIP_LIB: another build of the same library (e.g. a -DCERB_EXPERIMENTS / -DCERB_STAMP test build)
 LIB_PATH = os.environ.get("CERBERUS_HIP_LIB") or os.path.join(_HERE, "lib", "libcerberus_hip.so")
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 _lock = threading.Lock()
 _lib = None
@@ -34,6 +34,8 @@ PROTOTYPES = {
     "cerberus_flow_warp_forward": (_I, [_P, _P, _P] + [_I] * 7 + [_P]),
     "cerberus_flow_warp_context_bytes": (_I64, [_I, _I, _I]),
     "cerberus_flow_warp_forward_ctx": (_I, [_P, _P, _P, _P, _I64] + [_I] * 8 + [_P]),
+    "cerberus_warp_correlation_workspace_bytes": (_I64, [_I, _I, _I, _I]),
+    "cerberus_warp_correlation_forward": (_I, [_P, _P, _P, _P, _P, _I64] + [_I] * 5 + [ctypes.c_float, _I64, _I, _I, _P]),
     "cerberus_flow_warp_backward_workspace_bytes": (_I64, [_I, _I, _I, _I]),
     "cerberus_flow_warp_backward": (_I, [_P, _P, _P, _P, _P, _P, _I64, _P, _I64] + [_I] * 8 + [_P]),
     "cerberus_flow_upsample_forward": (_I, [_P, _P, _I64, _I, _I, _I, _I, _P]),

@@ -20,7 +20,7 @@ LIB = os.path.join(LIBDIR, "libcerberus_hip.so")
 ARCH = "gfx950"
 # the product: dispatched code only
 SOURCES = ["api.hip", "corr_generic.hip", "corr_d4.hip", "corr_d4_bwd.hip", "corr_strip.hip", "corr_coarse.hip", "corr_mfma.hip",
-           "corr_grad_prep.hip", "warp.hip", "warp16.hip", "upsample.hip"]
+           "corr_grad_prep.hip", "warp.hip", "warp16.hip", "warp_corr.hip", "upsample.hip"]
 # lib/libcerberus_hip_experiments.so (-DCERB_EXPERIMENTS): the product's sources + the measured-and-rejected kernels that no
 # dispatch rule selects (forward variants 1, 2, 8, 17; backward 2, 6, 7, 9, 10; the two-item strip backward) -- kept for the
 # record and tested through CERBERUS_HIP_LIB (tests/test_experiments_gpu.py), never loaded by default

@@ -1,6 +1,6 @@
 // api.hip -- the extern "C" surface declared in include/cerberus_hip.h.
 // Argument validation + dispatch only; kernels live in corr_d4.hip / corr_d4_bwd.hip / corr_strip.hip / corr_coarse.hip /
-// corr_mfma.hip / corr_generic.hip, corr_grad_prep.hip, warp.hip and upsample.hip.
+// corr_mfma.hip / corr_generic.hip, corr_grad_prep.hip, warp.hip, warp16.hip, warp_corr.hip and upsample.hip.
 #include <atomic>
 #include <cstring>
 
@@ -208,6 +208,25 @@ int cerberus_flow_warp_forward_ctx(const void *image, const void *flow, void *ou
     if (!image || !flow || !out) return CERB_EINVAL;
     return warp_forward(image, flow, out, context, context_bytes, B, C, H, W, pad_mode,
                         interp_mode, dtype, flow_dtype, static_cast<hipStream_t>(stream));
+}
+
+int64_t cerberus_warp_correlation_workspace_bytes(int B, int C, int H, int W) {
+    if (B <= 0 || C <= 0 || H <= 0 || W <= 0) return 0;
+    return warp_corr_workspace_bytes(B, C, H, W);
+}
+
+int cerberus_warp_correlation_forward(const void *input1, const void *input2, const void *flow, void *output, void *workspace,
+                                      int64_t workspace_bytes, int B, int C, int H, int W, int pad_mode, float negative_slope,
+                                      int64_t out_batch_stride, int dtype, int flow_dtype, void *stream) {
+    const int rc = warp_args_ok(B, C, H, W, pad_mode, CERB_INTERP_BILINEAR, dtype);
+    if (rc) return rc;
+    if (!dtype_ok(flow_dtype)) return CERB_EDTYPE;
+    if (pad_mode == CERB_PAD_REFLECTION) return CERB_EUNSUPPORTED;   // (no reference caller; the training path could not differentiate it)
+    if (B == 0) return CERB_OK;
+    if (!input1 || !input2 || !flow || !output) return CERB_EINVAL;
+    if (out_batch_stride != 0 && out_batch_stride < static_cast<int64_t>(81) * H * W) return CERB_EINVAL;
+    return warp_corr_forward(input1, input2, flow, output, workspace, workspace_bytes, B, C, H, W, pad_mode, negative_slope,
+                             out_batch_stride, dtype, flow_dtype, static_cast<hipStream_t>(stream));
 }
 
 int64_t cerberus_flow_warp_backward_workspace_bytes(int B, int C, int H, int W) {

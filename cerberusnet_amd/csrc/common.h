@@ -195,6 +195,11 @@ int warp_backward(const void *image, const void *flow, const void *gout, void *g
 int warp16_forward(const void *image, const void *flow, void *out, void *ctx, int B, int C, int H, int W, int pad_mode,
                    int dtype, int flow_dtype, int crange_opt, hipStream_t s);
 
+// warp_corr.hip: f2 -- the warp fused into the correlation forward (d = 4)
+int64_t warp_corr_workspace_bytes(int B, int C, int H, int W);
+int warp_corr_forward(const void *f1, const void *f2, const void *flow, void *out, void *workspace, int64_t workspace_bytes, int B,
+                      int C, int H, int W, int pad_mode, float slope, int64_t out_bstride, int dtype, int flow_dtype, hipStream_t s);
+
 // upsample.hip: flow * factor -> bilinear x factor, align_corners = true (forward) / its adjoint
 int flow_upsample(bool forward, const void *src, void *dst, int64_t planes, int H, int W, int factor,
                   int dtype, hipStream_t s);

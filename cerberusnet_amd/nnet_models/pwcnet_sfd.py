@@ -60,6 +60,10 @@ class PWCNetHead(nn.Module):
         self.fuse_leaky = bool(kwargs.get("fuse_leaky", True))
         self.fuse_concat = bool(kwargs.get("fuse_concat", True))
         self.fuse_upsample = bool(kwargs.get("fuse_upsample", True))
+        # f2: warp + correlation + LeakyReLU as ONE forward kernel that never writes the warped features
+        # (torch.ops.cerberus.warp_correlation_leaky; its backward recomputes the warp).  Off by default: measured slower than
+        # the two tuned launches (bench.py extra.f2_fused); what it saves is the warped tensor and the warp context per level
+        self.fuse_warp = bool(kwargs.get("fuse_warp", False))
         self.correlation_backend = kwargs.get("correlation_backend", "hip")
         if self.correlation_backend not in ("hip", "torch"):
             raise ValueError("correlation_backend must be 'hip' or 'torch'")
@@ -116,12 +120,19 @@ class PWCNetHead(nn.Module):
         flow = coarse.new_zeros((coarse.size(0), 2, coarse.size(2), coarse.size(3)))
         flows = []
         for level, (im1, im2) in enumerate(zip(feats1, feats2)):
+            c = self.corr
+            fused = (level > 0 and self.fuse_warp and self.correlation_backend == "hip" and c.pad_size == 4 and
+                     c.max_displacement == 4 and c.kernel_size == 1 and c.stride1 == 1 and c.stride2 == 1)
             if level == 0:
                 im2_warp = im2
             else:
                 flow = self._upsample(flow, 2)
-                im2_warp = self._warp(im2, flow).type(im1.dtype)
-            if self.correlation_backend == "hip" and self.fuse_leaky and self.fuse_concat:
+                if not fused:
+                    im2_warp = self._warp(im2, flow).type(im1.dtype)
+            if fused:
+                out_corr = torch.ops.cerberus.warp_correlation_leaky(im1, im2, flow, 1, 0.1)      # pad_mode 1 = border, as flow_warp's default
+                est_in = torch.cat([out_corr, self.conv_1x1[level](im1), flow], dim=1)
+            elif self.correlation_backend == "hip" and self.fuse_leaky and self.fuse_concat:
                 c = self.corr
                 est_in = cost_volume_concat(
                     im1, im2_warp, [self.conv_1x1[level](im1), flow],

@@ -45,6 +45,7 @@ _def.define("correlation_leaky_into(Tensor(a!) buffer, Tensor input1, Tensor inp
             "%s, float negative_slope) -> ()" % _CORR_ARGS)
 _def.define("correlation_backward_leaky(Tensor input1, Tensor input2, Tensor grad_buffer, Tensor fwd_buffer, "
             "int channel_offset, %s, float negative_slope) -> Tensor[]" % _CORR_ARGS)
+_def.define("warp_correlation_leaky(Tensor input1, Tensor input2, Tensor flow, int pad_mode, float negative_slope) -> Tensor")
 _def.define("area_pyramid(Tensor image, int[] sizes) -> Tensor[]")
 _def.define("flow_upsample(Tensor flow, int factor) -> Tensor")
 _def.define("flow_upsample_backward(Tensor grad_out, int factor) -> Tensor")
@@ -406,6 +407,33 @@ def _flow_warp_backward_ctx_cuda(image, flow, context, grad_out, pad_mode, inter
 
 
 # ----------------------------------------------------------------------------
+# f2: the warp fused into the correlation forward (pwcnet_sfd.py:178 -> :181-182, d = 4)
+# ----------------------------------------------------------------------------
+def _warp_correlation_leaky_cuda(input1, input2, flow, pad_mode, negative_slope):
+    """LeakyReLU(correlation(input1, flow_warp(input2, flow))) with pad = d = 4, k = s1 = s2 = 1, without writing the
+    warped features (cerberus_warp_correlation_forward).  Opt-in: measured slower than the two tuned launches."""
+    what = "cerberus::warp_correlation_leaky"
+    _check_pair(input1, input2, what)
+    _warp_check(input2, flow, what)
+    code = _dtype_code(input1, what)
+    x1, x2 = input1.contiguous(), input2.contiguous()
+    flo = _flow_for(x2, flow)
+    B, C, H, W = x1.shape
+    out = x1.new_empty((B, 81, H, W))
+    if out.numel() == 0:
+        return out
+    lib = _lib.get()
+    ws_bytes = lib.cerberus_warp_correlation_workspace_bytes(B, C, H, W)    # small maps: fp32 volume for the split channel sum
+    ws = torch.empty((ws_bytes + 7) // 8, dtype=torch.int64, device=x1.device) if ws_bytes else None
+    with torch.cuda.device(x1.device):
+        rc = lib.cerberus_warp_correlation_forward(
+            x1.data_ptr(), x2.data_ptr(), flo.data_ptr(), out.data_ptr(), ws.data_ptr() if ws is not None else None, ws_bytes,
+            B, C, H, W, pad_mode, ctypes.c_float(float(negative_slope)), 0, code, _DTYPES[flo.dtype], _stream_ptr(x1))
+    _lib.check(rc, what)
+    return out
+
+
+# ----------------------------------------------------------------------------
 # flow upsample (pwcnet_sfd.py:176, :199-201)
 # ----------------------------------------------------------------------------
 def _flow_upsample_run(t, factor, forward, what):
@@ -524,6 +552,9 @@ _def.impl("correlation", _no_cpu("correlation"), "CPU")
 _def.impl("correlation_leaky", _correlation_leaky_cuda, "CUDA")
 _def.impl("correlation_leaky", _correlation_meta, "Meta")
 _def.impl("correlation_leaky", _no_cpu("correlation_leaky"), "CPU")
+_def.impl("warp_correlation_leaky", _warp_correlation_leaky_cuda, "CUDA")
+_def.impl("warp_correlation_leaky", lambda a, b, f, p, sl: a.new_empty((a.shape[0], 81, a.shape[2], a.shape[3])), "Meta")
+_def.impl("warp_correlation_leaky", _no_cpu("warp_correlation_leaky"), "CPU")
 _def.impl("correlation_leaky_into", _correlation_leaky_into_cuda, "CUDA")
 _def.impl("correlation_leaky_into", lambda *a: None, "Meta")
 _def.impl("correlation_leaky_into", _no_cpu("correlation_leaky_into"), "CPU")
@@ -610,6 +641,30 @@ def _warp_backward(ctx, grad):
     return (gi if need_image else None, gf.to(flow.dtype) if need_flow else None, None, None)
 
 
+def _warp_corr_setup(ctx, inputs, output):
+    input1, input2, flow, pad_mode, slope = inputs
+    # f2's point in training: neither the warped features nor the warp's context are kept -- only the three inputs and the
+    # (81-channel) result, whose sign carries the LeakyReLU derivative
+    ctx.save_for_backward(input1, input2, flow, output)
+    ctx.pad_mode, ctx.slope = pad_mode, slope
+
+
+def _warp_corr_backward(ctx, grad):
+    input1, input2, flow, output = ctx.saved_tensors
+    bil = INTERP_MODES["bilinear"]
+    # recompute the warp (the tuned kernels, with its context), then the tuned correlation and warp backward
+    warped, context = torch.ops.cerberus.flow_warp_ctx(input2, flow, ctx.pad_mode, bil)
+    g1, gw = torch.ops.cerberus.correlation_backward_leaky(input1, warped, grad, output, 0, 4, 1, 4, 1, 1, 1, ctx.slope)
+    need_image, need_flow = ctx.needs_input_grad[1], ctx.needs_input_grad[2]
+    g2 = gf = None
+    if need_image or need_flow:
+        gi, gfl = torch.ops.cerberus.flow_warp_backward_ctx(input2, flow, context, gw, ctx.pad_mode, bil, need_image, need_flow)
+        g2 = gi if need_image else None
+        gf = gfl.to(flow.dtype) if need_flow else None
+    return g1, g2, gf, None, None
+
+
+torch.library.register_autograd("cerberus::warp_correlation_leaky", _warp_corr_backward, setup_context=_warp_corr_setup)
 torch.library.register_autograd("cerberus::correlation", _corr_backward,
                                 setup_context=_corr_setup)
 torch.library.register_autograd("cerberus::correlation_leaky", _corr_leaky_backward,

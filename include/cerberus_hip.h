@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define CERBERUS_HIP_ABI_VERSION 6   /* 6: cerberus_correlation_backward_ex, cerberus_area_pyramid, option warp_fewc (round 5) */
+#define CERBERUS_HIP_ABI_VERSION 7   /* 7: cerberus_warp_correlation_forward (f2), option warp_pair16 (round 6); 6: cerberus_correlation_backward_ex, cerberus_area_pyramid, option warp_fewc (round 5) */
 
 /* element types (AT_DISPATCH_FLOATING_TYPES_AND_HALF in the reference,
  * correlation_cuda_kernel.cu:269,303; bf16 is an extension) */
@@ -157,6 +157,27 @@ int cerberus_flow_warp_forward_ctx(const void *image, const void *flow, void *ou
                                    void *context, int64_t context_bytes, int B, int C,
                                    int H, int W, int pad_mode, int interp_mode,
                                    int dtype, int flow_dtype, void *stream);
+
+/* f2 of SURVEY.md section 8(f): flow_warp FUSED into the correlation forward -- what the reference's head computes at
+ * nnet_models/pwcnet_sfd.py:178 -> :181-182 with pad_size = max_displacement = 4, kernel_size = stride1 = stride2 = 1:
+ *   output[b][(dy+4)*9 + (dx+4)][y][x] = leaky( mean_c input1[b][c][y][x] * warped[b][c][y+dy][x+dx] ),
+ *   warped = flow_warp(input2, flow, pad_mode, bilinear), zero outside the image,
+ * without ever writing `warped` (no round trip, nothing to save for the backward: the training path recomputes the warp).
+ * Same arithmetic as the two stand-alone calls (the warp's coordinate rounding order; a 16-bit warped value is rounded through
+ * the storage type as the stand-alone warp's output is); the channel sum runs in another order (fp32 rounding).
+ *   input1, input2 : (B,C,H,W), dtype (CERB_F32 / F16 / BF16);  flow : (B,2,H,W), flow_dtype (= dtype, or CERB_F32)
+ *   output         : (B,81,H,W), dtype; batch stride out_batch_stride elements (0 = dense) as in cerberus_correlation_forward_ex
+ *   negative_slope : LeakyReLU slope applied to the result (1.0f = none)
+ *   workspace      : caller-owned device scratch of cerberus_warp_correlation_workspace_bytes(B,C,H,W) bytes (4-byte aligned,
+ *                    contents irrelevant), or NULL.  Only small maps need it (fewer than 256 tiles of 8 x 32 pixels: the channel
+ *                    sum is then split over several workgroups per tile, summed with float atomics in an fp32 volume and
+ *                    finished by a second launch: results agree to fp32 rounding run to run, not bit for bit); without it
+ *                    such a map takes the one-launch form (bit-reproducible, few workgroups).
+ * Built in round 6 so that the row exists as code; measured SLOWER than the two tuned launches (bench.py extra.f2_fused): opt-in. */
+int64_t cerberus_warp_correlation_workspace_bytes(int B, int C, int H, int W);
+int cerberus_warp_correlation_forward(const void *input1, const void *input2, const void *flow, void *output, void *workspace,
+                                      int64_t workspace_bytes, int B, int C, int H, int W, int pad_mode, float negative_slope,
+                                      int64_t out_batch_stride, int dtype, int flow_dtype, void *stream);
 
 /* flow_warp backward (autograd of the above w.r.t. image and flow).
  *   grad_image : (B,C,H,W), dtype -- fully overwritten.  With a context or a workspace

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     for name in names:
         assert hasattr(lib, name), name
     assert sorted(_lib.PROTOTYPES) == names  # binding covers the header exactly
-    assert _lib.get().cerberus_abi_version() == _lib.ABI_VERSION == 6
+    assert _lib.get().cerberus_abi_version() == _lib.ABI_VERSION == 7
 
 
 def test_out_shape_matches_reference_rules():

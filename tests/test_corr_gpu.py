@@ -1326,3 +1326,71 @@ def test_concat_buffer_written_in_place_before_backward_raises():
     buf.sum().backward()                       # only `other` needs a gradient
     assert torch.equal(other.grad, torch.ones_like(other))
     assert _lib.last_kernel(1) == before       # no correlation backward was launched
+
+
+# ---- round 6: f2, the warp fused into the correlation forward (warp_corr.hip) ---------------------------------------
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, TOL), (torch.float16, 2e-3), (torch.bfloat16, 1.6e-2)])
+@pytest.mark.parametrize("shape,amp", [((2, 32, 16, 24), 3.0), ((1, 12, 9, 37), 0.7), ((2, 7, 20, 70), 9.0), ((1, 64, 33, 64), 40.0),
+                                       ((1, 3, 5, 4), 2.0)])
+@pytest.mark.parametrize("pad", ["border", "zeros"])
+def test_fused_warp_correlation_equals_the_two_stand_alone_ops(shape, amp, pad, dtype, tol):
+    """SURVEY 8(f)-2: cerberus::warp_correlation_leaky against the oracle's composition (flow_warp_ref -> corr_forward_ref ->
+    LeakyReLU) and against this package's own two kernels; ragged tiles, flows from sub-pixel to larger than the image, both
+    padding modes, an fp32 flow beside 16-bit features."""
+    B, C, H, W = shape
+    x1, x2 = hash_uniform(shape, 461), hash_uniform(shape, 462)
+    flo = hash_uniform((B, 2, H, W), 463, -amp, amp)
+    a, b, f = dev(x1).to(dtype), dev(x2).to(dtype), dev(flo)
+    pm = {"zeros": 0, "border": 1}[pad]
+    fused = torch.ops.cerberus.warp_correlation_leaky(a, b, f, pm, 0.1)
+    assert _lib.last_kernel(0) == "warp_corr_fwd_8x32"
+    warped = torch.ops.cerberus.flow_warp(b, f, pm, 0)
+    two = torch.ops.cerberus.correlation_leaky(a, warped, 4, 1, 4, 1, 1, 1, 0.1)
+    assert rel_err(fused.float().cpu().numpy(), two.float().cpu().numpy()) < tol
+    if dtype == torch.float32:
+        w_ref = oracle.flow_warp_ref(torch.from_numpy(x2), torch.from_numpy(flo), pad).numpy()
+        ref = oracle.corr_forward_ref(x1, w_ref, 4, 1, 4, 1, 1)
+        ref = np.where(ref > 0, ref, ref * np.float32(0.1))
+        assert rel_err(fused.cpu().numpy(), ref) < TOL
+
+
+def test_fused_warp_correlation_backward_recomputes_the_warp():
+    """The training path of f2 saves neither the warped features nor the warp context: its backward recomputes the warp
+    and runs the tuned backward kernels -- gradients w.r.t. both feature maps and the flow equal those of the unfused chain
+    bit for bit (the same kernels on the same values)."""
+    shape = (2, 32, 24, 64)
+    x1 = dev(hash_uniform(shape, 471)).requires_grad_(True)
+    x2 = dev(hash_uniform(shape, 472)).requires_grad_(True)
+    fl = dev(hash_uniform((2, 2, 24, 64), 473, -3.0, 3.0)).requires_grad_(True)
+    go = dev(hash_uniform((2, 81, 24, 64), 474))
+    out = torch.ops.cerberus.warp_correlation_leaky(x1, x2, fl, 1, 0.1)
+    g1, g2, gf = torch.autograd.grad(out, (x1, x2, fl), go)
+    from cerberusnet_amd.loss_functions.UnFlowLoss import flow_warp
+    ref = torch.ops.cerberus.correlation_leaky(x1, flow_warp(x2, fl), 4, 1, 4, 1, 1, 1, 0.1)
+    r1, r2, rf = torch.autograd.grad(ref, (x1, x2, fl), go)
+    assert rel_err(out.detach().cpu().numpy(), ref.detach().cpu().numpy()) < TOL
+    # (the LeakyReLU mask comes from the stored result's sign: identical wherever the two forwards agree in sign, i.e.
+    # everywhere but at values within rounding of zero)
+    for a, b in ((g1, r1), (g2, r2), (gf, rf)):
+        assert rel_err(a.cpu().numpy(), b.cpu().numpy()) < 1e-4
+
+
+@pytest.mark.parametrize("shape", [(4, 128, 32, 64), (1, 256, 16, 32), (2, 64, 24, 40)])
+def test_fused_warp_correlation_on_small_maps_splits_the_channel_sum(shape):
+    """Fewer than 256 tiles: several workgroups per tile sum channel slices into an fp32 volume (float atomics) and a second
+    launch finishes it; with no workspace the same call takes the one-launch form.  Both against the two stand-alone ops."""
+    import ctypes
+    B, C, H, W = shape
+    a, b = dev(hash_uniform(shape, 481)), dev(hash_uniform(shape, 482))
+    f = dev(hash_uniform((B, 2, H, W), 483, -2.0, 2.0))
+    lib = _lib.get()
+    assert lib.cerberus_warp_correlation_workspace_bytes(B, C, H, W) == B * 81 * H * W * 4
+    assert lib.cerberus_warp_correlation_workspace_bytes(4, 32, 128, 256) == 0
+    two = torch.ops.cerberus.correlation_leaky(a, torch.ops.cerberus.flow_warp(b, f, 1, 0), 4, 1, 4, 1, 1, 1, 0.1)
+    fused = torch.ops.cerberus.warp_correlation_leaky(a, b, f, 1, 0.1)
+    assert rel_err(fused.cpu().numpy(), two.cpu().numpy()) < TOL
+    out = torch.empty_like(two)
+    rc = lib.cerberus_warp_correlation_forward(a.data_ptr(), b.data_ptr(), f.data_ptr(), out.data_ptr(), None, 0, B, C, H, W, 1,
+                                               ctypes.c_float(0.1), 0, 0, 0, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    assert rc == 0 and rel_err(out.cpu().numpy(), two.cpu().numpy()) < TOL

@@ -38,6 +38,26 @@ def test_hip_head_matches_reference_goldens(golden, est, tag, fuse):
     assert np.allclose(norms, g["param_grad_norms"], rtol=2e-3, atol=1e-9)
 
 
+@pytest.mark.parametrize("est,tag", [("FlowEstimatorLite", "lite")])
+def test_hip_head_with_the_fused_warp_correlation_matches_reference_goldens(golden, est, tag):
+    """f2 inside the head (fuse_warp=True: warp + correlation + LeakyReLU as one forward kernel per level, the backward
+    recomputing the warp) against the REFERENCE head's goldens: flows, loss, input and parameter gradients."""
+    g = golden("pwchead_" + tag)
+    head = build(est, fuse_warp=True).to(DEV)
+    p1, p2 = pyramids(g, DEV)
+    flows = head((None, p1), (None, p2))
+    for i, f in enumerate(flows):
+        assert rel_err(f.detach().cpu().numpy(), g["flow_%d" % i]) < 1e-4
+    loss = sum((f * f).mean() for f in flows)
+    assert abs(loss.item() - float(g["loss"])) < 1e-4 * abs(float(g["loss"]))
+    grads = torch.autograd.grad(loss, p1 + p2 + list(head.parameters()))
+    for l in range(4):
+        assert l2_err(grads[l].cpu().numpy(), g["g_im1_%d" % l]) < 2e-3
+        assert l2_err(grads[4 + l].cpu().numpy(), g["g_im2_%d" % l]) < 2e-3
+    norms = np.array([float(x.double().norm()) for x in grads[8:]])
+    assert np.allclose(norms, g["param_grad_norms"], rtol=2e-3, atol=1e-9)
+
+
 def test_hip_and_torch_backends_agree_on_device(golden):
     g = golden("pwchead_lite")
     res = {}
