@@ -634,9 +634,10 @@ def cpu_baseline(levels, budget_s=20.0):
     # on the 256-core GPU box): probe a few thread counts on one image pair and use the best
     default_threads = torch.get_num_threads()
     ncpu = os.cpu_count() or 1
+    usable, usable_how = usable_cores()
     probe = {}
-    for th in sorted({default_threads, 32, 16, 8}):
-        if th > ncpu:
+    for th in sorted({min(default_threads, 2 * usable), usable, 32, 16, 8}):
+        if th > ncpu or th > 2 * usable:
             continue
         torch.set_num_threads(th)
         for name, _ in shapes[1:]:
@@ -663,8 +664,8 @@ def cpu_baseline(levels, budget_s=20.0):
             row[what + "_ms_median"] = round(1e3 * float(np.median(ts)), 3)
             row[what + "_iters"] = len(ts)
         table[name] = row
-    # for the record: the config-1 forward with torch's default of one thread per host core (skipped on many-core hosts,
-    # where the all-cores child below says the same thing within its time budget)
+    # for the record: the config-1 forward with torch's default of one thread per visible core (skipped where the
+    # visible cores exceed the ones this process may run on: see usable_cores())
     all_cores_ms = None
     if ncpu <= 32:
         torch.set_num_threads(ncpu)
@@ -672,14 +673,15 @@ def cpu_baseline(levels, budget_s=20.0):
         t0 = time.perf_counter()
         fwd(shapes[0][0])
         all_cores_ms = round(1e3 * (time.perf_counter() - t0), 3)
-    # BASELINE.md section 4 as written: torch.set_num_threads(all host cores), forward + backward on the four levels.  On a
-    # many-core host that is far slower than the probed thread count (thread fan-out on small maps: 19.8 s for ONE config-1
-    # forward on 256 cores), so it runs in a CHILD process with a hard deadline: the levels it finished are measured, the
-    # rest are scaled from the probed-thread medians by the ratio seen on the finished ones (stated per level).
-    # (256 threads: ~50 s per fwd + bwd of ANY level -- the cost is the fork / join of ~500 small parallel regions, not the
-    # tensor size -- so on such a host the deadline lets the smallest level finish once or twice and the rest is scaled)
-    all_budget = max(6.0, budget_s) if ncpu <= 64 else 100.0
-    all_table, all_note = _cpu_all_cores_child(levels, all_budget)
+    # BASELINE.md section 4 as written: torch.set_num_threads(all host cores), forward + backward on the four levels.
+    # "All host cores" = the cores this process may RUN on: the GPU boxes show 256 logical CPUs to os.cpu_count() and to
+    # sched_getaffinity, but their cgroup grants 16 CPUs of time (cpu.max = 1600000 100000) -- 256 compute threads under
+    # that quota are throttled to a crawl (rounds 5 / 6 measured 19.8 s for ONE config-1 forward, ~50 s per fwd + bwd of
+    # any level; cpu.stat's nr_throttled counts it), which is a property of the container, not of the baseline.  The
+    # pass runs in a CHILD process with a hard deadline (a torch CPU op cannot be interrupted from inside): the levels it
+    # finished are measured, any rest is scaled from the probed-thread medians by the ratio seen on the finished ones.
+    all_budget = max(6.0, budget_s)
+    all_table, all_note = _cpu_all_cores_child(levels, all_budget, usable)
     done = [k for k, v in all_table.items() if v.get("iters")]
     ratio = (sum(all_table[k]["fwd_bwd_ms_median"] for k in done) / sum(table[k]["fwd_bwd_ms_median"] for k in done)) if done else None
     for l in range(len(levels)):
@@ -693,12 +695,12 @@ def cpu_baseline(levels, budget_s=20.0):
     pair_s = 2 * sum(table["L%d" % l]["fwd_bwd_ms_median"] for l in range(len(levels))) * 1e-3
     return {"value": round(1.0 / pair_s, 4), "unit": "image-pairs/s", "cores": threads, "kind": "port",
             "host_cores": ncpu, "per_shape_ms": table,
-            "value_all_cores": round(1.0 / all_pair_s, 4) if all_pair_s else None, "cores_all": ncpu,
-            "all_cores": {"per_shape_ms": all_table,
-                          "what": "BASELINE.md section 4 as specified: torch.set_num_threads(%d) = every host core, fwd + "
-                                  "autograd bwd on the four level shapes (smallest first), 1 warm-up + up to 3 timed iterations "
-                                  "per level in a child process stopped after %.0f s; %s; `value` / `cores` beside it is the "
-                                  "best thread count of a probe" % (ncpu, all_budget, all_note)},
+            "value_all_cores": round(1.0 / all_pair_s, 4) if all_pair_s else None, "cores_all": usable,
+            "all_cores": {"per_shape_ms": all_table, "usable_cores": usable_how,
+                          "what": "BASELINE.md section 4 as specified: torch.set_num_threads(%d) = every core this process may "
+                                  "run on (%s), fwd + autograd bwd on the four level shapes (smallest first), 1 warm-up + up to 3 "
+                                  "timed iterations per level in a child process stopped after %.0f s; %s; `value` / `cores` "
+                                  "beside it is the best thread count of a probe" % (usable, usable_how, all_budget, all_note)},
             "config1_fwd_ms_with_all_%d_cores" % ncpu: all_cores_ms,
             "sample": "CorrelationTorch semantics on torch CPU, B=1: config-1 tensor + the 4 level shapes, "
                       "3 warm-ups + up to 10 timed iterations each of fwd and fwd+autograd bwd (min / median "
@@ -707,7 +709,41 @@ def cpu_baseline(levels, budget_s=20.0):
                       % (threads, sorted(probe), ncpu, time.perf_counter() - t_start)}
 
 
-def _cpu_all_cores_child(levels, budget_s):
+def usable_cores():
+    """(n, how): the CPUs this process may actually run on = min(visible CPUs, scheduler affinity, the cgroup's CPU-time
+    quota).  os.cpu_count() alone reports the machine (256 on the GPU boxes), not the container's share (16 there)."""
+    n = os.cpu_count() or 1
+    how = ["os.cpu_count() = %d" % n]
+    try:
+        a = len(os.sched_getaffinity(0))
+        how.append("affinity = %d" % a)
+        n = min(n, a)
+    except (AttributeError, OSError):
+        pass
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:                       # cgroup v2
+            q, per = f.read().split()[:2]
+            if q != "max":
+                quota = float(q) / float(per)
+                how.append("cgroup cpu.max = %s %s" % (q, per))
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:      # cgroup v1
+                q = int(f.read())
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                per = int(f.read())
+            if q > 0:
+                quota = q / per
+                how.append("cgroup cfs quota = %d / %d" % (q, per))
+        except (OSError, ValueError):
+            pass
+    if quota:
+        n = min(n, max(1, int(-(-quota // 1))))
+    return n, ", ".join(how)
+
+
+def _cpu_all_cores_child(levels, budget_s, threads):
     """The all-host-cores pass of cpu_baseline() in a child process with a hard deadline (a torch CPU op cannot be
     interrupted from inside).  Returns ({level: {fwd_bwd_ms_median, iters}}, note)."""
     import subprocess
@@ -716,7 +752,7 @@ def _cpu_all_cores_child(levels, budget_s):
             "import numpy as np, torch\n"
             "from oracle import correlation_torch_ref\n"
             "from cerberusnet_amd.synth import hash_uniform\n"
-            "torch.set_num_threads(os.cpu_count() or 1)\n"
+            "torch.set_num_threads(%d)\n"
             "for l, (C, H, W) in enumerate(%r):\n"
             "    x1 = torch.from_numpy(hash_uniform((1, C, H, W), 4 * (l + 1))).requires_grad_(True)\n"
             "    x2 = torch.from_numpy(hash_uniform((1, C, H, W), 4 * (l + 1) + 1)).requires_grad_(True)\n"
@@ -725,7 +761,7 @@ def _cpu_all_cores_child(levels, budget_s):
             "        t0 = time.perf_counter()\n"
             "        torch.autograd.grad(correlation_torch_ref(x1, x2, 4), (x1, x2), go)\n"
             "        print(json.dumps({'level': l, 'iter': it, 'ms': 1e3 * (time.perf_counter() - t0)}), flush=True)\n"
-            % (REPO, [list(s) for s in levels]))
+            % (REPO, threads, [list(s) for s in levels]))
     env = {k: v for k, v in os.environ.items() if not _is_profiler_variable(k) and k not in ("OMP_NUM_THREADS", "MKL_NUM_THREADS")}
     env["CUDA_VISIBLE_DEVICES"] = ""            # CPU work only: the child never touches the GPU
     env["HIP_VISIBLE_DEVICES"] = ""
