@@ -706,9 +706,9 @@ __global__ __launch_bounds__(BwdSegCfg::THREADS, 2) void corr_bwd_d4_mfma_seg_ke
 // prefetched -- was measured and dropped: 32x256x512 55.6 -> 53.5 us, but 32x128x256 16.4 -> 18.2
 // and 64x64x128 9.7 -> 11.3: the forward's traffic is dominated by its 81-plane output, not by
 // the window halo.)
-template <int NKB_, int DS_ = (NKB_ == 4 ? 3 : 2)>
+template <int NKB_, int DS_ = (NKB_ == 4 ? 3 : 2), int NSEG_ = 4 / NKB_>
 struct FwdMfmaCfg {
-    static constexpr int NKB = NKB_, NSEG = 4 / NKB, TW = 16 * NSEG, TH = 4;
+    static constexpr int NKB = NKB_, NSEG = NSEG_, TW = 16 * NSEG, TH = 4;
     static constexpr int PIXB = 64 * NKB;                      // bytes per pixel (all channels)
     static constexpr int WR = TH + 2 * kD, WCOL = TW + 2 * kD; // window rows / columns
     static constexpr int GRP = 4 * PIXB + 16;                  // 4 pixels + 16 bytes: see pix()
@@ -725,6 +725,7 @@ struct FwdMfmaCfg {
     static constexpr int DPW = (kND + DS - 1) / DS;            // vertical displacements per wave
     static constexpr int THREADS = 64 * TH * DS;
     static constexpr size_t LDS_BYTES = WIN_B + (X1_B > TH * DS * T_B ? X1_B : TH * DS * T_B);   // the T tiles reuse the x1 tile's LDS
+    static constexpr int MINB = NKB == 4 ? 1 : (3 * LDS_BYTES <= 160 * 1024 && 3 * THREADS <= 2048) ? 3 : 2;   // workgroups per CU
     static_assert(NKB == 1 || NKB == 2 || NKB == 4, "channel blocks");
     // Byte offset, inside a row, of 16-byte chunk ci (8 channels) of the pixel at column col.
     // Two access patterns must both spread over the banks: the operand reads (16 lanes = 16
@@ -738,7 +739,7 @@ struct FwdMfmaCfg {
 };
 
 template <typename K, typename T>
-__global__ __launch_bounds__(K::THREADS, K::NKB == 4 ? 1 : 2) void corr_fwd_d4_mfma_kernel(
+__global__ __launch_bounds__(K::THREADS, K::MINB) void corr_fwd_d4_mfma_kernel(
     const T *__restrict__ x1, const T *__restrict__ x2, T *__restrict__ out, int C, int H, int W,
     int tiles_x, int tiles_y, float slope, int64_t out_bstride, int dbg) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -895,6 +896,496 @@ __global__ __launch_bounds__(K::THREADS, K::NKB == 4 ? 1 : 2) void corr_fwd_d4_m
 #endif
 }
 
+// ---- forward, second form (round 6): the tiles as they lie in memory + the transposing LDS read -------------------------
+// corr_fwd_d4_mfma_kernel above spends 20 of its 52 us (32 x 256 x 512, 4 pairs) bringing the tiles into LDS pixel-major:
+// 20 loads per thread into registers, 4 x 4 transposes (v_perm), 80 ds_write_b64 per thread with the bank conflicts of a
+// transposing write (SQ_LDS_BANK_CONFLICT: half of all LDS cycles of the launch).  gfx950 has the transposition in the LDS
+// READ: ds_read_b64_tr_b16 hands each lane of a 16-lane group one COLUMN of a 4-row x 16-column block of 16-bit values.
+// With rows = channels and columns = pixels that is an MFMA operand (a lane's k = consecutive channels of ITS pixel)
+// straight from NCHW rows -- so the tiles enter LDS as they lie in memory, by LDS-DMA (buffer_load_dwordx4 ... lds: no
+// registers, no VALU, no ds_write), in 16-byte cells of 8 pixels:
+//   window : [32 channel slots][12 rows][9 cells], the first cell at column x0 - 4; slot stride 1760 B
+//   x1 tile: [32 channel slots][ 4 rows][8 cells]; slot stride 544 B
+// * Same operands as the first form: a lane's k = 8 kg + e is channel 8 kg + e (two transposing reads: e = 0..3, 4..7),
+//   same MFMAs, same T tile, same stores -- identical bits (test).
+// * Banks: the 32 lanes of a half read 8 channels x 32 B; (a / 4) mod 64 makes that conflict-free when the 8 channels start
+//   in different 32-byte eighths of a 256-byte bank row.  A half's channels are {0-3, 8-11} (or + 4, + 16, + 20): channel c
+//   lives in SLOT c with bits 2 and 3 swapped, and the slot stride is an odd number of 32-byte units.
+// * A cell is copied whole (inside the image), arrives as zeros (outside: an out-of-range offset -- the zero padding), or
+//   -- the cell that holds column 0 or W of a border tile (cells start at 4 mod 8) -- is left to a fix-up pass: its lanes
+//   are masked out of the copy and a thread writes its inside half + zeros.  W % 8 == 0 (else: the first form).
+// * T tile: row pitch 69 floats (5 mod 8, odd): the (up to) 32 lanes of a half that write a wanted entry hit 32
+//   different banks (pitch 65: lanes kg = 0 and kg = 1 of one column met on one bank); lanes without one all write ONE
+//   dump slot per segment (one address: no conflict among them).
+template <int DS_ = 2>
+struct FwdTrCfg {
+    static constexpr int TW = 64, TH = 4, NSEG = TW / 16, DS = DS_, NCH = 32;
+    static constexpr int WR = TH + 2 * kD;                            // window rows
+    static constexpr int WCELL = (TW + 2 * kD) / 8, WPITCH = WCELL * 16;   // 9 cells = 144 B per window row
+    static constexpr int CSLOT = WR * WPITCH + 32;                    // 1760 B: 55 units of 32 B
+    static constexpr int XCELL = TW / 8, XPITCH = XCELL * 16;         // 8 cells = 128 B per x1 row
+    static constexpr int XSLOT = TH * XPITCH + 32;                    // 544 B: 17 units
+    static constexpr int WIN_B = NCH * CSLOT, X1_B = NCH * XSLOT;
+    static constexpr int WIN_INST = WIN_B / 1024, X1_INST = X1_B / 1024, NDMA = WIN_INST + X1_INST;   // 55 + 17 copy instructions
+    static constexpr int TP = 69, T_B = (kND * TP + 52) * 4;          // + the slots (one per segment) the lanes without a wanted entry write
+    static constexpr int DPW = (kND + DS - 1) / DS;
+    static constexpr int THREADS = 64 * TH * DS;
+    static constexpr size_t LDS_BYTES = WIN_B + (X1_B > TH * DS * T_B ? X1_B : TH * DS * T_B);
+    static_assert(WIN_B % 1024 == 0 && X1_B % 1024 == 0, "whole copy instructions");
+    static_assert((CSLOT / 32) % 2 == 1 && (XSLOT / 32) % 2 == 1, "odd slot strides");
+    static_assert(2 * LDS_BYTES <= 160 * 1024, "two workgroups per CU");
+};
+
+typedef short s4v __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) s4v *lds_s4v_ptr;
+typedef __attribute__((address_space(3))) void *lds_dma_ptr;
+// 8 channels x this lane's pixel: the two transposing reads (channels 8 kg + 0..3 at `p`, 8 kg + 4..7 at `p + hi`)
+__device__ __forceinline__ u4v tr_operand(const unsigned char *p, int hi) {
+    const u2v lo = __builtin_bit_cast(u2v, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v_ptr)(p)));
+    const u2v up = __builtin_bit_cast(u2v, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v_ptr)(p + hi)));
+    return u4v{lo.x, lo.y, up.x, up.y};
+}
+
+template <typename K, typename T>
+__global__ __launch_bounds__(K::THREADS, 2) void corr_fwd_d4_mfma_tr_kernel(
+    const T *__restrict__ x1, const T *__restrict__ x2, T *__restrict__ out, int C, int H, int W,
+    int tiles_x, int tiles_y, float slope, int64_t out_bstride, int dbg) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#ifndef CERB_ABLATE
+    dbg = 0;
+#endif
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    unsigned char *win = lds, *x1t = lds + K::WIN_B;
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+
+    int bid = xcd_chunk(blockIdx.x, gridDim.x);
+    const int tx = __builtin_amdgcn_readfirstlane(bid % tiles_x); bid /= tiles_x;
+    const int ty = __builtin_amdgcn_readfirstlane(bid % tiles_y);
+    const int b = __builtin_amdgcn_readfirstlane(bid / tiles_y);
+    const int x0 = tx * K::TW, y0 = ty * K::TH;
+    const int plane = H * W;
+    const __amdgpu_buffer_rsrc_t r1 = uniform_rsrc(x1 + static_cast<int64_t>(b) * C * plane, C * plane * 2);
+    const __amdgpu_buffer_rsrc_t r2 = uniform_rsrc(x2 + static_cast<int64_t>(b) * C * plane, C * plane * 2);
+    auto channel_of = [](int slot) { return (slot & 0x13) | ((slot & 4) << 1) | ((slot & 8) >> 1); };   // (its own inverse)
+
+    // ---- global -> LDS: copy instruction k fills bytes 1024 k .. 1024 k + 1023; lane l owns cell 64 k + l ----
+    {
+        constexpr int NW = K::THREADS / 64;
+#pragma unroll
+        for (int i = 0; i < (K::NDMA + NW - 1) / NW; ++i) {
+            const int k = wave + NW * i;                       // (uniform)
+            if (k >= K::NDMA || (dbg & 1)) break;
+            const bool isw = k < K::WIN_INST;
+            int slot, row, col, gy, gx;
+            bool real;
+            if (isw) {
+                const int cell = 64 * k + lane;
+                slot = cell / (K::CSLOT / 16);
+                const int r = cell - slot * (K::CSLOT / 16);
+                real = r < K::WR * K::WCELL;
+                row = r / K::WCELL; col = r - row * K::WCELL;
+                gy = y0 - kD + row; gx = x0 - kD + 8 * col;
+            } else {
+                const int cell = 64 * (k - K::WIN_INST) + lane;
+                slot = cell / (K::XSLOT / 16);
+                const int r = cell - slot * (K::XSLOT / 16);
+                real = r < K::TH * K::XCELL;
+                row = r / K::XCELL; col = r - row * K::XCELL;
+                gy = y0 + row; gx = x0 + 8 * col;
+            }
+            const int ch = channel_of(slot);
+            const bool rowok = real && ch < C && gy >= 0 && gy < H;
+            const bool inside = rowok && gx >= 0 && gx + 8 <= W;
+            const bool straddle = rowok && !inside && gx + 8 > 0 && gx < W;   // an image edge inside the cell: the fix-up's
+            const int voff = inside ? (ch * plane + gy * W + gx) * 2 : kDead;
+            if (!straddle)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(isw ? r2 : r1, (lds_dma_ptr)(lds + k * 1024), 16, voff, 0, 0, 0);
+        }
+        // border tiles: the window cell that holds column 0 (side 0) or column W (side 1) of each row and channel
+        if ((x0 == 0 || x0 + K::TW + kD > W) && !(dbg & 1)) {
+            for (int it = tid; it < 2 * K::NCH * K::WR; it += K::THREADS) {
+                const int side = it / (K::NCH * K::WR), rem = it - side * (K::NCH * K::WR);
+                const int slot = rem / K::WR, row = rem - slot * K::WR;
+                const int ch = channel_of(slot), gy = y0 - kD + row;
+                const int col = side == 0 ? 0 : (W - x0) >> 3;
+                const int gx = x0 - kD + 8 * col;
+                const bool has = side == 0 ? x0 == 0 : (col < K::WCELL && gx < W && gx + 8 > W);
+                if (has && ch < C && gy >= 0 && gy < H) {
+                    const u2v d = __builtin_amdgcn_raw_buffer_load_b64(r2, (ch * plane + gy * W + (side == 0 ? 0 : gx)) * 2, 0, 0);
+                    *reinterpret_cast<u4v *>(win + slot * K::CSLOT + row * K::WPITCH + col * 16) =
+                        side == 0 ? u4v{0u, 0u, d.x, d.y} : u4v{d.x, d.y, 0u, 0u};
+                }
+            }
+        }
+    }
+    __syncthreads();   // (waits for this wave's copies: vmcnt(0), then the barrier)
+
+    // ---- this wave's row ----
+    const int p = lane & 15, kg = lane >> 4;
+    const int row = wave % K::TH, part = wave / K::TH;   // (uniform: wave is)
+    const int y = y0 + row;
+    // lane 4 q + r of a 16-lane group addresses row q (channel 8 kg + q -> slot q + 4 (kg & 1) + 16 (kg >> 1); + 8: channels + 4),
+    // columns 4 r .. 4 r + 3 of the block
+    const int slot0 = (p >> 2) + 4 * (kg & 1) + 16 * (kg >> 1);
+    u4v a[K::NSEG];
+    {
+        const unsigned char *xa = x1t + slot0 * K::XSLOT + row * K::XPITCH + 8 * (p & 3);
+#pragma unroll
+        for (int s = 0; s < K::NSEG; ++s) a[s] = tr_operand(xa + 32 * s, 8 * K::XSLOT);
+    }
+    __syncthreads();   // every wave holds its x1 operands in registers: the tile's LDS becomes the T tiles
+    float *tt = reinterpret_cast<float *>(x1t + wave * K::T_B);
+    const float inv_nelems = 1.0f / static_cast<float>(C);
+    const int64_t obs = out_bstride ? out_bstride : static_cast<int64_t>(kND * kND) * plane;
+    const __amdgpu_buffer_rsrc_t ro = uniform_rsrc(out + b * obs, kND * kND * plane * 2);
+    // D[m][q]: a lane holds q = p and m = 4 kg + j; dx = q - m - 4 + 8 h.  Block 0 serves the pixels m < 8 (lanes kg < 2),
+    // block 1 the pixels m >= 8, and then dx + 4 = p - 4 (kg & 1) - j for both (see the first form)
+    const bool low = kg < 2;
+    int t_slot[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int dxi = p - 4 * (kg & 1) - j;
+        t_slot[j] = (dxi >= 0 && dxi < kND) ? dxi * K::TP + 4 * kg + j : kND * K::TP;   // (+ 16 s below)
+    }
+    const int st_voff = (y < H && x0 + lane < W) ? (y * W + x0 + lane) * 2 : kDead;
+    const unsigned char *wb = win + slot0 * K::CSLOT + row * K::WPITCH + 8 * (p & 3);
+#pragma unroll 1
+    for (int dyi = part * K::DPW; dyi < min(kND, (part + 1) * K::DPW); ++dyi) {
+        const unsigned char *wrow = wb + dyi * K::WPITCH;
+        f4v acc[K::NSEG][2];
+#pragma unroll
+        for (int s = 0; s < K::NSEG; ++s)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const u4v bv = tr_operand(wrow + (16 * s + 8 * h) * 2, 8 * K::CSLOT);
+                acc[s][h] = Mma<T>::run(a[s], bv, f4v{0.f, 0.f, 0.f, 0.f});
+            }
+        if (dbg & 4) {   // no T tile, no stores: one store keeps the MFMAs alive
+            if (dyi == min(kND, (part + 1) * K::DPW) - 1 && acc[0][0][0] + acc[K::NSEG - 1][1][3] == 123.f) tt[0] = 1.f;
+            continue;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int s = 0; s < K::NSEG; ++s)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                tt[t_slot[j] + 16 * s] = low ? acc[s][0][j] : acc[s][1][j];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (dbg & 8) continue;   // no read-back, no stores
+        // whole plane rows: lane = pixel; scale, LeakyReLU, one rounding
+#pragma unroll
+        for (int dxi = 0; dxi < kND; ++dxi) {
+            const float q = tt[dxi * K::TP + lane] * inv_nelems;
+            const float v = q > 0.f ? q : q * slope;
+            const unsigned short bits = static_cast<unsigned short>(Mma<T>::pack2(v, v));
+            __builtin_amdgcn_raw_buffer_store_b16(bits, ro, st_voff,
+                                                  __builtin_amdgcn_readfirstlane((dyi * kND) * plane * 2) + dxi * plane * 2, 0);
+        }
+    }
+#endif
+}
+
+// ---- forward, third form (round 6): the second form walking down a column of 4 x 32 tiles ------------------------------
+// Ablation of the second form (32 x 256 x 512, 4 pairs, 48 us): without the copies 31, without the output 28, without both
+// 15 -- the parts ADD, and each memory part runs at the memory system's rate while it runs (145 MB window + tile reads,
+// 67 of them from HBM, in ~15 us; 85 MB of stores in ~17): every workgroup of the launch copies, then computes, then
+// stores, in step with all the others.  Here a workgroup keeps the window ROWS in a ring of 16 and walks down its column:
+// a further tile needs 4 new rows (window traffic 3.4 x -> 1.6 x the source) and their copies -- asynchronous, no
+// registers -- are issued BEFORE the current tile is computed and stored, so that the three parts overlap inside every
+// workgroup.  One barrier per tile.
+//   window : [16 ring rows][32 channel slots][6 cells = 48 pixels from x0 - 8]   (3072 B per row; a slot = 3 units of 32 B)
+//   x1 tile: 2 x [32 channel slots][4 rows][4 cells] + 2 cells                    (288 B per slot = 9 units)
+// Cells start at multiples of 8 pixels of the IMAGE (x0 is a multiple of 32): with W % 8 == 0 a cell is inside or outside
+// as a whole -- no fix-up pass.  Same operands, MFMAs, T tile values and rounding as the other two forms: identical bits.
+struct FwdWalkCfg {
+    static constexpr int TW = 32, TH = 4, NSEG = TW / 16, DS = 2, NCH = 32, RR = 16;
+    static constexpr int WCELL = 6, WSLOT = WCELL * 16, WROW = NCH * WSLOT;   // 96 B, 3072 B
+    static constexpr int WIN_B = RR * WROW;                                    // 49152
+    static constexpr int GRP_INST = TH * WROW / 1024;                          // 12 copy instructions per group of 4 rows
+    static constexpr int XSLOT = TH * (TW / 8) * 16 + 32, X1_B = NCH * XSLOT;  // 288 B, 9216 B
+    static constexpr int X1_INST = X1_B / 1024;                                // 9
+    static constexpr int TP = 37;                                              // T row pitch in floats: 5 mod 8
+    static constexpr int T_DUMP = 352, T_B = 1664;                             // floats 352 .. 399: the lanes without a wanted entry (see the kernel)
+    static constexpr int DPW = (kND + DS - 1) / DS;
+    static constexpr int NWAVE = TH * DS, THREADS = 64 * NWAVE;
+    static constexpr int ST_PER_DY = (kND + 3) / 4;                            // store instructions per displacement row: 4 planes each
+    static constexpr size_t LDS_BYTES = WIN_B + 2 * X1_B + NWAVE * T_B;
+    static_assert((TH * WROW) % 1024 == 0 && X1_B % 1024 == 0, "whole copy instructions");
+    static_assert((WSLOT / 32) % 2 == 1 && (XSLOT / 32) % 2 == 1, "odd slot strides");
+    static_assert(2 * LDS_BYTES <= 160 * 1024, "two workgroups per CU");
+    static_assert(DPW * ST_PER_DY < 50 && NSEG == 2 && ST_PER_DY == 3, "the counted wait fits vmcnt; the loop body is written out for two segments");
+    static_assert(T_B % 128 == 0 && T_DUMP % 32 == 0 && T_DUMP >= kND * TP + 16 && (T_DUMP + 48) * 4 <= T_B && (WIN_B + 2 * X1_B) % 128 == 0,
+                  "a T tile starts at bank 0; the dump slots behind the live ones");
+};
+
+template <int N> __device__ __forceinline__ void mfma_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// at most n (wave-uniform) vector-memory operations of this wave still outstanding
+__device__ __forceinline__ void mfma_wait_vmcnt_upto(int n) {
+    switch (n) {
+#define W(k) case k: mfma_wait_vmcnt<k>(); break;
+        W(0) W(1) W(2) W(3) W(4) W(5) W(6) W(7) W(8) W(9) W(10) W(11) W(12) W(13) W(14) W(15) W(16) W(17) W(18) W(19)
+        W(20) W(21) W(22) W(23) W(24) W(25) W(26) W(27) W(28) W(29) W(30) W(31) W(32) W(33) W(34) W(35) W(36) W(37) W(38) W(39)
+        W(40) W(41) W(42) W(43) W(44) W(45) W(46) W(47) W(48) W(49)
+#undef W
+        default: mfma_wait_vmcnt<50>(); break;
+    }
+}
+
+// LDS accesses the compiler must not see as such: after an LDS-DMA it makes every ds_read / ds_write it knows of wait for
+// the copy (it cannot tell the ring rows being filled from the ones being read), which would serialise exactly what this
+// kernel overlaps.  Inline asm, in-order per wave, lgkmcnt by hand (the waited values are tied to the wait).
+template <int OFF> __device__ __forceinline__ u2v asm_tr_read(unsigned addr) {
+    u2v d;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
+    return d;
+}
+template <int OFF> __device__ __forceinline__ float asm_lds_read(unsigned addr) {
+    float d;
+    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
+    return d;
+}
+typedef float f2v __attribute__((ext_vector_type(2)));
+template <int OFF0> __device__ __forceinline__ f2v asm_lds_read2(unsigned addr) {      // dwords OFF0, OFF0 + 1 behind addr
+    f2v d;
+    asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(d) : "v"(addr), "n"(OFF0), "n"(OFF0 + 1));
+    return d;
+}
+template <int OFF> __device__ __forceinline__ void asm_lds_write(unsigned addr, float v) {
+    asm volatile("ds_write_b32 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF) : "memory");
+}
+template <int N> __device__ __forceinline__ void asm_lgkm_wait(u2v &a, u2v &b) {
+    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N));
+}
+
+// MAXFORM: 0 < slope <= 1, LeakyReLU as max(v, v * slope) -- the same value as v > 0 ? v : v * slope for every input
+// (slope 0 is not: -Inf * 0 = NaN), two instructions instead of three per value
+template <typename T, bool MAXFORM>
+__global__ __launch_bounds__(FwdWalkCfg::THREADS, 2) void corr_fwd_d4_mfma_walk_kernel(
+    const T *__restrict__ x1, const T *__restrict__ x2, T *__restrict__ out, int C, int H, int W,
+    int tiles_x, int tiles_y, int nwalk, float slope, int64_t out_bstride, int dbg) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#ifndef CERB_ABLATE
+    dbg = 0;
+#endif
+    using K = FwdWalkCfg;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    unsigned char *win = lds, *x1t = lds + K::WIN_B;
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+
+    const int walks_y = (tiles_y + nwalk - 1) / nwalk;
+    int bid = xcd_chunk(blockIdx.x, gridDim.x);
+    const int tx = __builtin_amdgcn_readfirstlane(bid % tiles_x); bid /= tiles_x;
+    const int wy = __builtin_amdgcn_readfirstlane(bid % walks_y);
+    const int b = __builtin_amdgcn_readfirstlane(bid / walks_y);
+    const int x0 = tx * K::TW, ystart = wy * nwalk * K::TH;
+    const int ntile = min(nwalk, tiles_y - wy * nwalk);            // (uniform)
+    const int plane = H * W;
+    const __amdgpu_buffer_rsrc_t r1 = uniform_rsrc(x1 + static_cast<int64_t>(b) * C * plane, C * plane * 2);
+    const __amdgpu_buffer_rsrc_t r2 = uniform_rsrc(x2 + static_cast<int64_t>(b) * C * plane, C * plane * 2);
+    auto channel_of = [](int slot) { return (slot & 0x13) | ((slot & 4) << 1) | ((slot & 8) >> 1); };
+
+    // ---- the copy plan: fixed per lane; a tile only moves the rows ----
+    // window group (4 rows): instruction k (0..11) fills bytes 1024 k.. of the group; this wave issues k = wave and wave + 8
+    int w_col[2], w_row[2];       // source byte offset without the row term (kDead: nothing to copy); row inside the group
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int cell = 64 * (wave + K::NWAVE * i) + lane;
+        const int rowin = cell / (K::NCH * K::WCELL), rem = cell - rowin * (K::NCH * K::WCELL);
+        const int slot = rem / K::WCELL, cc = rem - slot * K::WCELL;
+        const int ch = channel_of(slot), gx = x0 - 8 + 8 * cc;
+        w_row[i] = rowin;
+        w_col[i] = (ch < C && gx >= 0 && gx + 8 <= W) ? (ch * plane + gx) * 2 : kDead;
+    }
+    // x1 tile: instruction k (0..8); this wave issues k = (wave + 4) % 8 and, wave 4 only, k = 8
+    int x_col[2], x_row[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int k = i == 0 ? ((wave + 4) & 7) : 8;
+        const int cell = 64 * k + lane;
+        const int slot = cell / (K::XSLOT / 16), r = cell - slot * (K::XSLOT / 16);
+        const int rowin = r >> 2, cc = r & 3;
+        const int ch = channel_of(slot), gx = x0 + 8 * cc;
+        x_row[i] = rowin;
+        x_col[i] = (r < 16 && ch < C && gx + 8 <= W) ? (ch * plane + gx) * 2 : kDead;
+    }
+    auto issue_rows = [&](int gy0, int ring_row) {      // image rows gy0 .. gy0 + 3 -> ring rows ring_row .. + 3 (uniform arguments)
+        if (dbg & 1) return;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int k = wave + K::NWAVE * i;
+            if (k >= K::GRP_INST) break;
+            const int gy = gy0 + w_row[i];
+            const int voff = (w_col[i] != kDead && gy >= 0 && gy < H) ? w_col[i] + gy * W * 2 : kDead;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(r2, (lds_dma_ptr)(win + ring_row * K::WROW + k * 1024), 16, voff, 0, 0, 0);
+        }
+    };
+    auto issue_x1 = [&](int gy0, int buf) {
+        if (dbg & 1) return;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            if (i == 1 && wave != 4) break;
+            const int k = i == 0 ? ((wave + 4) & 7) : 8;
+            const int gy = gy0 + x_row[i];
+            const int voff = (x_col[i] != kDead && gy < H) ? x_col[i] + gy * W * 2 : kDead;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(r1, (lds_dma_ptr)(x1t + buf * K::X1_B + k * 1024), 16, voff, 0, 0, 0);
+        }
+    };
+
+    // ---- this wave's row / displacement rows; operand addresses ----
+    const int p = lane & 15, kg = lane >> 4;
+    const int row = wave % K::TH, part = wave / K::TH;
+    const int dy_lo = part * K::DPW, dy_hi = min(kND, (part + 1) * K::DPW);
+    const int slot0 = (p >> 2) + 4 * (kg & 1) + 16 * (kg >> 1);
+    const unsigned lds0 = static_cast<unsigned>(reinterpret_cast<size_t>((__attribute__((address_space(3))) unsigned char *)lds));
+    const unsigned xa = lds0 + K::WIN_B + slot0 * K::XSLOT + row * (K::TW * 2) + 8 * (p & 3);
+    const unsigned wb = lds0 + slot0 * K::WSLOT + 8 * (p & 3) + 8;          // (+ 8: window column 4 is x0 - 4)
+    const unsigned tt = lds0 + K::WIN_B + 2 * K::X1_B + wave * K::T_B;
+    const float inv_nelems = 1.0f / static_cast<float>(C);
+    const int64_t obs = out_bstride ? out_bstride : static_cast<int64_t>(kND * kND) * plane;
+    const __amdgpu_buffer_rsrc_t ro = uniform_rsrc(out + b * obs, kND * kND * plane * 2);
+    const bool low = kg < 2;
+    // T tile: float dxi * TP + m holds displacement dxi of pixel m.  Pitch 37 (5 mod 8): the lanes of a 32-lane half that
+    // hold a wanted entry write 32 different banks; a lane without one writes the dump slot of the bank it WOULD have hit.
+    unsigned t_slot[4];        // byte addresses (segment s: + 64)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int dxi = p - 4 * (kg & 1) - j;
+        const int nat = dxi * K::TP + 4 * kg + j;
+        t_slot[j] = tt + 4 * ((dxi >= 0 && dxi < kND) ? nat : K::T_DUMP + (nat & 31));
+    }
+    // read-back / stores: lane = (plane 4 i + sub, pixels 2 pp, 2 pp + 1): ds_read2_b32 (lanes 0-15 even banks, 16-31 odd), one dword store
+    const int st_pp = lane & 15, st_sub = lane >> 4;
+    const int st_col = x0 + 2 * st_pp < W ? (st_sub * plane + x0 + 2 * st_pp) * 2 : kDead;
+    const unsigned t_rd = tt + 4 * (st_sub * K::TP + 2 * st_pp);
+    const unsigned t_rd_last = tt + 4 * ((kND - 1) * K::TP + 2 * st_pp);
+
+    // ---- prologue: the first tile's 12 rows and its x1 tile ----
+    issue_rows(ystart - kD, 0);
+    issue_rows(ystart - kD + 4, 4);
+    issue_rows(ystart - kD + 8, 8);
+    issue_x1(ystart, 0);
+    int stores_behind = 0;     // this wave's stores issued after its youngest copies
+    for (int t = 0; t < ntile; ++t) {
+        const int y0 = ystart + K::TH * t, y = y0 + row;
+        mfma_wait_vmcnt_upto(stores_behind);     // in order: everything older than those stores -- the copies -- has landed
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (t + 1 < ntile) {                     // the next tile's rows replace the ring rows tile t - 1 read first
+            issue_rows(y0 + K::TH + kD, (4 * t + 12) & (K::RR - 1));
+            issue_x1(y0 + K::TH, (t + 1) & 1);
+        }
+        u4v a[K::NSEG];
+        {
+            const unsigned xat = xa + (t & 1) * K::X1_B;
+            u2v a0 = asm_tr_read<0>(xat), a1 = asm_tr_read<8 * K::XSLOT>(xat);
+            u2v a2 = asm_tr_read<32>(xat), a3 = asm_tr_read<8 * K::XSLOT + 32>(xat);
+            asm_lgkm_wait<0>(a0, a1);
+            asm_lgkm_wait<0>(a2, a3);
+            a[0] = u4v{a0.x, a0.y, a1.x, a1.y};
+            a[1] = u4v{a2.x, a2.y, a3.x, a3.y};
+        }
+        const int st_voff = (st_col != kDead && y < H) ? st_col + y * W * 2 : kDead;
+        stores_behind = 0;
+#pragma unroll 1
+        for (int dyi = dy_lo; dyi < dy_hi; ++dyi) {
+            const unsigned wrow = wb + ((4 * t + row + dyi) & (K::RR - 1)) * K::WROW;
+            // operands (s, h) at window columns 4 + 16 s + 8 h ..: 8 transposing reads, an MFMA as its pair arrives
+            u2v b00 = asm_tr_read<0>(wrow), b01 = asm_tr_read<8 * K::WSLOT>(wrow);
+            u2v b10 = asm_tr_read<16>(wrow), b11 = asm_tr_read<8 * K::WSLOT + 16>(wrow);
+            u2v b20 = asm_tr_read<32>(wrow), b21 = asm_tr_read<8 * K::WSLOT + 32>(wrow);
+            u2v b30 = asm_tr_read<48>(wrow), b31 = asm_tr_read<8 * K::WSLOT + 48>(wrow);
+            f4v acc[K::NSEG][2];
+            const f4v zero = {0.f, 0.f, 0.f, 0.f};
+            asm_lgkm_wait<6>(b00, b01);
+            acc[0][0] = Mma<T>::run(a[0], u4v{b00.x, b00.y, b01.x, b01.y}, zero);
+            asm_lgkm_wait<4>(b10, b11);
+            acc[0][1] = Mma<T>::run(a[0], u4v{b10.x, b10.y, b11.x, b11.y}, zero);
+            asm_lgkm_wait<2>(b20, b21);
+            acc[1][0] = Mma<T>::run(a[1], u4v{b20.x, b20.y, b21.x, b21.y}, zero);
+            asm_lgkm_wait<0>(b30, b31);
+            acc[1][1] = Mma<T>::run(a[1], u4v{b30.x, b30.y, b31.x, b31.y}, zero);
+            if (dbg & 4) {
+                if (dyi == dy_hi - 1 && acc[0][0][0] + acc[K::NSEG - 1][1][3] == 123.f) asm_lds_write<0>(tt, 1.f);
+                continue;
+            }
+            // the wanted diagonals -> the T tile (in-order LDS per wave: the reads below see them)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                asm_lds_write<0>(t_slot[j], low ? acc[0][0][j] : acc[0][1][j]);
+                asm_lds_write<64>(t_slot[j], low ? acc[1][0][j] : acc[1][1][j]);
+            }
+            if (dbg & 8) continue;
+            // whole plane rows, four planes per instruction; scale, LeakyReLU, one rounding
+            f2v q[K::ST_PER_DY];
+            q[0] = asm_lds_read2<0>(t_rd);
+            q[1] = asm_lds_read2<4 * K::TP>(t_rd);
+            q[2] = asm_lds_read2<0>(t_rd_last);
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]));
+#pragma unroll
+            for (int i = 0; i < K::ST_PER_DY; ++i) {
+                const f2v sc = q[i] * f2v{inv_nelems, inv_nelems};
+                f2v v;
+                if constexpr (MAXFORM) {
+                    const f2v neg = sc * f2v{slope, slope};
+                    asm("v_max_f32 %0, %1, %2" : "=v"(v.x) : "v"(sc.x), "v"(neg.x));
+                    asm("v_max_f32 %0, %1, %2" : "=v"(v.y) : "v"(sc.y), "v"(neg.y));
+                } else {
+                    v = f2v{sc.x > 0.f ? sc.x : sc.x * slope, sc.y > 0.f ? sc.y : sc.y * slope};
+                }
+                __builtin_amdgcn_raw_buffer_store_b32(Mma<T>::pack2(v.x, v.y), ro, 4 * i + st_sub < kND ? st_voff : kDead,
+                                                      __builtin_amdgcn_readfirstlane((dyi * kND) * plane * 2) + (4 * i) * plane * 2, 0);
+            }
+            stores_behind += K::ST_PER_DY;
+        }
+    }
+#endif
+}
+
+template <typename T>
+int launch_fwd_mfma_walk(const void *in1, const void *in2, void *outp, const CorrGeom &g, float slope, int64_t obs,
+                         hipStream_t s) {
+    using K = FwdWalkCfg;
+    const int tiles_x = (g.W + K::TW - 1) / K::TW, tiles_y = (g.H + K::TH - 1) / K::TH;
+    // tiles per walk: as many as still leave one round of two workgroups per CU
+    const int64_t tiles = static_cast<int64_t>(g.B) * tiles_x * tiles_y;
+    int nwalk = static_cast<int>(std::min<int64_t>(tiles_y, std::max<int64_t>(1, (tiles + 511) / 512)));
+    if (const int forced = option(OPT_CORR_BWD_CSLICE)) nwalk = std::max(1, std::min(forced, tiles_y));
+    const int64_t blocks = static_cast<int64_t>(g.B) * tiles_x * ((tiles_y + nwalk - 1) / nwalk);
+    if (blocks > 0x7fffffff) return CERB_ETOOLARGE;
+    note_kernel(0, "corr_fwd_d4_mfma_walk_4x32");
+    auto go = [&](auto maxform) {
+        constexpr bool M = decltype(maxform)::value;
+        static std::atomic<uint64_t> lds_done{0};
+        if (const int rc = ensure_lds(corr_fwd_d4_mfma_walk_kernel<T, M>, K::LDS_BYTES, &lds_done)) return rc;
+        hipLaunchKernelGGL((corr_fwd_d4_mfma_walk_kernel<T, M>), dim3(static_cast<unsigned>(blocks)), dim3(K::THREADS),
+                           K::LDS_BYTES, s, static_cast<const T *>(in1), static_cast<const T *>(in2),
+                           static_cast<T *>(outp), g.C, g.H, g.W, tiles_x, tiles_y, nwalk, slope, obs, debug_mask());
+        return 0;
+    };
+    if (const int rc = (slope > 0.f && slope <= 1.f) ? go(std::true_type{}) : go(std::false_type{})) return rc;
+    return launch_status();
+}
+
+template <typename K, typename T>
+int launch_fwd_mfma_tr(const char *name, const void *in1, const void *in2, void *outp, const CorrGeom &g,
+                       float slope, int64_t obs, hipStream_t s) {
+    const int tiles_x = (g.W + K::TW - 1) / K::TW, tiles_y = (g.H + K::TH - 1) / K::TH;
+    const int64_t blocks = static_cast<int64_t>(g.B) * tiles_x * tiles_y;
+    if (blocks > 0x7fffffff) return CERB_ETOOLARGE;
+    static std::atomic<uint64_t> lds_done{0};
+    if (const int rc = ensure_lds(corr_fwd_d4_mfma_tr_kernel<K, T>, K::LDS_BYTES, &lds_done)) return rc;
+    note_kernel(0, name);
+    hipLaunchKernelGGL((corr_fwd_d4_mfma_tr_kernel<K, T>), dim3(static_cast<unsigned>(blocks)), dim3(K::THREADS),
+                       K::LDS_BYTES, s, static_cast<const T *>(in1), static_cast<const T *>(in2),
+                       static_cast<T *>(outp), g.C, g.H, g.W, tiles_x, tiles_y, slope, obs, debug_mask());
+    return launch_status();
+}
+
 template <typename K, typename T>
 int launch_fwd_mfma(const char *name, const void *in1, const void *in2, void *outp, const CorrGeom &g,
                     float slope, int64_t obs, hipStream_t s) {
@@ -913,8 +1404,22 @@ int launch_fwd_mfma(const char *name, const void *in1, const void *in2, void *ou
 template <typename T>
 int fwd_pick(const void *in1, const void *in2, void *out, const CorrGeom &g, float slope, int64_t obs,
              hipStream_t s) {
-    if (g.C <= 32)
+    if (g.C <= 32) {
+        const int v = option(OPT_CORR_FWD_VARIANT);
+        if (g.W % 8 == 0 && (v == 0 || v == 14 || v == 27))   // the third form: a column walk (26: the second form, 20: the first)
+            return launch_fwd_mfma_walk<T>(in1, in2, out, g, slope, obs, s);
+        if (g.W % 8 == 0 && v != 20 && !(v >= 21 && v <= 25))   // 20: the first form (register-staged, transposing writes)
+            return launch_fwd_mfma_tr<FwdTrCfg<2>, T>("corr_fwd_d4_mfma_tr_4x64", in1, in2, out, g, slope, obs, s);
+        switch (v) {   // tile geometry experiments (round 6)
+            case 21: return launch_fwd_mfma<FwdMfmaCfg<1, 2, 2>, T>("corr_fwd_d4_mfma_4x32_ds2", in1, in2, out, g, slope, obs, s);
+            case 22: return launch_fwd_mfma<FwdMfmaCfg<1, 1, 2>, T>("corr_fwd_d4_mfma_4x32_ds1", in1, in2, out, g, slope, obs, s);
+            case 23: return launch_fwd_mfma<FwdMfmaCfg<1, 3, 2>, T>("corr_fwd_d4_mfma_4x32_ds3", in1, in2, out, g, slope, obs, s);
+            case 24: return launch_fwd_mfma<FwdMfmaCfg<1, 1, 4>, T>("corr_fwd_d4_mfma_4x64_ds1", in1, in2, out, g, slope, obs, s);
+            case 25: return launch_fwd_mfma<FwdMfmaCfg<1, 3, 4>, T>("corr_fwd_d4_mfma_4x64_ds3", in1, in2, out, g, slope, obs, s);
+            default: break;
+        }
         return launch_fwd_mfma<FwdMfmaCfg<1>, T>("corr_fwd_d4_mfma_4x64", in1, in2, out, g, slope, obs, s);
+    }
     if (g.C <= 64)
         return launch_fwd_mfma<FwdMfmaCfg<2>, T>("corr_fwd_d4_mfma_4x32", in1, in2, out, g, slope, obs, s);
     if (g.C <= 128)
