@@ -11,7 +11,7 @@ namespace {
 // indexed by OptId (common.h)
 const char *const g_option_names[OPT_COUNT] = {
     "corr_force_generic",   // 1: always use the generic kernels
-    "corr_fwd_variant",     // 0: auto, 1..8: force a register-staged variant, 9..13: LDS-DMA, 14: matrix cores (16-bit), 15: coarse-level kernel, 16: auto without it, 17: persistent pipelined forward (-DCERB_EXPERIMENTS builds only)
+    "corr_fwd_variant",     // 0: auto, 1..8: force a register-staged variant, 9..13: LDS-DMA, 14: matrix cores (16-bit), 15: coarse-level kernel, 16: auto without it, 17: persistent pipelined forward (-DCERB_EXPERIMENTS builds only), 20 / 26: the matrix-core forward register-staged / without the walk
     "corr_bwd_variant",     // 0: auto, 1: all-81 per lane, 2/3: 3 dy groups, 4/5: LDS-DMA, 6-9: dy-streaming, 10: column walk, 11: matrix cores, row per wave (16-bit; auto: segment per wave), 12/13: strip, 14/15: coarse-level kernel forced / off
     "corr_bwd_cslice",      // 0: auto, else channels per backward workgroup (matrix-core backward: tiles per column walk)
     "corr_no_mfma",         // 1: 16-bit storage never takes the matrix-core kernels (vector kernels, auto-selected)

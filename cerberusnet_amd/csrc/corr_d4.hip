@@ -596,7 +596,7 @@ int fwd_dispatch(const void *x1, const void *x2, void *o, const CorrGeom &g, flo
     if constexpr (sizeof(T) == 2) {
         // 16-bit storage, 16 < C <= 128: the matrix-core kernel (corr_mfma.hip; 14 forces it); variants 1-8 keep the VALU kernels
         const int v = option(OPT_CORR_FWD_VARIANT);
-        if (vec && dma_ok(g) && g.C <= 128 && option(OPT_CORR_NO_MFMA) == 0 && (v == 14 || (v >= 20 && v < 30) || (v == 0 && g.C > 16)))   // <= 16 channels fill half an MFMA: no gain
+        if (vec && dma_ok(g) && g.C <= 128 && option(OPT_CORR_NO_MFMA) == 0 && (v == 14 || v == 20 || v == 26 || (v == 0 && g.C > 16)))   // <= 16 channels fill half an MFMA: no gain
             return corr_mfma_forward(x1, x2, o, g, slope, obs,
                                      std::is_same<T, __half>::value ? CERB_F16 : CERB_BF16, s);
     }

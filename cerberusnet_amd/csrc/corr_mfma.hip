@@ -39,6 +39,7 @@
 // holds it.  That can only add non-finite results, so a row with a non-finite accumulator is
 // recomputed tap by tap (see the kernel): NaN / Inf reach exactly the vector kernels' elements.
 #include <atomic>
+#include <utility>
 
 #include "common.h"
 
@@ -706,9 +707,9 @@ __global__ __launch_bounds__(BwdSegCfg::THREADS, 2) void corr_bwd_d4_mfma_seg_ke
 // prefetched -- was measured and dropped: 32x256x512 55.6 -> 53.5 us, but 32x128x256 16.4 -> 18.2
 // and 64x64x128 9.7 -> 11.3: the forward's traffic is dominated by its 81-plane output, not by
 // the window halo.)
-template <int NKB_, int DS_ = (NKB_ == 4 ? 3 : 2), int NSEG_ = 4 / NKB_>
+template <int NKB_, int DS_ = (NKB_ == 4 ? 3 : 2)>
 struct FwdMfmaCfg {
-    static constexpr int NKB = NKB_, NSEG = NSEG_, TW = 16 * NSEG, TH = 4;
+    static constexpr int NKB = NKB_, NSEG = 4 / NKB, TW = 16 * NSEG, TH = 4;
     static constexpr int PIXB = 64 * NKB;                      // bytes per pixel (all channels)
     static constexpr int WR = TH + 2 * kD, WCOL = TW + 2 * kD; // window rows / columns
     static constexpr int GRP = 4 * PIXB + 16;                  // 4 pixels + 16 bytes: see pix()
@@ -725,7 +726,7 @@ struct FwdMfmaCfg {
     static constexpr int DPW = (kND + DS - 1) / DS;            // vertical displacements per wave
     static constexpr int THREADS = 64 * TH * DS;
     static constexpr size_t LDS_BYTES = WIN_B + (X1_B > TH * DS * T_B ? X1_B : TH * DS * T_B);   // the T tiles reuse the x1 tile's LDS
-    static constexpr int MINB = NKB == 4 ? 1 : (3 * LDS_BYTES <= 160 * 1024 && 3 * THREADS <= 2048) ? 3 : 2;   // workgroups per CU
+    static constexpr int MINB = NKB == 4 ? 1 : 2;              // workgroups per CU (round 6: 4 x 32 tiles at 3 per CU for C <= 32 -- within 3 % either way)
     static_assert(NKB == 1 || NKB == 2 || NKB == 4, "channel blocks");
     // Byte offset, inside a row, of 16-byte chunk ci (8 channels) of the pixel at column col.
     // Two access patterns must both spread over the banks: the operand reads (16 lanes = 16
@@ -1101,24 +1102,28 @@ __global__ __launch_bounds__(K::THREADS, 2) void corr_fwd_d4_mfma_tr_kernel(
 //   x1 tile: 2 x [32 channel slots][4 rows][4 cells] + 2 cells                    (288 B per slot = 9 units)
 // Cells start at multiples of 8 pixels of the IMAGE (x0 is a multiple of 32): with W % 8 == 0 a cell is inside or outside
 // as a whole -- no fix-up pass.  Same operands, MFMAs, T tile values and rounding as the other two forms: identical bits.
+template <int NKB_, int DS_, int XBUF_>
 struct FwdWalkCfg {
-    static constexpr int TW = 32, TH = 4, NSEG = TW / 16, DS = 2, NCH = 32, RR = 16;
-    static constexpr int WCELL = 6, WSLOT = WCELL * 16, WROW = NCH * WSLOT;   // 96 B, 3072 B
-    static constexpr int WIN_B = RR * WROW;                                    // 49152
-    static constexpr int GRP_INST = TH * WROW / 1024;                          // 12 copy instructions per group of 4 rows
-    static constexpr int XSLOT = TH * (TW / 8) * 16 + 32, X1_B = NCH * XSLOT;  // 288 B, 9216 B
-    static constexpr int X1_INST = X1_B / 1024;                                // 9
+    static constexpr int NKB = NKB_, DS = DS_, XBUF = XBUF_;                   // 32-channel blocks; waves per row; x1 tile buffers
+    static constexpr int TW = 32, TH = 4, NSEG = TW / 16, NCH = 32 * NKB, RR = 16;
+    static constexpr int WCELL = 6, WSLOT = WCELL * 16, WROW = NCH * WSLOT;   // 96 B; 3072 B per 32 channels
+    static constexpr int WIN_B = RR * WROW;
+    static constexpr int GRP_INST = TH * WROW / 1024;                          // copy instructions per group of 4 rows
+    static constexpr int XSLOT = TH * (TW / 8) * 16 + 32, X1_B = NCH * XSLOT;  // 288 B; 9216 B per 32 channels
+    static constexpr int X1_INST = X1_B / 1024;
     static constexpr int TP = 37;                                              // T row pitch in floats: 5 mod 8
     static constexpr int T_DUMP = 352, T_B = 1664;                             // floats 352 .. 399: the lanes without a wanted entry (see the kernel)
     static constexpr int DPW = (kND + DS - 1) / DS;
     static constexpr int NWAVE = TH * DS, THREADS = 64 * NWAVE;
+    static constexpr int NI_W = (GRP_INST + NWAVE - 1) / NWAVE, NI_X = (X1_INST + NWAVE - 1) / NWAVE;   // per wave
     static constexpr int ST_PER_DY = (kND + 3) / 4;                            // store instructions per displacement row: 4 planes each
-    static constexpr size_t LDS_BYTES = WIN_B + 2 * X1_B + NWAVE * T_B;
+    static constexpr size_t LDS_BYTES = WIN_B + XBUF * X1_B + NWAVE * T_B;
+    static constexpr int MINB = 2 * LDS_BYTES <= 160 * 1024 ? 2 : 1;          // workgroups per CU
     static_assert((TH * WROW) % 1024 == 0 && X1_B % 1024 == 0, "whole copy instructions");
     static_assert((WSLOT / 32) % 2 == 1 && (XSLOT / 32) % 2 == 1, "odd slot strides");
-    static_assert(2 * LDS_BYTES <= 160 * 1024, "two workgroups per CU");
+    static_assert(LDS_BYTES <= 160 * 1024, "fits a CU");
     static_assert(DPW * ST_PER_DY < 50 && NSEG == 2 && ST_PER_DY == 3, "the counted wait fits vmcnt; the loop body is written out for two segments");
-    static_assert(T_B % 128 == 0 && T_DUMP % 32 == 0 && T_DUMP >= kND * TP + 16 && (T_DUMP + 48) * 4 <= T_B && (WIN_B + 2 * X1_B) % 128 == 0,
+    static_assert(T_B % 128 == 0 && T_DUMP % 32 == 0 && T_DUMP >= kND * TP + 16 && (T_DUMP + 48) * 4 <= T_B && (WIN_B + XBUF * X1_B) % 128 == 0,
                   "a T tile starts at bank 0; the dump slots behind the live ones");
 };
 
@@ -1143,11 +1148,6 @@ template <int OFF> __device__ __forceinline__ u2v asm_tr_read(unsigned addr) {
     asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
     return d;
 }
-template <int OFF> __device__ __forceinline__ float asm_lds_read(unsigned addr) {
-    float d;
-    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
-    return d;
-}
 typedef float f2v __attribute__((ext_vector_type(2)));
 template <int OFF0> __device__ __forceinline__ f2v asm_lds_read2(unsigned addr) {      // dwords OFF0, OFF0 + 1 behind addr
     f2v d;
@@ -1160,18 +1160,20 @@ template <int OFF> __device__ __forceinline__ void asm_lds_write(unsigned addr, 
 template <int N> __device__ __forceinline__ void asm_lgkm_wait(u2v &a, u2v &b) {
     asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N));
 }
+template <int... I, typename F> __device__ __forceinline__ void static_for(std::integer_sequence<int, I...>, F &&f) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
 
 // MAXFORM: 0 < slope <= 1, LeakyReLU as max(v, v * slope) -- the same value as v > 0 ? v : v * slope for every input
 // (slope 0 is not: -Inf * 0 = NaN), two instructions instead of three per value
-template <typename T, bool MAXFORM>
-__global__ __launch_bounds__(FwdWalkCfg::THREADS, 2) void corr_fwd_d4_mfma_walk_kernel(
+template <typename K, typename T, bool MAXFORM>
+__global__ __launch_bounds__(K::THREADS, K::MINB) void corr_fwd_d4_mfma_walk_kernel(
     const T *__restrict__ x1, const T *__restrict__ x2, T *__restrict__ out, int C, int H, int W,
     int tiles_x, int tiles_y, int nwalk, float slope, int64_t out_bstride, int dbg) {
 #if defined(__HIP_DEVICE_COMPILE__)
 #ifndef CERB_ABLATE
     dbg = 0;
 #endif
-    using K = FwdWalkCfg;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     unsigned char *win = lds, *x1t = lds + K::WIN_B;
     const int tid = threadIdx.x;
@@ -1187,13 +1189,13 @@ __global__ __launch_bounds__(FwdWalkCfg::THREADS, 2) void corr_fwd_d4_mfma_walk_
     const int plane = H * W;
     const __amdgpu_buffer_rsrc_t r1 = uniform_rsrc(x1 + static_cast<int64_t>(b) * C * plane, C * plane * 2);
     const __amdgpu_buffer_rsrc_t r2 = uniform_rsrc(x2 + static_cast<int64_t>(b) * C * plane, C * plane * 2);
-    auto channel_of = [](int slot) { return (slot & 0x13) | ((slot & 4) << 1) | ((slot & 8) >> 1); };
+    auto channel_of = [](int slot) { return (slot & ~0xc) | ((slot & 4) << 1) | ((slot & 8) >> 1); };   // (its own inverse)
 
     // ---- the copy plan: fixed per lane; a tile only moves the rows ----
-    // window group (4 rows): instruction k (0..11) fills bytes 1024 k.. of the group; this wave issues k = wave and wave + 8
-    int w_col[2], w_row[2];       // source byte offset without the row term (kDead: nothing to copy); row inside the group
+    // window group (4 rows): instruction k fills bytes 1024 k.. of the group; this wave issues k = wave + NWAVE i
+    int w_col[K::NI_W], w_row[K::NI_W];   // source byte offset without the row term (kDead: nothing to copy); row inside the group
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < K::NI_W; ++i) {
         const int cell = 64 * (wave + K::NWAVE * i) + lane;
         const int rowin = cell / (K::NCH * K::WCELL), rem = cell - rowin * (K::NCH * K::WCELL);
         const int slot = rem / K::WCELL, cc = rem - slot * K::WCELL;
@@ -1201,22 +1203,20 @@ __global__ __launch_bounds__(FwdWalkCfg::THREADS, 2) void corr_fwd_d4_mfma_walk_
         w_row[i] = rowin;
         w_col[i] = (ch < C && gx >= 0 && gx + 8 <= W) ? (ch * plane + gx) * 2 : kDead;
     }
-    // x1 tile: instruction k (0..8); this wave issues k = (wave + 4) % 8 and, wave 4 only, k = 8
-    int x_col[2], x_row[2];
+    // x1 tile: instruction k = (wave + NWAVE / 2) % NWAVE + NWAVE i (the waves with fewer window copies first)
+    int x_col[K::NI_X], x_row[K::NI_X];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int k = i == 0 ? ((wave + 4) & 7) : 8;
-        const int cell = 64 * k + lane;
+    for (int i = 0; i < K::NI_X; ++i) {
+        const int cell = 64 * ((wave + K::NWAVE / 2) % K::NWAVE + K::NWAVE * i) + lane;
         const int slot = cell / (K::XSLOT / 16), r = cell - slot * (K::XSLOT / 16);
-        const int rowin = r >> 2, cc = r & 3;
-        const int ch = channel_of(slot), gx = x0 + 8 * cc;
-        x_row[i] = rowin;
+        const int ch = channel_of(slot), gx = x0 + 8 * (r & 3);
+        x_row[i] = r >> 2;
         x_col[i] = (r < 16 && ch < C && gx + 8 <= W) ? (ch * plane + gx) * 2 : kDead;
     }
     auto issue_rows = [&](int gy0, int ring_row) {      // image rows gy0 .. gy0 + 3 -> ring rows ring_row .. + 3 (uniform arguments)
         if (dbg & 1) return;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < K::NI_W; ++i) {
             const int k = wave + K::NWAVE * i;
             if (k >= K::GRP_INST) break;
             const int gy = gy0 + w_row[i];
@@ -1227,9 +1227,9 @@ __global__ __launch_bounds__(FwdWalkCfg::THREADS, 2) void corr_fwd_d4_mfma_walk_
     auto issue_x1 = [&](int gy0, int buf) {
         if (dbg & 1) return;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            if (i == 1 && wave != 4) break;
-            const int k = i == 0 ? ((wave + 4) & 7) : 8;
+        for (int i = 0; i < K::NI_X; ++i) {
+            const int k = (wave + K::NWAVE / 2) % K::NWAVE + K::NWAVE * i;
+            if (k >= K::X1_INST) break;
             const int gy = gy0 + x_row[i];
             const int voff = (x_col[i] != kDead && gy < H) ? x_col[i] + gy * W * 2 : kDead;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(r1, (lds_dma_ptr)(x1t + buf * K::X1_B + k * 1024), 16, voff, 0, 0, 0);
@@ -1244,7 +1244,7 @@ __global__ __launch_bounds__(FwdWalkCfg::THREADS, 2) void corr_fwd_d4_mfma_walk_
     const unsigned lds0 = static_cast<unsigned>(reinterpret_cast<size_t>((__attribute__((address_space(3))) unsigned char *)lds));
     const unsigned xa = lds0 + K::WIN_B + slot0 * K::XSLOT + row * (K::TW * 2) + 8 * (p & 3);
     const unsigned wb = lds0 + slot0 * K::WSLOT + 8 * (p & 3) + 8;          // (+ 8: window column 4 is x0 - 4)
-    const unsigned tt = lds0 + K::WIN_B + 2 * K::X1_B + wave * K::T_B;
+    const unsigned tt = lds0 + K::WIN_B + K::XBUF * K::X1_B + wave * K::T_B;
     const float inv_nelems = 1.0f / static_cast<float>(C);
     const int64_t obs = out_bstride ? out_bstride : static_cast<int64_t>(kND * kND) * plane;
     const __amdgpu_buffer_rsrc_t ro = uniform_rsrc(out + b * obs, kND * kND * plane * 2);
@@ -1270,45 +1270,58 @@ __global__ __launch_bounds__(FwdWalkCfg::THREADS, 2) void corr_fwd_d4_mfma_walk_
     issue_rows(ystart - kD + 8, 8);
     issue_x1(ystart, 0);
     int stores_behind = 0;     // this wave's stores issued after its youngest copies
+    constexpr int NOP = 4 * K::NKB;    // operand (pairs of transposing reads) per displacement row: (s, h, kb)
     for (int t = 0; t < ntile; ++t) {
         const int y0 = ystart + K::TH * t, y = y0 + row;
         mfma_wait_vmcnt_upto(stores_behind);     // in order: everything older than those stores -- the copies -- has landed
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (t + 1 < ntile) {                     // the next tile's rows replace the ring rows tile t - 1 read first
+        if (K::XBUF == 2 && t + 1 < ntile) {     // the next tile's rows replace the ring rows tile t - 1 read first
             issue_rows(y0 + K::TH + kD, (4 * t + 12) & (K::RR - 1));
             issue_x1(y0 + K::TH, (t + 1) & 1);
         }
-        u4v a[K::NSEG];
+        u4v a[K::NSEG][K::NKB];
         {
-            const unsigned xat = xa + (t & 1) * K::X1_B;
-            u2v a0 = asm_tr_read<0>(xat), a1 = asm_tr_read<8 * K::XSLOT>(xat);
-            u2v a2 = asm_tr_read<32>(xat), a3 = asm_tr_read<8 * K::XSLOT + 32>(xat);
-            asm_lgkm_wait<0>(a0, a1);
-            asm_lgkm_wait<0>(a2, a3);
-            a[0] = u4v{a0.x, a0.y, a1.x, a1.y};
-            a[1] = u4v{a2.x, a2.y, a3.x, a3.y};
+            const unsigned xat = xa + (K::XBUF == 2 ? (t & 1) * K::X1_B : 0);
+            u2v lo[K::NSEG * K::NKB], hi[K::NSEG * K::NKB];
+            static_for(std::make_integer_sequence<int, K::NSEG * K::NKB>{}, [&](auto I) {
+                constexpr int s = I / K::NKB, kb = I % K::NKB;
+                lo[I] = asm_tr_read<32 * s + kb * 32 * K::XSLOT>(xat);
+                hi[I] = asm_tr_read<32 * s + kb * 32 * K::XSLOT + 8 * K::XSLOT>(xat);
+            });
+            static_for(std::make_integer_sequence<int, K::NSEG * K::NKB>{}, [&](auto I) {
+                asm_lgkm_wait<0>(lo[I], hi[I]);
+                a[I / K::NKB][I % K::NKB] = u4v{lo[I].x, lo[I].y, hi[I].x, hi[I].y};
+            });
+        }
+        if (K::XBUF == 1) {                      // one x1 buffer: it is free once every wave holds its operands
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (t + 1 < ntile) {
+                issue_rows(y0 + K::TH + kD, (4 * t + 12) & (K::RR - 1));
+                issue_x1(y0 + K::TH, 0);
+            }
         }
         const int st_voff = (st_col != kDead && y < H) ? st_col + y * W * 2 : kDead;
         stores_behind = 0;
 #pragma unroll 1
         for (int dyi = dy_lo; dyi < dy_hi; ++dyi) {
             const unsigned wrow = wb + ((4 * t + row + dyi) & (K::RR - 1)) * K::WROW;
-            // operands (s, h) at window columns 4 + 16 s + 8 h ..: 8 transposing reads, an MFMA as its pair arrives
-            u2v b00 = asm_tr_read<0>(wrow), b01 = asm_tr_read<8 * K::WSLOT>(wrow);
-            u2v b10 = asm_tr_read<16>(wrow), b11 = asm_tr_read<8 * K::WSLOT + 16>(wrow);
-            u2v b20 = asm_tr_read<32>(wrow), b21 = asm_tr_read<8 * K::WSLOT + 32>(wrow);
-            u2v b30 = asm_tr_read<48>(wrow), b31 = asm_tr_read<8 * K::WSLOT + 48>(wrow);
+            // operand (s, h, kb) at window columns 4 + 16 s + 8 h .., channels 32 kb ..: two transposing reads each, all in
+            // flight, an MFMA as its pair arrives (kb ascending into one accumulator: the first form's order)
+            u2v blo[NOP], bhi[NOP];
+            static_for(std::make_integer_sequence<int, NOP>{}, [&](auto I) {
+                constexpr int o = I / K::NKB, kb = I % K::NKB;
+                blo[I] = asm_tr_read<16 * o + kb * 32 * K::WSLOT>(wrow);
+                bhi[I] = asm_tr_read<16 * o + kb * 32 * K::WSLOT + 8 * K::WSLOT>(wrow);
+            });
             f4v acc[K::NSEG][2];
-            const f4v zero = {0.f, 0.f, 0.f, 0.f};
-            asm_lgkm_wait<6>(b00, b01);
-            acc[0][0] = Mma<T>::run(a[0], u4v{b00.x, b00.y, b01.x, b01.y}, zero);
-            asm_lgkm_wait<4>(b10, b11);
-            acc[0][1] = Mma<T>::run(a[0], u4v{b10.x, b10.y, b11.x, b11.y}, zero);
-            asm_lgkm_wait<2>(b20, b21);
-            acc[1][0] = Mma<T>::run(a[1], u4v{b20.x, b20.y, b21.x, b21.y}, zero);
-            asm_lgkm_wait<0>(b30, b31);
-            acc[1][1] = Mma<T>::run(a[1], u4v{b30.x, b30.y, b31.x, b31.y}, zero);
+            static_for(std::make_integer_sequence<int, NOP>{}, [&](auto I) {
+                constexpr int o = I / K::NKB, kb = I % K::NKB, s = o >> 1, h = o & 1;
+                asm_lgkm_wait<2 * (NOP - 1 - I)>(blo[I], bhi[I]);
+                acc[s][h] = Mma<T>::run(a[s][kb], u4v{blo[I].x, blo[I].y, bhi[I].x, bhi[I].y},
+                                        kb == 0 ? f4v{0.f, 0.f, 0.f, 0.f} : acc[s][h]);
+            });
             if (dbg & 4) {
                 if (dyi == dy_hi - 1 && acc[0][0][0] + acc[K::NSEG - 1][1][3] == 123.f) asm_lds_write<0>(tt, 1.f);
                 continue;
@@ -1346,23 +1359,22 @@ __global__ __launch_bounds__(FwdWalkCfg::THREADS, 2) void corr_fwd_d4_mfma_walk_
 #endif
 }
 
-template <typename T>
-int launch_fwd_mfma_walk(const void *in1, const void *in2, void *outp, const CorrGeom &g, float slope, int64_t obs,
-                         hipStream_t s) {
-    using K = FwdWalkCfg;
+template <typename K, typename T>
+int launch_fwd_mfma_walk(const char *name, const void *in1, const void *in2, void *outp, const CorrGeom &g, float slope,
+                         int64_t obs, hipStream_t s) {
     const int tiles_x = (g.W + K::TW - 1) / K::TW, tiles_y = (g.H + K::TH - 1) / K::TH;
-    // tiles per walk: as many as still leave one round of two workgroups per CU
-    const int64_t tiles = static_cast<int64_t>(g.B) * tiles_x * tiles_y;
-    int nwalk = static_cast<int>(std::min<int64_t>(tiles_y, std::max<int64_t>(1, (tiles + 511) / 512)));
+    // tiles per walk: as many as still leave one round of resident workgroups
+    const int64_t tiles = static_cast<int64_t>(g.B) * tiles_x * tiles_y, round = 256 * K::MINB;
+    int nwalk = static_cast<int>(std::min<int64_t>(tiles_y, std::max<int64_t>(1, (tiles + round - 1) / round)));
     if (const int forced = option(OPT_CORR_BWD_CSLICE)) nwalk = std::max(1, std::min(forced, tiles_y));
     const int64_t blocks = static_cast<int64_t>(g.B) * tiles_x * ((tiles_y + nwalk - 1) / nwalk);
     if (blocks > 0x7fffffff) return CERB_ETOOLARGE;
-    note_kernel(0, "corr_fwd_d4_mfma_walk_4x32");
+    note_kernel(0, name);
     auto go = [&](auto maxform) {
         constexpr bool M = decltype(maxform)::value;
         static std::atomic<uint64_t> lds_done{0};
-        if (const int rc = ensure_lds(corr_fwd_d4_mfma_walk_kernel<T, M>, K::LDS_BYTES, &lds_done)) return rc;
-        hipLaunchKernelGGL((corr_fwd_d4_mfma_walk_kernel<T, M>), dim3(static_cast<unsigned>(blocks)), dim3(K::THREADS),
+        if (const int rc = ensure_lds(corr_fwd_d4_mfma_walk_kernel<K, T, M>, K::LDS_BYTES, &lds_done)) return rc;
+        hipLaunchKernelGGL((corr_fwd_d4_mfma_walk_kernel<K, T, M>), dim3(static_cast<unsigned>(blocks)), dim3(K::THREADS),
                            K::LDS_BYTES, s, static_cast<const T *>(in1), static_cast<const T *>(in2),
                            static_cast<T *>(outp), g.C, g.H, g.W, tiles_x, tiles_y, nwalk, slope, obs, debug_mask());
         return 0;
@@ -1404,24 +1416,22 @@ int launch_fwd_mfma(const char *name, const void *in1, const void *in2, void *ou
 template <typename T>
 int fwd_pick(const void *in1, const void *in2, void *out, const CorrGeom &g, float slope, int64_t obs,
              hipStream_t s) {
+    // round 6: W % 8 == 0 and C <= 64 take the column walk (LDS-DMA, transposing reads); corr_fwd_variant 20 keeps the
+    // register-staged form of rounds 4-5 (also: other widths, 65 .. 128 channels), 26 the walk's stand-still form (C <= 32)
+    const int v = option(OPT_CORR_FWD_VARIANT);
+    const bool cells = g.W % 8 == 0 && v != 20;
     if (g.C <= 32) {
-        const int v = option(OPT_CORR_FWD_VARIANT);
-        if (g.W % 8 == 0 && (v == 0 || v == 14 || v == 27))   // the third form: a column walk (26: the second form, 20: the first)
-            return launch_fwd_mfma_walk<T>(in1, in2, out, g, slope, obs, s);
-        if (g.W % 8 == 0 && v != 20 && !(v >= 21 && v <= 25))   // 20: the first form (register-staged, transposing writes)
+        if (cells && v == 26)
             return launch_fwd_mfma_tr<FwdTrCfg<2>, T>("corr_fwd_d4_mfma_tr_4x64", in1, in2, out, g, slope, obs, s);
-        switch (v) {   // tile geometry experiments (round 6)
-            case 21: return launch_fwd_mfma<FwdMfmaCfg<1, 2, 2>, T>("corr_fwd_d4_mfma_4x32_ds2", in1, in2, out, g, slope, obs, s);
-            case 22: return launch_fwd_mfma<FwdMfmaCfg<1, 1, 2>, T>("corr_fwd_d4_mfma_4x32_ds1", in1, in2, out, g, slope, obs, s);
-            case 23: return launch_fwd_mfma<FwdMfmaCfg<1, 3, 2>, T>("corr_fwd_d4_mfma_4x32_ds3", in1, in2, out, g, slope, obs, s);
-            case 24: return launch_fwd_mfma<FwdMfmaCfg<1, 1, 4>, T>("corr_fwd_d4_mfma_4x64_ds1", in1, in2, out, g, slope, obs, s);
-            case 25: return launch_fwd_mfma<FwdMfmaCfg<1, 3, 4>, T>("corr_fwd_d4_mfma_4x64_ds3", in1, in2, out, g, slope, obs, s);
-            default: break;
-        }
+        if (cells)
+            return launch_fwd_mfma_walk<FwdWalkCfg<1, 2, 2>, T>("corr_fwd_d4_mfma_walk_4x32", in1, in2, out, g, slope, obs, s);
         return launch_fwd_mfma<FwdMfmaCfg<1>, T>("corr_fwd_d4_mfma_4x64", in1, in2, out, g, slope, obs, s);
     }
-    if (g.C <= 64)
+    if (g.C <= 64) {
+        if (cells)   // 64 channel slots: one workgroup of 12 waves (3 per row) per CU
+            return launch_fwd_mfma_walk<FwdWalkCfg<2, 3, 2>, T>("corr_fwd_d4_mfma_walk_4x32_c64", in1, in2, out, g, slope, obs, s);
         return launch_fwd_mfma<FwdMfmaCfg<2>, T>("corr_fwd_d4_mfma_4x32", in1, in2, out, g, slope, obs, s);
+    }
     if (g.C <= 128)
         return launch_fwd_mfma<FwdMfmaCfg<4>, T>("corr_fwd_d4_mfma_4x16", in1, in2, out, g, slope, obs, s);
     return CERB_EUNSUPPORTED;

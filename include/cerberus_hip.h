@@ -246,7 +246,11 @@ int cerberus_area_pyramid(const void *src, void *const *dsts, const int *out_h, 
  *                          row) workgroups), 16 = auto without it, 17 = the persistent, cross-item pipelined forward
  *                          (fp32, C % 8 == 0: corr_fwd_pipe.hip; built and measured in round 5, slower than the tile
  *                          kernels: -DCERB_EXPERIMENTS builds only since round 6; with it, "corr_bwd_cslice" > 0 sets
- *                          its number of workgroups)
+ *                          its number of workgroups); round 6, 16-bit storage with W % 8 == 0: 16 < C <= 64 take the
+ *                          column-walk form of the matrix-core forward (LDS-DMA tiles, ds_read_b64_tr_b16 operands;
+ *                          corr_mfma.hip) -- 20 = the register-staged form of rounds 4-5 instead (what other widths and
+ *                          65 .. 128 channels use), 26 = the walk's stand-still form (4 x 64 tiles, C <= 32); all three
+ *                          give identical bits; with them "corr_bwd_cslice" > 0 sets the tiles per walk
  *   "corr_bwd_variant"   : 0 = auto, 1 = all 81 displacements per lane (register-staged),
  *                          3 = three displacement groups, 4 / 5 = LDS-DMA with the 8x64 /
  *                          16x32 tile (fp32, W % 4 == 0), 8 = displacement-row streaming,

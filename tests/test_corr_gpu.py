@@ -793,16 +793,17 @@ def test_mfma_backward_keeps_nonfinite_values_local(dtype):
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 def test_mfma_forward_column_walk_equals_the_register_staged_form_bit_for_bit(dtype):
-    """Round 6: the matrix-core forward for 16 < C <= 32, W % 8 == 0 keeps its tiles in LDS as they lie in memory (LDS-DMA,
+    """Round 6: the matrix-core forward for 16 < C <= 64, W % 8 == 0 keeps its tiles in LDS as they lie in memory (LDS-DMA,
     no registers), takes the MFMA operands with the transposing read ds_read_b64_tr_b16 and walks down a column of 4 x 32
     tiles with the window rows in a ring, the next tile's copies in flight behind the current tile's MFMAs and stores
-    (`corr_fwd_d4_mfma_walk_4x32`); variant 26 is the same without the walk (4 x 64 tiles, `..._tr_4x64`), variant 20 the
-    register-staged form of rounds 4-5.  Same operands, same MFMAs, same rounding: identical bits -- every border, ragged
+    (`corr_fwd_d4_mfma_walk_4x32`, `..._c64` with 64 channel slots); variant 26 is the same without the walk (4 x 64 tiles,
+    C <= 32, `..._tr_4x64`), variant 20 the register-staged form of rounds 4-5.  Same operands, same MFMAs, same rounding: identical bits -- every border, ragged
     tiles, one to many tiles per walk, channel counts below 32, the fused LeakyReLU in both forms (0 < slope <= 1 is a
     max, anything else a select), the strided output, NaN / Inf in the inputs."""
     p = (4, 1, 4, 1, 1, 1)
     shapes = [(2, 32, 8, 64), (1, 20, 13, 72), (3, 24, 5, 136), (2, 32, 4, 8), (1, 17, 9, 200), (2, 32, 30, 64),
-              (1, 32, 64, 320), (2, 32, 37, 96), (1, 32, 100, 32), (1, 28, 23, 40), (4, 32, 128, 256), (1, 32, 1, 16)]
+              (1, 32, 64, 320), (2, 32, 37, 96), (1, 32, 100, 32), (1, 28, 23, 40), (4, 32, 128, 256), (1, 32, 1, 16),
+              (2, 64, 9, 72), (1, 40, 13, 40), (3, 33, 5, 136), (1, 64, 37, 96), (4, 64, 64, 128), (1, 48, 70, 32)]
     for k, shp in enumerate(shapes):
         B, C, H, W = shp
         a1, a2 = hash_uniform(shp, 2610 + k), hash_uniform(shp, 2630 + k)
@@ -813,7 +814,9 @@ def test_mfma_forward_column_walk_equals_the_register_staged_form_bit_for_bit(dt
         x1, x2 = torch.from_numpy(a1).to(dtype).to(DEV), torch.from_numpy(a2).to(dtype).to(DEV)
         for slope in ((0.1, 1.0, 0.0, 2.5, -0.5) if k < 4 else (0.1,)):
             outs = {}
-            for v, name in ((0, "corr_fwd_d4_mfma_walk_4x32"), (26, "corr_fwd_d4_mfma_tr_4x64"), (20, "corr_fwd_d4_mfma_4x64")):
+            forms = (((0, "corr_fwd_d4_mfma_walk_4x32"), (26, "corr_fwd_d4_mfma_tr_4x64"), (20, "corr_fwd_d4_mfma_4x64")) if C <= 32 else
+                     ((0, "corr_fwd_d4_mfma_walk_4x32_c64"), (20, "corr_fwd_d4_mfma_4x32")))
+            for v, name in forms:
                 _lib.set_option("corr_fwd_variant", v)
                 try:
                     outs[v] = torch.ops.cerberus.correlation_leaky(x1, x2, *p, slope)
@@ -821,15 +824,16 @@ def test_mfma_forward_column_walk_equals_the_register_staged_form_bit_for_bit(dt
                 finally:
                     _lib.set_option("corr_fwd_variant", 0)
             ref = outs[20]
-            for v in (0, 26):
+            for v in [f[0] for f in forms if f[0] != 20]:
                 assert torch.equal(torch.isnan(outs[v]), torch.isnan(ref)), (shp, slope, v)
                 keep = ~torch.isnan(ref)
                 assert torch.equal(outs[v][keep].view(torch.int16), ref[keep].view(torch.int16)), (shp, slope, v)
         buf = torch.zeros(B, 81 + 5, H, W, dtype=dtype, device=DEV)
         torch.ops.cerberus.correlation_leaky_into(buf, x1, x2, 3, *p, 0.1)
-        assert _lib.last_kernel(0) == "corr_fwd_d4_mfma_walk_4x32"
-        keep = ~torch.isnan(outs[0])
-        assert torch.equal(buf[:, 3:84][keep].view(torch.int16), outs[0][keep].view(torch.int16)), shp
+        assert _lib.last_kernel(0) == forms[0][1]
+        plain = torch.ops.cerberus.correlation_leaky(x1, x2, *p, 0.1)
+        keep = ~torch.isnan(plain)
+        assert torch.equal(buf[:, 3:84][keep].view(torch.int16), plain[keep].view(torch.int16)), shp
         assert float(buf[:, :3].abs().max()) == 0.0 and float(buf[:, 84:].abs().max()) == 0.0
     # tiles per walk forced (the option the backward's walk uses): 1, 3 and more tiles than the column has
     x1 = torch.from_numpy(hash_uniform((2, 32, 45, 96), 2660)).to(dtype).to(DEV)
