@@ -1,5 +1,6 @@
-// corr_coarse.hip -- correlation forward / backward for the COARSE pyramid levels (d = 4, W <= 64; round 6: the forward on
-// any W % 4 == 0 up to 64, the widths between 16 / 32 / 64 on the lanes of the next one).
+// corr_coarse.hip -- correlation forward / backward for the COARSE pyramid levels (d = 4, W <= 64; round 6: both on
+// any EVEN W up to 64, the widths between 16 / 32 / 64 on the lanes of the next one, half a strip at the end of a row
+// that is 2 mod 4 wide).
 //
 //   out[dy*9+dx][y][x] = leaky(1/C sum_c x1[c][y][x] * x2[c][y+dy-4][x+dx-4])
 //   (reference: correlation_cuda_kernel.cu:29-95; same sums, other order)
@@ -98,6 +99,23 @@ __device__ __forceinline__ void store_px4(T *p, f4 v) {
 }
 #endif
 
+#if defined(__HIP_DEVICE_COMPILE__)
+// two consecutive pixels (the half strips of a width that is 2 mod 4: 8-byte / 4-byte aligned)
+template <typename T>
+__device__ __forceinline__ void store_px2(T *p, float a, float b) {
+    typedef float f2v __attribute__((ext_vector_type(2)));
+    if constexpr (sizeof(T) == 4) {
+        __builtin_nontemporal_store(f2v{a, b}, reinterpret_cast<f2v *>(p));
+    } else if constexpr (std::is_same<T, __half>::value) {
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+        __builtin_nontemporal_store(__builtin_bit_cast(unsigned, __builtin_convertvector(f2v{a, b}, h2)), reinterpret_cast<unsigned *>(p));
+    } else {
+        typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+        __builtin_nontemporal_store(__builtin_bit_cast(unsigned, __builtin_convertvector(f2v{a, b}, b2)), reinterpret_cast<unsigned *>(p));
+    }
+}
+#endif
+
 template <int B, int E, typename F>
 __device__ __forceinline__ void static_for(F &&f) {
     if constexpr (B < E) {
@@ -112,9 +130,12 @@ __device__ __forceinline__ void static_for(F &&f) {
 // RAG  1: the image row is narrower than the lanes' 4 * SPR columns (any W % 4 == 0 up to that): the true width is a
 //      run-time value, the strips past the row's end load nothing -- their zeros are the zero padding their left
 //      neighbour's shift picks up -- and store nothing (round 6)
+//      2: the same for W % 4 == 2 (1216 x 352 frames: the coarsest level is 38 wide): the row's last strip is HALF a strip.
+//      Its 16-byte load brings the next row's first two pixels along: they are zeroed where the strip is the shifted
+//      operand (two selects per channel), and the outputs leave as two 8-byte halves (rows are 8-byte aligned, not 16)
 template <int SPR_, int NW_, int CB_, int RAG_ = 0>
 struct CoarseFwdCfg {
-    static constexpr bool RAG = RAG_ != 0;
+    static constexpr bool RAG = RAG_ != 0, PART = RAG_ == 2;
     static constexpr int SPR = SPR_, W = 4 * SPR_, NW = NW_, CB = CB_;
     static constexpr int KI = 16 / SPR_;          // channel groups interleaved inside a 16-lane DPP row
     static constexpr int G = 64 / SPR_;           // channel groups per wave
@@ -207,6 +228,7 @@ __global__ __launch_bounds__(K::THREADS, K::NW >= 8 ? 5 : 3) void corr_fwd_d4_co
     const __amdgpu_buffer_rsrc_t r2 = uniform_rsrc(x2 + static_cast<int64_t>(b) * C * plane, item_bytes);
     const int c0 = (wave * K::G + g) * cpl;
     const bool strip_live = !K::RAG || 4 * sx < W;
+    const bool strip_whole = !K::PART || 4 * sx + 4 <= W;     // (PART: else pixels 2, 3 of the strip belong to the next row)
     const int v1 = strip_live ? ((c0 * H + y) * W + 4 * sx) * E : kDead;
     const int v2 = strip_live ? ((c0 * H + y2) * W + 4 * sx) * E : kDead;
     const int nb = cpl / CB;
@@ -240,7 +262,12 @@ __global__ __launch_bounds__(K::THREADS, K::NW >= 8 ? 5 : 3) void corr_fwd_d4_co
         }
 #pragma unroll
         for (int i = 0; i < CB; ++i) {
-            const f4 a = widen_px4<T>(xa[set][i]), w = widen_px4<T>(xw[set][i]);
+            const f4 a = widen_px4<T>(xa[set][i]);
+            f4 w = widen_px4<T>(xw[set][i]);
+            if constexpr (K::PART) {
+                w[2] = strip_whole ? w[2] : 0.f;
+                w[3] = strip_whole ? w[3] : 0.f;
+            }
             float win[12];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -323,7 +350,13 @@ __global__ __launch_bounds__(K::THREADS, K::NW >= 8 ? 5 : 3) void corr_fwd_d4_co
         f4 q = s0 * inv;
 #pragma unroll
         for (int p = 0; p < 4; ++p) q[p] = q[p] > 0.f ? q[p] : q[p] * slope;
-        if (!K::RAG || (t % SPR) * 4 < W) store_px4<T>(orow + (t / SPR) * plane + (t % SPR) * 4, q);
+        if constexpr (K::PART) {
+            T *o = orow + (t / SPR) * plane + (t % SPR) * 4;
+            if ((t % SPR) * 4 < W) store_px2<T>(o, q[0], q[1]);
+            if ((t % SPR) * 4 + 4 <= W) store_px2<T>(o + 2, q[2], q[3]);
+        } else {
+            if (!K::RAG || (t % SPR) * 4 < W) store_px4<T>(orow + (t / SPR) * plane + (t % SPR) * 4, q);
+        }
     }
     COARSE_STAMP(6);
 #ifdef CERB_STAMP
@@ -370,7 +403,7 @@ int launch_coarse_fwd(const char *name, const void *in1, const void *in2, void *
 // No barrier before the final one, no division by a run-time value.
 template <int SPR_, int CPL_, int RAG_ = 0>
 struct CoarseBwdCfg {
-    static constexpr bool RAG = RAG_ != 0;     // as in CoarseFwdCfg: the image row is narrower than the lanes' 4 * SPR columns
+    static constexpr bool RAG = RAG_ != 0, PART = RAG_ == 2;   // as in CoarseFwdCfg: a row narrower than the lanes' 4 * SPR columns; W % 4 == 2
     static constexpr int SPR = SPR_, W = 4 * SPR_, CPL = CPL_;
     static constexpr int KI = 16 / SPR_, G = 64 / SPR_, CSET = G * CPL_;
     static constexpr int NWV = 3, NDYW = 3, THREADS = 64 * NWV;
@@ -436,7 +469,7 @@ __global__ __launch_bounds__(K::THREADS, 4) void corr_bwd_d4_coarse_kernel(
             int dx, p, right;
             if (q < 10) { right = 0; dx = q < 4 ? 0 : q < 7 ? 1 : q < 9 ? 2 : 3; p = q - (q < 4 ? 0 : q < 7 ? 4 : q < 9 ? 7 : 9); }
             else { const int r = q - 10; right = 1; dx = r < 1 ? 5 : r < 3 ? 6 : r < 6 ? 7 : 8; p = r < 1 ? 3 : r < 3 ? r + 1 : r < 6 ? r - 2 : r - 6; }
-            patch_off = dx * (SPR * 16) + (right ? (W / 4 - 1) * 16 : 0) + p * 4;      // the image row's true end
+            patch_off = dx * (SPR * 16) + (right ? (W - 4) * 4 : 0) + p * 4;      // the image row's true end
         }
 
         float acc[CPL][4];
@@ -485,7 +518,11 @@ __global__ __launch_bounds__(K::THREADS, 4) void corr_bwd_d4_coarse_kernel(
             if (ok[k]) {
 #pragma unroll
                 for (int i = 0; i < CPL; ++i) {
-                    const f4 w = xs[set][i];
+                    f4 w = xs[set][i];
+                    if constexpr (K::PART) {          // the row's last strip is half a strip: its pixels 2, 3 are the next row's
+                        w[2] = sx * 4 + 4 <= W ? w[2] : 0.f;
+                        w[3] = sx * 4 + 4 <= W ? w[3] : 0.f;
+                    }
                     float win[12];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
@@ -549,7 +586,13 @@ __global__ __launch_bounds__(K::THREADS, 4) void corr_bwd_d4_coarse_kernel(
             const int lsx = (l & 15) / K::KI, lg = (l >> 4) * K::KI + (l & 15) % K::KI;
             const int c = cs * K::CSET + lg * CPL + i;
             float *o = gdst + ((static_cast<int64_t>(b) * C + c) * H + y) * W + 4 * lsx;
-            if (!K::RAG || 4 * lsx < W) __builtin_nontemporal_store(sum * inv, reinterpret_cast<f4 *>(o));
+            if constexpr (K::PART) {
+                const f4 r = sum * inv;
+                if (4 * lsx < W) store_px2<float>(o, r[0], r[1]);
+                if (4 * lsx + 4 <= W) store_px2<float>(o + 2, r[2], r[3]);
+            } else {
+                if (!K::RAG || 4 * lsx < W) __builtin_nontemporal_store(sum * inv, reinterpret_cast<f4 *>(o));
+            }
         }
     };
     if (side == 0) run(std::integral_constant<int, 0>{});
@@ -605,6 +648,15 @@ static int coarse_forward_t(const void *in1, const void *in2, void *out, const C
         if (g.W > 16 && g.W < 32 && g.C % R32::CMULT == 0) return launch_coarse_fwd<R32, T>("corr_fwd_d4_coarse_rag32", in1, in2, out, g, slope, obs, s);
         if (g.W < 16 && g.C % R16::CMULT == 0) return launch_coarse_fwd<R16, T>("corr_fwd_d4_coarse_rag16", in1, in2, out, g, slope, obs, s);
     }
+    // widths that are 2 mod 4: half a strip at the row's end
+    using P16 = CoarseFwdCfg<4, 4, 2, 2>;
+    using P32 = CoarseFwdCfg<8, 4, 4, 2>;
+    using P64 = CoarseFwdCfg<16, 4, 4, 2>;
+    if (g.W % 4 == 2) {
+        if (g.W > 32 && g.W < 64 && g.C % P64::CMULT == 0) return launch_coarse_fwd<P64, T>("corr_fwd_d4_coarse_half64", in1, in2, out, g, slope, obs, s);
+        if (g.W > 16 && g.W < 32 && g.C % P32::CMULT == 0) return launch_coarse_fwd<P32, T>("corr_fwd_d4_coarse_half32", in1, in2, out, g, slope, obs, s);
+        if (g.W > 4 && g.W < 16 && g.C % P16::CMULT == 0) return launch_coarse_fwd<P16, T>("corr_fwd_d4_coarse_half16", in1, in2, out, g, slope, obs, s);
+    }
     return CERB_EUNSUPPORTED;
 }
 
@@ -637,6 +689,14 @@ int corr_coarse_backward(const void *in1, const void *in2, const void *gout, voi
         if (g.W > 32 && g.W < 64 && g.C % R64::CSET == 0) return launch_coarse_bwd<R64>("corr_bwd_d4_coarse_rag64", in1, in2, gout, gin1, gin2, g, s);
         if (g.W > 16 && g.W < 32 && g.C % R32::CSET == 0) return launch_coarse_bwd<R32>("corr_bwd_d4_coarse_rag32", in1, in2, gout, gin1, gin2, g, s);
         if (g.W < 16 && g.C % R16::CSET == 0) return launch_coarse_bwd<R16>("corr_bwd_d4_coarse_rag16", in1, in2, gout, gin1, gin2, g, s);
+    }
+    using P16 = CoarseBwdCfg<4, 2, 2>;
+    using P32 = CoarseBwdCfg<8, 4, 2>;
+    using P64 = CoarseBwdCfg<16, 4, 2>;
+    if (g.W % 4 == 2) {
+        if (g.W > 32 && g.W < 64 && g.C % P64::CSET == 0) return launch_coarse_bwd<P64>("corr_bwd_d4_coarse_half64", in1, in2, gout, gin1, gin2, g, s);
+        if (g.W > 16 && g.W < 32 && g.C % P32::CSET == 0) return launch_coarse_bwd<P32>("corr_bwd_d4_coarse_half32", in1, in2, gout, gin1, gin2, g, s);
+        if (g.W > 4 && g.W < 16 && g.C % P16::CSET == 0) return launch_coarse_bwd<P16>("corr_bwd_d4_coarse_half16", in1, in2, gout, gin1, gin2, g, s);
     }
     return CERB_EUNSUPPORTED;
 }

@@ -592,7 +592,7 @@ int64_t fwd_tiles(const CorrGeom &g) {
 
 template <typename T>
 int fwd_dispatch(const void *x1, const void *x2, void *o, const CorrGeom &g, float slope,
-                 int64_t obs, bool vec, hipStream_t s) {
+                 int64_t obs, bool vec, bool half, hipStream_t s) {
     if constexpr (sizeof(T) == 2) {
         // 16-bit storage, 16 < C <= 128: the matrix-core kernel (corr_mfma.hip; 14 forces it); variants 1-8 keep the VALU kernels
         const int v = option(OPT_CORR_FWD_VARIANT);
@@ -607,7 +607,7 @@ int fwd_dispatch(const void *x1, const void *x2, void *o, const CorrGeom &g, flo
         // with the loads widened (the matrix-core kernel above keeps 16 < C <= 128)
         const int v = option(OPT_CORR_FWD_VARIANT);
         const bool coarse_auto = g.W <= 64 && static_cast<int64_t>(g.B) * g.H * kND <= 2560;   // 8 pairs of 128 x 32 x 64: 12.5 vs 13.0 us
-        if (vec && dma_ok(g) && (v == 15 || (v == 0 && coarse_auto))) {
+        if ((vec || half) && dma_ok(g) && (v == 15 || (v == 0 && coarse_auto))) {
             const int dt = sizeof(T) == 4 ? CERB_F32 : std::is_same<T, __half>::value ? CERB_F16 : CERB_BF16;
             const int rc = corr_coarse_forward(x1, x2, o, g, slope, obs, dt, s);
             if (rc != CERB_EUNSUPPORTED) return rc;
@@ -736,10 +736,12 @@ int corr_d4_forward(const void *in1, const void *in2, void *out, const CorrGeom 
     if (!fast_config(g, dtype)) return CERB_EUNSUPPORTED;
     const bool vec = g.W % 4 == 0 && aligned_group(in1, dtype) && aligned_group(in2, dtype) &&
                      aligned_group(out, dtype) && (obs % 4 == 0);
+    // W % 4 == 2: the coarse-level kernels take the row's last two pixels as half a strip (corr_coarse.hip, round 6)
+    const bool half = g.W % 4 == 2 && aligned_group(in1, dtype) && aligned_group(in2, dtype) && aligned_group(out, dtype) && (obs % 2 == 0);
     switch (dtype) {
-        case CERB_F32: return fwd_dispatch<float>(in1, in2, out, g, slope, obs, vec, s);
-        case CERB_F16: return fwd_dispatch<__half>(in1, in2, out, g, slope, obs, vec, s);
-        case CERB_BF16: return fwd_dispatch<hip_bfloat16>(in1, in2, out, g, slope, obs, vec, s);
+        case CERB_F32: return fwd_dispatch<float>(in1, in2, out, g, slope, obs, vec, half, s);
+        case CERB_F16: return fwd_dispatch<__half>(in1, in2, out, g, slope, obs, vec, half, s);
+        case CERB_BF16: return fwd_dispatch<hip_bfloat16>(in1, in2, out, g, slope, obs, vec, half, s);
         default: return CERB_EUNSUPPORTED;
     }
 }

@@ -1168,7 +1168,7 @@ int launch_bwd_rows(const char *name, const void *in1, const void *in2, const vo
 
 template <typename T>
 int bwd_dispatch(const void *x1, const void *x2, const void *go, void *g1, void *g2,
-                 const CorrGeom &g, bool vec, hipStream_t s) {
+                 const CorrGeom &g, bool vec, bool half, hipStream_t s) {
     if constexpr (sizeof(T) == 2) {
         // 16-bit storage: the matrix-core kernel (corr_mfma.hip; 11: its row-per-wave form of rounds 2-4); variants 1-3 keep the VALU kernels
         const int v = option(OPT_CORR_BWD_VARIANT);
@@ -1183,7 +1183,7 @@ int bwd_dispatch(const void *x1, const void *x2, const void *go, void *g1, void 
         // dispatch without it.
         const int v = option(OPT_CORR_BWD_VARIANT);
         const int64_t coarse_wgs = static_cast<int64_t>(g.B) * 2 * g.H * (g.C / (g.W > 32 ? 16 : 32));
-        if (vec && dma_ok(g) && (v == 14 || ((v == 0 || v == 13) && g.W <= 64 && coarse_wgs <= 4096))) {   // 13 = auto, minus the strip kernel on 64-wide maps
+        if ((vec || half) && dma_ok(g) && (v == 14 || ((v == 0 || v == 13) && g.W <= 64 && coarse_wgs <= 4096))) {   // 13 = auto, minus the strip kernel on 64-wide maps
             const int rc = corr_coarse_backward(x1, x2, go, g1, g2, g, s);
             if (rc != CERB_EUNSUPPORTED) return rc;
         }
@@ -1302,10 +1302,13 @@ int corr_d4_backward(const void *in1, const void *in2, const void *gout, void *g
     const bool vec = g.W % 4 == 0 && aligned_group(in1, dtype) && aligned_group(in2, dtype) &&
                      aligned_group(gout, dtype) && aligned_group(gin1, dtype) &&
                      aligned_group(gin2, dtype);
+    // W % 4 == 2: the coarse-level kernel takes the row's last two pixels as half a strip (corr_coarse.hip, round 6)
+    const bool half = g.W % 4 == 2 && aligned_group(in1, dtype) && aligned_group(in2, dtype) && aligned_group(gout, dtype) &&
+                      aligned_group(gin1, dtype) && aligned_group(gin2, dtype);
     switch (dtype) {
-        case CERB_F32: return bwd_dispatch<float>(in1, in2, gout, gin1, gin2, g, vec, s);
-        case CERB_F16: return bwd_dispatch<__half>(in1, in2, gout, gin1, gin2, g, vec, s);
-        case CERB_BF16: return bwd_dispatch<hip_bfloat16>(in1, in2, gout, gin1, gin2, g, vec, s);
+        case CERB_F32: return bwd_dispatch<float>(in1, in2, gout, gin1, gin2, g, vec, half, s);
+        case CERB_F16: return bwd_dispatch<__half>(in1, in2, gout, gin1, gin2, g, vec, half, s);
+        case CERB_BF16: return bwd_dispatch<hip_bfloat16>(in1, in2, gout, gin1, gin2, g, vec, half, s);
         default: return CERB_EUNSUPPORTED;
     }
 }

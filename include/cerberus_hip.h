@@ -241,7 +241,7 @@ int cerberus_area_pyramid(const void *src, void *const *dsts, const int *out_h, 
  *                          9..13 = the LDS-DMA variants (fp32, W % 4 == 0) with 1, 2, 4, 8,
  *                          16 channel groups, 14 = the matrix-core kernel (fp16 / bf16 storage,
  *                          C <= 128; auto uses it for 16 < C <= 128), 15 = the coarse-level kernel (fp32, and
- *                          fp16 / bf16 storage with C > 128; W = 16 / 32 / 64 and a channel count its lane
+ *                          fp16 / bf16 storage with C > 128; any even W up to 64 -- round 6 -- and a channel count its lane
  *                          layout divides: corr_coarse.hip; auto uses it there up to 2560 (row, displacement
  *                          row) workgroups), 16 = auto without it, 17 = the persistent, cross-item pipelined forward
  *                          (fp32, C % 8 == 0: corr_fwd_pipe.hip; built and measured in round 5, slower than the tile

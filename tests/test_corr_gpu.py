@@ -1127,15 +1127,20 @@ def test_coarse_level_forward_with_16bit_storage_against_the_oracle(dtype, tol, 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, TOL), (torch.float16, 2e-3), (torch.bfloat16, 1.6e-2)])
 @pytest.mark.parametrize("shape", [(2, 128, 7, 28), (1, 256, 5, 12), (1, 128, 9, 56), (2, 64, 6, 44), (1, 128, 3, 20),
-                                   (1, 256, 4, 60), (4, 256, 14, 28), (1, 128, 2, 4), (2, 128, 5, 36)])
+                                   (1, 256, 4, 60), (4, 256, 14, 28), (1, 128, 2, 4), (2, 128, 5, 36),
+                                   (4, 256, 11, 38), (1, 256, 5, 62), (2, 128, 6, 6), (1, 128, 13, 34), (2, 256, 3, 18), (1, 128, 4, 10)])
 def test_coarse_forward_on_ragged_widths_against_the_oracle(shape, dtype, tol):
-    """Round 6: the coarse-level forward on any width that is a multiple of 4 up to 64 -- the strips past
-    the row's end load nothing (their zeros are the padding the last strip's neighbour shift reads) and store nothing --,
-    fp32 and 16-bit storage, incl. an Inf at a row's last pixel and the LeakyReLU epilogue."""
+    """Round 6: the coarse-level forward on any EVEN width up to 64 -- the strips past the row's end load
+    nothing (their zeros are the padding the last strip's neighbour shift reads) and store nothing; a width that is 2 mod 4
+    (the 38-wide coarsest level of 1216 x 352 frames) ends in HALF a strip whose load brings the next row's first two
+    pixels along: zeroed where the strip is the shifted operand, stored as two 8-byte halves --, fp32 and 16-bit storage,
+    incl. an Inf at a row's last pixel (and, behind it, at the next row's first) and the LeakyReLU epilogue."""
     B, C, H, W = shape
     x1, x2 = hash_uniform(shape, 431), hash_uniform(shape, 432)
     if dtype == torch.float32:
         x2[0, 0, H // 2, W - 1] = np.inf
+        if H > 3:
+            x2[0, 1, 1, 0] = np.nan         # the first pixel of a row: the half strip in front of it must not see it
     a, b = dev(x1).to(dtype), dev(x2).to(dtype)
     ref = oracle.corr_forward_ref(a.float().cpu().numpy(), b.float().cpu().numpy(), 4, 1, 4, 1, 1)
     _lib.set_option("corr_fwd_variant", 15)
@@ -1145,7 +1150,7 @@ def test_coarse_forward_on_ragged_widths_against_the_oracle(shape, dtype, tol):
         lk = torch.ops.cerberus.correlation_leaky(a, b, 4, 1, 4, 1, 1, 1, 0.1)
     finally:
         _lib.set_option("corr_fwd_variant", 0)
-    assert name.startswith("corr_fwd_d4_coarse_rag"), name
+    assert name.startswith("corr_fwd_d4_coarse_rag" if W % 4 == 0 else "corr_fwd_d4_coarse_half"), name
     o = out.float().cpu().numpy()
     assert np.array_equal(np.isfinite(o), np.isfinite(ref))
     ok = np.isfinite(ref)
@@ -1155,16 +1160,20 @@ def test_coarse_forward_on_ragged_widths_against_the_oracle(shape, dtype, tol):
 
 
 @pytest.mark.parametrize("shape", [(2, 128, 7, 28), (1, 256, 5, 12), (1, 128, 9, 56), (2, 64, 6, 44), (1, 128, 3, 20),
-                                   (1, 256, 4, 60), (4, 256, 14, 28), (1, 128, 2, 4), (2, 128, 5, 36), (4, 128, 28, 56)])
+                                   (1, 256, 4, 60), (4, 256, 14, 28), (1, 128, 2, 4), (2, 128, 5, 36), (4, 128, 28, 56),
+                                   (4, 256, 11, 38), (1, 256, 5, 62), (2, 128, 6, 6), (1, 128, 13, 34), (2, 256, 3, 18), (1, 128, 4, 10)])
 def test_coarse_backward_on_ragged_widths_against_the_oracle(shape):
     """The coarse-level backward on the same widths: dead strips neither load nor store, the second gradient's shifted
-    gradOutput rows are zeroed at the TRUE row end; NaN / Inf stay where the reference's sums put them."""
+    gradOutput rows are zeroed at the TRUE row end (also when that lies inside the half strip of a width that is 2 mod 4);
+    NaN / Inf stay where the reference's sums put them."""
     B, C, H, W = shape
     x1, x2 = hash_uniform(shape, 441), hash_uniform(shape, 442)
     go = hash_uniform((B, 81, H, W), 443)
     x1[0, 1, H // 2, W - 1] = np.inf
     go[0, 44, H - 1, W - 1] = np.nan
     go[0, 8, 0, 0] = -np.inf
+    if H > 3:
+        x2[0, 2, 2, 0] = np.inf             # the first pixel of a row, behind the previous row's half strip
     r1, r2 = oracle.corr_backward_ref(x1, x2, go, 4, 1, 4, 1, 1)
     _lib.set_option("corr_bwd_variant", 14)
     try:
@@ -1172,7 +1181,7 @@ def test_coarse_backward_on_ragged_widths_against_the_oracle(shape):
         name = _lib.last_kernel(1)
     finally:
         _lib.set_option("corr_bwd_variant", 0)
-    assert name.startswith("corr_bwd_d4_coarse_rag"), name
+    assert name.startswith("corr_bwd_d4_coarse_rag" if W % 4 == 0 else "corr_bwd_d4_coarse_half"), name
     assert np.array_equal(np.isnan(g1), np.isnan(r1)) and np.array_equal(np.isinf(g1), np.isinf(r1))
     assert np.array_equal(np.isnan(g2), np.isnan(r2)) and np.array_equal(np.isinf(g2), np.isinf(r2))
     ok1, ok2 = np.isfinite(r1), np.isfinite(r2)
