@@ -1550,7 +1550,7 @@ static int launch_tiles(const void *image, const void *gout, const void *ctx, vo
     nrange = std::max(1, std::min(nrange, groups));
     const int crange = (groups + nrange - 1) / nrange * CW;
     nrange = (C + crange - 1) / crange;
-    const int64_t tile_blocks = tiles * nrange;
+    const int64_t tile_blocks = gimage ? tiles * nrange : 0;     // (no grad_image: flow workgroups only)
     // grad_flow: 8 x 32 tiles through an LDS window (16-byte aligned rows, 32-bit byte
     // offsets), else 2 x 32 strips x 4 channel-group waves by direct gathers
     const Strips strips(H, W);
@@ -1627,7 +1627,9 @@ int warp_backward(const void *image, const void *flow, const void *gout, void *g
     // the forward's, or one built here in the caller's workspace
     const bool ws_ok = workspace && workspace_bytes >= warp_backward_workspace_bytes(B, C, H, W) &&
                        (reinterpret_cast<uintptr_t>(workspace) & 15) == 0;
-    const bool tiled = gimage && dtype != CERB_F64 && (ctx || ws_ok) &&
+    // (round 6: grad_flow ALONE with more than 4 channels takes the same launch with no tile workgroups -- its flow role's
+    // LDS window beats the per-pixel gathers of warp_bwd_kernel: 32 x 256 x 512 fp16 68.8 -> 30 us)
+    const bool tiled = (gimage || (gflow && C > 4)) && dtype != CERB_F64 && (ctx || ws_ok) &&
                        static_cast<int64_t>(C) * plane * static_cast<int64_t>(esz) < 0x7fffffff &&
                        option(OPT_WARP_FORCE_SCATTER) == 0;
     if (tiled) {

@@ -620,3 +620,31 @@ def test_fp32_forward_through_the_dma_window_kernel_is_bit_identical_too():
             finally:
                 _lib.set_option("warp_pair16", 0)
             assert torch.equal(out0.view(torch.int32), out1.view(torch.int32)) and torch.equal(ctx0, ctx1), (shape, pad)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
+def test_grad_flow_alone_takes_the_flow_role_of_the_tile_launch_bit_for_bit(dtype):
+    """Round 6: grad_flow WITHOUT grad_image for more than 4 channels (a frozen feature extractor) used to fall to the
+    per-pixel gather kernel -- slower than computing both (32 x 256 x 512 fp16: 68.8 us against 54.8).  It now takes the
+    tile launch with no tile workgroups (its flow role through the LDS window: 23.7 us): the bits are those of the launch
+    that computes both (the gather kernel sums its channel groups in another order: equal within rounding)."""
+    from cerberusnet_amd import _lib
+    for k, (shape, amp) in enumerate([((2, 32, 64, 128), 6.0), ((1, 19, 37, 132), 0.7), ((4, 128, 32, 64), 3.0), ((1, 8, 24, 64), 30.0),
+                                      ((2, 64, 40, 72), 2.0)]):
+        B, C, H, W = shape
+        img, go = dev(hash_uniform(shape, 3000 + k)).to(dtype), dev(hash_uniform(shape, 3010 + k)).to(dtype)
+        flo = dev(hash_uniform((B, 2, H, W), 3020 + k, -amp, amp)).to(dtype)
+        for pad in (0, 1):
+            _, ctx = torch.ops.cerberus.flow_warp_ctx(img, flo, pad, 0)
+            both = torch.ops.cerberus.flow_warp_backward_ctx(img, flo, ctx, go, pad, 0, True, True)
+            alone = torch.ops.cerberus.flow_warp_backward_ctx(img, flo, ctx, go, pad, 0, False, True)
+            bits = torch.int32 if dtype == torch.float32 else torch.int16
+            assert torch.equal(alone[1].view(bits), both[1].view(bits)), (shape, pad)
+            _lib.set_option("warp_force_scatter", 1)
+            try:
+                gather = torch.ops.cerberus.flow_warp_backward_ctx(img, flo, ctx, go, pad, 0, False, True)
+            finally:
+                _lib.set_option("warp_force_scatter", 0)
+            scale = float(gather[1].float().abs().max())
+            tol = {torch.float32: 2e-6, torch.float16: 2e-3, torch.bfloat16: 1.6e-2}[dtype]
+            assert float((alone[1].float() - gather[1].float()).abs().max()) <= tol * scale, (shape, pad)
