@@ -379,7 +379,7 @@ def _flow_warp_backward_run(image, flow, context, grad_out, pad_mode, interp_mod
     # none (caching allocator: no sync, graph-capturable; stream-ordered reuse keeps it
     # private to this call)
     ws, ws_bytes = None, 0
-    if need_image and context is None:
+    if (need_image or (need_flow and C > 4)) and context is None:   # (round 6: grad_flow alone takes the tile launch's flow role too)
         ws_bytes = lib.cerberus_flow_warp_backward_workspace_bytes(B, C, H, W)
         ws = torch.empty((ws_bytes + 7) // 8, dtype=torch.int64, device=img.device)
         _check_aligned16(ws, what, "workspace")

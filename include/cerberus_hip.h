@@ -185,7 +185,10 @@ int cerberus_warp_correlation_forward(const void *input1, const void *input2, co
  *                global atomics, bit-reproducible; NaN / Inf in grad_out reach the same
  *                elements as in ATen's scatter.  With neither (or fp64): global float atomics
  *                as ATen's (summation order not fixed).
- *   grad_flow  : (B,2,H,W), flow_dtype -- fully overwritten, deterministic
+ *   grad_flow  : (B,2,H,W), flow_dtype -- fully overwritten, deterministic.  With a context or a workspace
+ *                it comes from the LDS-window role of the tile launch -- round 6: also when grad_image is NULL
+ *                and C > 4 (the bits are the both-gradients call's); with neither, from per-pixel gathers
+ *                (another channel-group order: equal within rounding)
  *   context    : the buffer a cerberus_flow_warp_forward_ctx call with the SAME flow,
  *                shape and pad_mode filled, or NULL (the backward then derives it from the
  *                flow with one extra launch, into the workspace).
