@@ -1120,14 +1120,20 @@ def short_ops_rate(pairs, width, height, dtype, device, steps=60, warmup=10, flo
     for _ in range(warmup):
         graph.replay()
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        graph.replay()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    # three timed passes of `steps` replays each, the MEDIAN pass reported (a 20 ms window is at the mercy of one host
+    # hiccup: a default run once put the 896 x 448 pyramid at 10.9 k pairs/s with every kernel as fast as in the 12.6 k runs)
+    passes = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            graph.replay()
+        torch.cuda.synchronize()
+        passes.append(time.perf_counter() - t0)
+    dt = sorted(passes)[1]
     kern = dict(wl.kernels())
     corr_b = 2 * sum(v for k, v in kern.items() if k.startswith("corr"))
     out = {"value": round(pairs * steps / dt, 2), "unit": "image-pairs/s", "ms_per_step": round(1e3 * dt / steps, 5),
+           "passes_ms_per_step": [round(1e3 * t / steps, 5) for t in passes],
            "steps": steps, "warmup": warmup, "pairs_per_gpu": pairs, "levels_CHW": [list(x) for x in wl.levels],
            "dtype": {torch.float16: "f16", torch.bfloat16: "bf16", torch.float32: "f32"}[dtype],
            "algorithmic_bytes_per_step": 2 * sum(kern.values()),
