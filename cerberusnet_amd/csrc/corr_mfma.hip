@@ -1,4 +1,7 @@
-// corr_mfma.hip -- correlation backward for 16-bit storage (fp16 / bf16) on the matrix cores.
+// corr_mfma.hip -- the correlation for 16-bit storage (fp16 / bf16) on the matrix cores: the backward (band-matrix
+// formulation, below), and -- further down -- the forward in three forms: register-staged with transposing LDS writes
+// (rounds 4-5; today: 65 .. 128 channels and widths off a multiple of 8), tiles by LDS-DMA + ds_read_b64_tr_b16 operands
+// standing still (variant 26), and the same walking down a column of tiles (round 6, the default for 16 < C <= 64).
 //
 // Same function as corr_bwd_d4_kernel (reference: correlation_backward_input1 / _input2,
 // /root/reference/nnet_training/correlation_package/correlation_cuda_kernel.cu:97-242, at
